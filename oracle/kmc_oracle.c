@@ -1,0 +1,818 @@
+/*
+ * kmc_oracle.c -- CPU restatement of DeviceKMC's per-superstep hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle and the `cpu_baseline`
+ * ("port") leg of bench.py.  Nothing in the product path (devicekmc_amd/, include/)
+ * may link, import or call it.  It restates, in plain C + OpenMP, the semantics of
+ * the reference's CUDA path (file:line cited per function; paths are relative to
+ * /root/reference/src), with switches for the few places where the reference's CPU
+ * path differs (used only to pin the oracle against CPU-path numbers).
+ *
+ * Pinning (see oracle/README.md and tests/test_oracle_golden.py):
+ *   - X sparsity pattern == the CSR dump the reference ships
+ *     (structures/single_devices/timing_2.5nm/fullmatrix_assembly/), bit-exact;
+ *   - Current [uA] / KMC time of the reference's own CUDA-path log
+ *     (structures/single_devices/timing_7.5nm/output_noguess.txt) at 85 071 sites.
+ *
+ * Build: make -C oracle   (gcc -O2 -fopenmp -shared)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <omp.h>
+
+/* ELEMENT / EVENTTYPE enum values: utils.h:37-44, utils.h:53-60 */
+enum { DEFECT = 0, OXYGEN_DEFECT = 1, VACANCY = 2, O_EL = 3, Hf_EL = 4, Ni_EL = 5, Ti_EL = 6, Pt_EL = 7, N_EL = 8, NULL_ELEMENT = 9 };
+enum { EV_GEN = 0, EV_REC = 1, EV_VDIFF = 2, EV_IDIFF = 3, EV_NULL = 4 };
+
+static const double kB = 8.617333262e-5;      /* kmc_events.cu:4 */
+static const double Q_E = 1.60217663e-19;     /* gpu_solvers.h:261, potential_solver_gpu.cu:4 */
+static const double H_BAR = 1.054571817e-34;  /* iterative_solvers_gpu.cu:8 */
+
+/* ------------------------------------------------------------------------- */
+/* geometry: gpu_solvers.h:225-257 (site_dist_gpu), host twin utils.cpp:100-137 */
+static inline double site_dist(double x1, double y1, double z1, double x2, double y2, double z2,
+                               const double *lat, int pbc)
+{
+    if (pbc) {
+        double dx = x1 - x2;
+        double fy = (y1 - y2) / lat[1];
+        fy -= round(fy);
+        double fz = (z1 - z2) / lat[2];
+        fz -= round(fz);
+        double dy = fy * lat[1], dz = fz * lat[2];
+        return sqrt(dx * dx + dy * dy + dz * dz);
+    }
+    double dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
+    return sqrt(dx * dx + dy * dy + dz * dz);
+}
+
+double okmc_site_dist(double x1, double y1, double z1, double x2, double y2, double z2, const double *lat, int pbc)
+{
+    return site_dist(x1, y1, z1, x2, y2, z2, lat, pbc);
+}
+
+/* gpu_solvers.h:259-265 (v_solve_gpu) */
+static inline double v_solve(double r, int charge, double sigma, double k)
+{
+    return (double)charge * erfc(r / (sigma * sqrt(2.0))) * k * Q_E / r;
+}
+
+double okmc_v_solve(double r, int charge, double sigma, double k) { return v_solve(r, charge, sigma, k); }
+
+static inline int is_metal(int e, const int *metals, int nm)
+{
+    for (int t = 0; t < nm; ++t) if (metals[t] == e) return 1;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* RNG: random_num.h:4-23 -- std::mt19937 + uniform_real_distribution<double>(0,1)
+ * as libstdc++ implements it (generate_canonical<double,53>: two 32-bit draws,
+ * sum = x1 + x2 * 2^32 accumulated in double, divided by 2^64; 1.0 -> nextafter). */
+typedef struct { uint32_t mt[624]; int idx; } okmc_rng;
+
+void okmc_rng_seed(okmc_rng *r, uint32_t seed)
+{
+    r->mt[0] = seed;
+    for (int i = 1; i < 624; ++i) r->mt[i] = 1812433253u * (r->mt[i - 1] ^ (r->mt[i - 1] >> 30)) + (uint32_t)i;
+    r->idx = 624;
+}
+
+static uint32_t rng_u32(okmc_rng *r)
+{
+    if (r->idx >= 624) {
+        for (int i = 0; i < 624; ++i) {
+            uint32_t y = (r->mt[i] & 0x80000000u) | (r->mt[(i + 1) % 624] & 0x7fffffffu);
+            r->mt[i] = r->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        r->idx = 0;
+    }
+    uint32_t y = r->mt[r->idx++];
+    y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+    return y;
+}
+
+double okmc_rng_uniform(okmc_rng *r)
+{
+    double sum = (double)rng_u32(r);
+    sum += (double)rng_u32(r) * 4294967296.0;
+    double ret = sum / 18446744073709551616.0;
+    if (ret >= 1.0) ret = nextafter(1.0, 0.0);
+    return ret;
+}
+
+int okmc_rng_sizeof(void) { return (int)sizeof(okmc_rng); }
+
+/* ------------------------------------------------------------------------- */
+/* Neighbour list: Device.cpp:98-136 (O(N^2) there) + padding Device.cpp:69-80.
+ * Same result via a cell list: row i holds every j != i with dist < nn_dist in
+ * ascending j, padded with -1 to the global maximum nn.
+ * Two calls: out == NULL returns nn (max neighbours); otherwise fills out[N*nn]. */
+typedef struct { int nx, ny, nz; double x0, y0, z0, h; int *head, *next; } cells_t;
+
+static void cells_build(cells_t *c, int N, const double *x, const double *y, const double *z, double h)
+{
+    double xmin = 1e300, ymin = 1e300, zmin = 1e300, xmax = -1e300, ymax = -1e300, zmax = -1e300;
+    for (int i = 0; i < N; ++i) {
+        if (x[i] < xmin) xmin = x[i]; if (x[i] > xmax) xmax = x[i];
+        if (y[i] < ymin) ymin = y[i]; if (y[i] > ymax) ymax = y[i];
+        if (z[i] < zmin) zmin = z[i]; if (z[i] > zmax) zmax = z[i];
+    }
+    c->h = h; c->x0 = xmin; c->y0 = ymin; c->z0 = zmin;
+    c->nx = (int)((xmax - xmin) / h) + 1; c->ny = (int)((ymax - ymin) / h) + 1; c->nz = (int)((zmax - zmin) / h) + 1;
+    size_t nc = (size_t)c->nx * c->ny * c->nz;
+    c->head = (int *)malloc(nc * sizeof(int));
+    c->next = (int *)malloc((size_t)N * sizeof(int));
+    for (size_t k = 0; k < nc; ++k) c->head[k] = -1;
+    for (int i = N - 1; i >= 0; --i) {
+        int cx = (int)((x[i] - xmin) / h), cy = (int)((y[i] - ymin) / h), cz = (int)((z[i] - zmin) / h);
+        size_t k = ((size_t)cx * c->ny + cy) * c->nz + cz;
+        c->next[i] = c->head[k]; c->head[k] = i;
+    }
+}
+
+static void cells_free(cells_t *c) { free(c->head); free(c->next); }
+
+static int cmp_int(const void *a, const void *b) { int x = *(const int *)a, y = *(const int *)b; return (x > y) - (x < y); }
+
+/* collects neighbours of i (ascending) into buf, returns count */
+static int cells_query(const cells_t *c, int i, const double *x, const double *y, const double *z,
+                       const double *lat, int pbc, double cutoff, int *buf, int cap)
+{
+    int cx = (int)((x[i] - c->x0) / c->h), cy = (int)((y[i] - c->y0) / c->h), cz = (int)((z[i] - c->z0) / c->h);
+    int n = 0;
+    for (int dx = -1; dx <= 1; ++dx) {
+        int ax = cx + dx; if (ax < 0 || ax >= c->nx) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            int ay = cy + dy;
+            if (pbc) { /* periodic images may live in any cell: handled by the brute-force fallback below */ }
+            if (ay < 0 || ay >= c->ny) continue;
+            for (int dz = -1; dz <= 1; ++dz) {
+                int az = cz + dz; if (az < 0 || az >= c->nz) continue;
+                for (int j = c->head[((size_t)ax * c->ny + ay) * c->nz + az]; j >= 0; j = c->next[j]) {
+                    if (j == i) continue;
+                    if (site_dist(x[i], y[i], z[i], x[j], y[j], z[j], lat, pbc) < cutoff) { if (n < cap) buf[n] = j; ++n; }
+                }
+            }
+        }
+    }
+    if (n <= cap) qsort(buf, n, sizeof(int), cmp_int);
+    return n;
+}
+
+int okmc_build_neighbors(int N, const double *x, const double *y, const double *z, const double *lat,
+                         int pbc, double nn_dist, int nn, int *out)
+{
+    enum { CAP = 512 };
+    int maxn = 0;
+    if (pbc) { /* rare path (all shipped parameter sets use pbc = 0): literal O(N^2) restatement */
+#pragma omp parallel for reduction(max : maxn) schedule(dynamic, 64)
+        for (int i = 0; i < N; ++i) {
+            int n = 0;
+            for (int j = 0; j < N; ++j) {
+                if (j != i && site_dist(x[i], y[i], z[i], x[j], y[j], z[j], lat, pbc) < nn_dist) {
+                    if (out && n < nn) out[(size_t)i * nn + n] = j;
+                    ++n;
+                }
+            }
+            if (out) for (int s = n; s < nn; ++s) out[(size_t)i * nn + s] = -1;
+            if (n > maxn) maxn = n;
+        }
+        return maxn;
+    }
+    cells_t c; cells_build(&c, N, x, y, z, nn_dist);
+#pragma omp parallel for reduction(max : maxn) schedule(dynamic, 256)
+    for (int i = 0; i < N; ++i) {
+        int buf[CAP];
+        int n = cells_query(&c, i, x, y, z, lat, 0, nn_dist, buf, CAP);
+        if (n > maxn) maxn = n;
+        if (out) {
+            for (int s = 0; s < nn; ++s) out[(size_t)i * nn + s] = (s < n) ? buf[s] : -1;
+        }
+    }
+    cells_free(&c);
+    return maxn;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Layer of a site: KMCProcess.cpp:34-50 (last layer whose [start,end] holds x) */
+int okmc_site_layers(int N, const double *x, int nl, const double *start_x, const double *end_x, int *layer)
+{
+    for (int i = 0; i < N; ++i) {
+        int id = 1000;
+        for (int j = 0; j < nl; ++j) if (start_x[j] <= x[i] && x[i] <= end_x[j]) id = j;
+        if (id == 1000) return i + 1;
+        layer[i] = id;
+    }
+    return 0;
+}
+
+/* Device.cpp:202-233 makeSubstoichiometric (+ updateAtomLists Device.cpp:138-172) */
+int okmc_make_substoichiometric(int N, int *element, double conc, okmc_rng *rng)
+{
+    int *atom_ind = (int *)malloc((size_t)N * sizeof(int));
+    int na = 0, num_O = 0;
+    for (int i = 0; i < N; ++i) {
+        if (element[i] != DEFECT && element[i] != OXYGEN_DEFECT) atom_ind[na++] = i;
+        if (element[i] == O_EL) ++num_O;
+    }
+    int num_V_add = (int)(conc * num_O);
+    int added = num_V_add;
+    while (num_V_add > 0) {
+        double r = okmc_rng_uniform(rng);
+        int loc = (int)(r * na);
+        if (element[atom_ind[loc]] == O_EL) { element[atom_ind[loc]] = VACANCY; --num_V_add; }
+    }
+    free(atom_ind);
+    return added;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Charge rule: potential_solver_gpu.cu:10-52 (host twin potential_solver.cpp:172-217).
+ * The CUDA kernel reads element[neigh_idx[j]] for padded (-1) slots too;
+ * here padded slots are skipped, which is what the host twin does. */
+void okmc_update_charge(int N, int nn, const int *neigh, const int *element, int *charge,
+                        const int *metals, int nm)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
+        if (element[i] == VACANCY) {
+            int c = 2, vnn = 0;
+            for (int s = 0; s < nn; ++s) {
+                int j = neigh[(size_t)i * nn + s]; if (j < 0) continue;
+                if (element[j] == VACANCY) ++vnn;
+                if (is_metal(element[j], metals, nm)) c = 0;
+                if (vnn >= 2) c = 0;
+            }
+            charge[i] = c;
+        }
+        if (element[i] == OXYGEN_DEFECT) {
+            int c = -2;
+            for (int s = 0; s < nn; ++s) {
+                int j = neigh[(size_t)i * nn + s]; if (j < 0) continue;
+                if (is_metal(element[j], metals, nm)) c = 0;
+            }
+            charge[i] = c;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* K sparsity: iterative_solvers_gpu.cu:2158-2208 (Assemble_K_sparsity),
+ * :938-961/:823-851 (device block incl. diagonal: dist < cutoff with dist = 0),
+ * :1723-1785 (device x contact blocks).  Derived from the neighbour list, which
+ * holds exactly the pairs with dist < nn_dist (same cutoff is passed, kmc_main.cpp:121).
+ * which: 0 = device block (cols relative to N_left, diagonal included)
+ *        1 = left contact block (cols in [0, N_left)), 2 = right block (cols relative to N_left+m).
+ * Pass col == NULL to get counts in row_ptr only. Returns nnz. */
+int okmc_k_pattern(int N, int nn, const int *neigh, int N_left, int N_right, int which, int *row_ptr, int *col)
+{
+    int m = N - N_left - N_right;
+    int nnz = 0;
+    row_ptr[0] = 0;
+    for (int r = 0; r < m; ++r) {
+        int i = N_left + r;
+        int diag_done = (which != 0);
+        for (int s = 0; s < nn; ++s) {
+            int j = neigh[(size_t)i * nn + s]; if (j < 0) continue;
+            int c = -1;
+            if (which == 0) {
+                if (j >= N_left && j < N_left + m) {
+                    if (!diag_done && j > i) { if (col) col[nnz] = r; ++nnz; diag_done = 1; }
+                    c = j - N_left;
+                }
+            } else if (which == 1) { if (j < N_left) c = j; }
+            else { if (j >= N_left + m) c = j - (N_left + m); }
+            if (c >= 0) { if (col) col[nnz] = c; ++nnz; }
+        }
+        if (!diag_done) { if (col) col[nnz] = r; ++nnz; }
+        row_ptr[r + 1] = nnz;
+    }
+    return nnz;
+}
+
+/* conductance rule: potential_solver_gpu.cu:202-217 (cb == 0) and :239-249 (cb == 1) */
+static inline double k_conductance(int ei, int ej, int qi, int qj, const int *metals, int nm,
+                                   double high_G, double low_G, int cb)
+{
+    int m1 = is_metal(ei, metals, nm), m2 = is_metal(ej, metals, nm);
+    if (cb) return (m1 || m2) ? high_G : low_G;
+    int cv1 = (ei == VACANCY) && (qi == 0), cv2 = (ej == VACANCY) && (qj == 0);
+    return ((m1 && m2) || (cv1 && cv2)) ? high_G : low_G;
+}
+
+/* K values + rhs: Assemble_A / Assemble_A_CB (potential_solver_gpu.cu:397-593),
+ * reduce_rows_into_diag (iterative_solvers_gpu.cu:11-34), contact row reductions
+ * (potential_solver_gpu.cu:257-356), add_vector_to_diagonal (:359-375), calc_rhs_for_A (:379-393).
+ * The contact sums test dist < cutoff again; by construction of the pattern it always holds. */
+void okmc_k_assemble(int N, int N_left, int N_right, const int *element, const int *charge,
+                     const int *metals, int nm, double high_G, double low_G, int cb,
+                     const int *row_ptr, const int *col, const int *lrow_ptr, const int *lcol,
+                     const int *rrow_ptr, const int *rcol, double VL, double VR,
+                     double *data, double *rhs)
+{
+    int m = N - N_left - N_right;
+#pragma omp parallel for schedule(static)
+    for (int r = 0; r < m; ++r) {
+        int i = N_left + r;
+        double off = 0.0;
+        int dpos = -1;
+        for (int p = row_ptr[r]; p < row_ptr[r + 1]; ++p) {
+            if (col[p] == r) { dpos = p; continue; }
+            int j = N_left + col[p];
+            double g = k_conductance(element[i], element[j], charge[i], charge[j], metals, nm, high_G, low_G, cb);
+            data[p] = -g;
+            off += -g;
+        }
+        double kl = 0.0, kr = 0.0;
+        for (int p = lrow_ptr[r]; p < lrow_ptr[r + 1]; ++p) {
+            int j = lcol[p];
+            kl += k_conductance(element[i], element[j], charge[i], charge[j], metals, nm, high_G, low_G, cb);
+        }
+        for (int p = rrow_ptr[r]; p < rrow_ptr[r + 1]; ++p) {
+            int j = N_left + m + rcol[p];
+            kr += k_conductance(element[i], element[j], charge[i], charge[j], metals, nm, high_G, low_G, cb);
+        }
+        double d = -off;   /* reduce_rows_into_diag */
+        d += kl;           /* add_vector_to_diagonal (left) */
+        d += kr;           /* add_vector_to_diagonal (right) */
+        data[dpos] = d;
+        rhs[r] = kl * VL + kr * VR;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* CSR SpMV, deterministic dot */
+static void spmv(int m, const int *rp, const int *ci, const double *a, const double *x, double *y)
+{
+#pragma omp parallel for schedule(dynamic, 512)
+    for (int i = 0; i < m; ++i) {
+        double s = 0.0;
+        for (int p = rp[i]; p < rp[i + 1]; ++p) s += a[p] * x[ci[p]];
+        y[i] = s;
+    }
+}
+
+static double dot(int m, const double *a, const double *b)
+{
+    enum { CH = 4096 };
+    int nch = (m + CH - 1) / CH;
+    double *part = (double *)malloc((size_t)(nch > 0 ? nch : 1) * sizeof(double));
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < nch; ++c) {
+        int lo = c * CH, hi = lo + CH < m ? lo + CH : m;
+        double s = 0.0;
+        for (int i = lo; i < hi; ++i) s += a[i] * b[i];
+        part[c] = s;
+    }
+    double s = 0.0;
+    for (int c = 0; c < nch; ++c) s += part[c];
+    free(part);
+    return s;
+}
+
+/* Jacobi-scaled CG: iterative_solvers_gpu.cu:309-480 (solve_sparse_CG_Jacobi).
+ * A_data is overwritten with S A S, x (rhs) with S x, y is the warm start / solution.
+ * tol: the reference hard-codes 1e-6 (:322).  First test on ||r|| (nrm2, :418), later
+ * ones on ||r||^2 (:448), both against tol*tol.  Returns the iteration count. */
+int okmc_cg_jacobi(int m, const int *rp, const int *ci, double *a, double *x, double *y,
+                   double tol, int max_iter, double *final_rr)
+{
+    double *s = (double *)malloc((size_t)m * sizeof(double));
+    double *r = (double *)malloc((size_t)m * sizeof(double));
+    double *p = (double *)malloc((size_t)m * sizeof(double));
+    double *t = (double *)malloc((size_t)m * sizeof(double));
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < m; ++i) {           /* computeDiagonalInvSqrt :227-254 */
+        double d = 0.0;
+        for (int q = rp[i]; q < rp[i + 1]; ++q) if (ci[q] == i) { d = a[q]; break; }
+        s[i] = 1.0 / sqrt(d);
+    }
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < m; ++i) {
+        x[i] = x[i] * s[i];                                   /* jacobi_precondition_array :257-269 */
+        for (int q = rp[i]; q < rp[i + 1]; ++q) a[q] = a[q] * s[i] * s[ci[q]];   /* :272-291 */
+        y[i] = y[i] * 1 / s[i];                               /* jacobi_unprecondition_array :294-306 */
+    }
+    spmv(m, rp, ci, a, y, r);                                 /* r = A y */
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < m; ++i) { r[i] = -x[i] + r[i]; p[i] = -r[i]; }
+    double h_norm = sqrt(dot(m, r, r));                       /* cublasDnrm2 :418 */
+    int it = 0;
+    while (h_norm > tol * tol) {
+        double tt = dot(m, r, r);
+        spmv(m, rp, ci, a, p, t);
+        double alpha = tt / dot(m, p, t);
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < m; ++i) { y[i] += alpha * p[i]; r[i] += alpha * t[i]; }
+        double tnew = dot(m, r, r);
+        double beta = tnew / tt;
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < m; ++i) p[i] = p[i] * beta - r[i];
+        h_norm = tnew;                                        /* cublasDdot :448 */
+        ++it;
+        if (max_iter > 0 && it >= max_iter) break;
+    }
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < m; ++i) y[i] = y[i] * s[i];           /* :459 */
+    if (final_rr) *final_rr = h_norm;
+    free(s); free(r); free(p); free(t);
+    return it;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Pairwise screened Coulomb: potential_solver_gpu.cu:908-978; host twin
+ * potential_solver.cpp:412-432 (sequential ascending-j accumulation, used here). */
+void okmc_poisson_gridless(int N, const double *x, const double *y, const double *z, const double *lat,
+                           int pbc, double sigma, double k, const int *charge, double *out)
+{
+    int nc = 0;
+    int *cj = (int *)malloc((size_t)N * sizeof(int));
+    for (int j = 0; j < N; ++j) if (charge[j] != 0) cj[nc++] = j;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < N; ++i) {
+        double v = 0.0;
+        for (int c = 0; c < nc; ++c) {
+            int j = cj[c];
+            if (j == i) continue;
+            double r = 1e-10 * site_dist(x[i], y[i], z[i], x[j], y[j], z[j], lat, pbc);
+            v += v_solve(r, charge[j], sigma, k);
+        }
+        out[i] = v;
+    }
+    free(cj);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Event table: kmc_events.cu:34-126 (build_event_list); host twin KMCProcess.cpp:67-164.
+ * vdiff_layer_from_i = 0 reproduces the CUDA kernel (layer[j], kmc_events.cu:98);
+ * 1 reproduces the host code (layer[i], KMCProcess.cpp:134). */
+void okmc_build_event_list(int N, int nn, const int *neigh, const int *layer, const double *lat, int pbc,
+                           double T_bg, double freq, double sigma, double k,
+                           const double *x, const double *y, const double *z,
+                           const double *pot_b, const double *pot_c, const int *element, const int *charge,
+                           const double *E_gen, const double *E_rec, const double *E_Vdiff, const double *E_Odiff,
+                           int vdiff_layer_from_i, int *ev_type, double *ev_prob)
+{
+    size_t total = (size_t)N * nn;
+#pragma omp parallel for schedule(static)
+    for (size_t idx = 0; idx < total; ++idx) {
+        int type = EV_NULL; double P = 0.0;
+        int i = (int)(idx / nn);
+        int j = neigh[idx];
+        if (j >= 0 && j < N) {
+            double dist = 1e-10 * site_dist(x[i], y[i], z[i], x[j], y[j], z[j], lat, pbc);
+            double dphi = (pot_b[i] + pot_c[i]) - (pot_b[j] + pot_c[j]);
+            if (element[i] == DEFECT && element[j] == O_EL) {
+                double E = 2 * dphi;
+                double EA = E_gen[layer[j]] - E - 0;
+                type = EV_GEN; P = exp(-1 * EA / (kB * T_bg)) * freq;
+            }
+            if (element[i] == OXYGEN_DEFECT && element[j] == VACANCY) {
+                double self = v_solve(dist, 2, sigma, k);
+                int cs = charge[i] - charge[j];
+                double E = cs * (dphi + (cs / 2) * self);     /* integer division, kmc_events.cu:77 */
+                double EA = E_rec[layer[j]] - E - 0;
+                type = EV_REC; P = exp(-1 * EA / (kB * T_bg)) * freq;
+            }
+            if (element[i] == VACANCY && element[j] == O_EL) {
+                double self = 0.0;
+                if (charge[i] != 0) self = v_solve(dist, charge[i], sigma, k);
+                double E = (charge[i] - charge[j]) * (dphi + self);
+                double EA = E_Vdiff[layer[vdiff_layer_from_i ? i : j]] - E - 0;
+                type = EV_VDIFF; P = exp(-1 * EA / (kB * T_bg)) * freq;
+            }
+            if (element[i] == OXYGEN_DEFECT && element[j] == DEFECT) {
+                double self = 0.0;
+                if (charge[i] != 0) self = v_solve(dist, 2, sigma, k);
+                double E = (charge[i] - charge[j]) * (dphi - self);
+                double EA = E_Odiff[layer[j]] - E - 0;
+                type = EV_IDIFF; P = exp(-1 * EA / (kB * T_bg)) * freq;
+            }
+        }
+        ev_type[idx] = type; ev_prob[idx] = P;
+    }
+}
+
+/* Residence-time loop: kmc_events.cu:210-349 with the deterministic sequential prefix
+ * sum of the host engine (utils.h:91-99, KMCProcess.cpp:303-358).  Random numbers are
+ * drawn from `rng` exactly as the reference does (2 per executed event).
+ * evlog (optional, 4 ints per event): event_idx, i, j, type.  margin (optional, per event):
+ * min(|number - cum[idx-1]|, |cum[idx] - number|) / Psum, to flag draws that land within
+ * rounding distance of a bucket edge.  Returns the number of executed events. */
+int okmc_execute_events(int N, int nn, const int *neigh, int *ev_type, double *ev_prob, double freq,
+                        int *element, int *charge, okmc_rng *rng, int max_events,
+                        int *evlog, double *margin, double *psum_log, double *event_time_out)
+{
+    size_t total = (size_t)N * nn;
+    double *cum = (double *)malloc(total * sizeof(double));
+    double event_time = 0.0;
+    int count = 0;
+    while (event_time < 1 / freq) {
+        if (max_events > 0 && count >= max_events) break;
+        cum[0] = ev_prob[0];
+        for (size_t q = 1; q < total; ++q) cum[q] = cum[q - 1] + ev_prob[q];
+        double Psum = cum[total - 1];
+        double number = okmc_rng_uniform(rng) * Psum;
+        /* std::upper_bound: first idx with cum[idx] > number */
+        size_t lo = 0, hi = total;
+        while (lo < hi) { size_t mid = lo + (hi - lo) / 2; if (!(number < cum[mid])) lo = mid + 1; else hi = mid; }
+        size_t event_idx = lo;
+        if (event_idx >= total) { /* Psum == 0: the reference would read out of bounds; stop */
+            event_time = INFINITY; break;
+        }
+        int type = ev_type[event_idx];
+        int i = (int)(event_idx / nn);
+        int j = neigh[event_idx];
+        if (evlog) { evlog[4 * count] = (int)event_idx; evlog[4 * count + 1] = i; evlog[4 * count + 2] = j; evlog[4 * count + 3] = type; }
+        if (margin) {
+            double below = event_idx ? cum[event_idx - 1] : 0.0;
+            double a = number - below, b = cum[event_idx] - number;
+            margin[count] = (a < b ? a : b) / Psum;
+        }
+        if (psum_log) psum_log[count] = Psum;
+        switch (type) {             /* kmc_events.cu:249-320 */
+        case EV_GEN:   element[i] = OXYGEN_DEFECT; element[j] = VACANCY; charge[i] = -2; charge[j] = 2; break;
+        case EV_REC:   element[i] = DEFECT; element[j] = O_EL; charge[i] = 0; charge[j] = 0; break;
+        case EV_VDIFF:
+        case EV_IDIFF: { int te = element[i]; element[i] = element[j]; element[j] = te;
+                         int tc = charge[i]; charge[i] = charge[j]; charge[j] = tc; } break;
+        default: break;
+        }
+        /* zero_out_events kmc_events.cu:129-143 + rows i and j (:342-345) */
+#pragma omp parallel for schedule(static)
+        for (size_t q = 0; q < total; ++q) {
+            int i_ = (int)(q / nn), j_ = neigh[q];
+            if (i_ == i || j_ == j || i_ == j || j_ == i) { ev_type[q] = EV_NULL; ev_prob[q] = 0.0; }
+        }
+        event_time = -log(okmc_rng_uniform(rng)) / Psum;
+        ++count;
+    }
+    free(cum);
+    *event_time_out = event_time;
+    return count;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Site -> atom compaction: current_solver_gpu.cu:8-14, :869-879 (copy_if with is_defect) */
+int okmc_compact_atoms(int N, const int *element, int *atom_site)
+{
+    int na = 0;
+    for (int i = 0; i < N; ++i) if (element[i] != DEFECT && element[i] != OXYGEN_DEFECT) atom_site[na++] = i;
+    return na;
+}
+
+/* atom-level neighbour rows (ascending atom index, -1 padded) from the site neighbour list */
+void okmc_atom_neighbors(int N, int nn, const int *neigh, int Na, const int *atom_site, int *atom_neigh)
+{
+    int *site_atom = (int *)malloc((size_t)N * sizeof(int));
+    for (int i = 0; i < N; ++i) site_atom[i] = -1;
+    for (int a = 0; a < Na; ++a) site_atom[atom_site[a]] = a;
+#pragma omp parallel for schedule(static)
+    for (int a = 0; a < Na; ++a) {
+        int n = 0; const int *row = neigh + (size_t)atom_site[a] * nn;
+        for (int s = 0; s < nn; ++s) { int j = row[s]; if (j >= 0 && site_atom[j] >= 0) atom_neigh[(size_t)a * nn + n++] = site_atom[j]; }
+        for (; n < nn; ++n) atom_neigh[(size_t)a * nn + n] = -1;
+    }
+    free(site_atom);
+}
+
+/* tunnelling-pair predicate shared by pattern and value kernels:
+ * iterative_solvers_gpu.cu:887-912 / :1095-1121 (pattern, bound = Natom) and :1624-1646 (values,
+ * bound = N_full = Natom + 2).  a, b are atom indices. Returns 0 none, 1 contact_to_trap, 2 other. */
+static inline int tunnel_kind(int a, int b, const int *ael, const double *acb, const int *metals, int nm,
+                              int nlc, int n_src, int n_gnd, int bound, double tol)
+{
+    int v1 = ael[a] == VACANCY, v2 = ael[b] == VACANCY;
+    int m1p = is_metal(ael[a], metals, nm) && (a > (nlc - 1) * n_src) && (a < bound - (nlc - 1) * n_gnd);
+    int m2p = is_metal(ael[b], metals, nm) && (b > (nlc - 1) * n_src) && (b < bound - (nlc - 1) * n_gnd);
+    int t2t = v1 && v2, c2t = (v1 && m2p) || (v2 && m1p), c2c = m1p && m2p;
+    double drop = acb[a] - acb[b];
+    if ((t2t || c2t || c2c) && (fabs(drop) > tol)) return c2t ? 1 : 2;
+    return 0;
+}
+
+/* X sparsity: Assemble_X_sparsity (iterative_solvers_gpu.cu:1909-1983) with
+ * calc_nnz_per_row_X_gpu (:855-936) and assemble_X_indices_gpu (:1016-1127).
+ * Nodes: 0 extraction driver, 1 injection driver, a + 2 = atom a; the last atom (ground) is
+ * dropped, so Nsub = Na + 1 rows.  Columns ascend within a row.
+ * atom_neigh: per atom, its neighbouring ATOM indices ascending, -1 padded (ann wide).
+ * Call with col == NULL to get row_ptr / nnz only.  Returns nnz (64-bit). */
+long long okmc_x_pattern(int Na, int ann, const int *atom_neigh, const int *ael, const double *acb,
+                         const int *metals, int nm, double tol, int n_src, int n_gnd, int nlc,
+                         int *row_ptr, int *col)
+{
+    int N_full = Na + 2, Nsub = Na + 1;
+    /* tunnelling candidates: vacancies and inner-contact metals (bound = Natom in the pattern kernels) */
+    int *S = (int *)malloc((size_t)Na * sizeof(int)); int ns = 0;
+    for (int a = 0; a < Na - 1; ++a) {
+        int mp = is_metal(ael[a], metals, nm) && (a > (nlc - 1) * n_src) && (a < Na - (nlc - 1) * n_gnd);
+        if (ael[a] == VACANCY || mp) S[ns++] = a;
+    }
+    char *inS = (char *)calloc((size_t)Na, 1);
+    for (int q = 0; q < ns; ++q) inS[S[q]] = 1;
+    int *cnt = (int *)calloc((size_t)Nsub + 1, sizeof(int));
+    int nthr = omp_get_max_threads();
+    char *marks = (char *)calloc((size_t)nthr * Na, 1);
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && !col) break;
+#pragma omp parallel for schedule(dynamic, 64)
+        for (int i = 0; i < Nsub; ++i) {
+            char *mark = marks + (size_t)omp_get_thread_num() * Na;
+            int n = 0; int *out = (pass == 1) ? col + row_ptr[i] : NULL;
+            if (i == 0) {
+                for (int j = 0; j < N_full - 1; ++j) if (j < 2 || j > N_full - n_gnd) { if (out) out[n] = j; ++n; }
+            } else if (i == 1) {
+                for (int j = 0; j < n_src + 2; ++j) { if (out) out[n] = j; ++n; }
+            } else {
+                int a = i - 2;
+                if (i > N_full - n_gnd) { if (out) out[n] = 0; ++n; }      /* extraction column */
+                if (i < n_src + 2) { if (out) out[n] = 1; ++n; }          /* injection column */
+                /* merge: neighbours (ascending) U {a} U tunnel partners (ascending over S) */
+                int pn = 0, ps = 0; int self_done = 0;
+                const int *nb = atom_neigh + (size_t)a * ann;
+                if (inS[a]) for (int s = 0; s < ann && nb[s] >= 0; ++s) mark[nb[s]] = 1;
+                for (;;) {
+                    int jn = -1; while (pn < ann && nb[pn] >= 0 && nb[pn] >= Na - 1) ++pn;   /* skip ground atom */
+                    if (pn < ann && nb[pn] >= 0) jn = nb[pn];
+                    int js = -1;
+                    if (inS[a]) {
+                        while (ps < ns) {
+                            int b = S[ps];
+                            if (b == a) { ++ps; continue; }
+                            /* neighbour pairs are "direct terms", not tunnelling */
+                            if (!mark[b] && tunnel_kind(a, b, ael, acb, metals, nm, nlc, n_src, n_gnd, Na, tol)) break;
+                            ++ps;
+                        }
+                        if (ps < ns) js = S[ps];
+                    }
+                    int jd = self_done ? -1 : a;
+                    int best = -1;
+                    if (jn >= 0) best = jn;
+                    if (js >= 0 && (best < 0 || js < best)) best = js;
+                    if (jd >= 0 && (best < 0 || jd < best)) best = jd;
+                    if (best < 0) break;
+                    if (out) out[n] = best + 2; ++n;
+                    if (best == jn) ++pn;
+                    if (best == js) ++ps;
+                    if (best == jd) self_done = 1;
+                }
+                if (inS[a]) for (int s = 0; s < ann && nb[s] >= 0; ++s) mark[nb[s]] = 0;
+            }
+            cnt[i] = n;
+        }
+        if (pass == 0) {
+            long long acc = 0; row_ptr[0] = 0;
+            for (int i = 0; i < Nsub; ++i) { acc += cnt[i]; if (acc > 2147483647LL) { acc = -1; break; } row_ptr[i + 1] = (int)acc; }
+            if (acc < 0) { free(S); free(inS); free(cnt); free(marks); return -1; }
+        }
+    }
+    long long nnz = row_ptr[Nsub];
+    free(S); free(inS); free(cnt); free(marks);
+    return nnz;
+}
+
+/* X values: populate_sparse_X_gpu2 (iterative_solvers_gpu.cu:1525-1721) + calc_diagonal_X_gpu
+ * (:2053-2076).  Positions are atom positions; data must hold nnz doubles. */
+void okmc_x_values(int Na, const double *ax, const double *ay, const double *az, const int *ael,
+                   const int *aq, const double *acb, const double *lat, int pbc, double nn_dist,
+                   const int *metals, int nm, double tol, double high_G, double low_G, double loop_G,
+                   double m_e, double V0, int n_src, int n_gnd, int nlc,
+                   const int *row_ptr, const int *col, double *data)
+{
+    int N_full = Na + 2, Nsub = Na + 1, N_atom = Na;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int i = 0; i < Nsub; ++i) {
+        for (int p = row_ptr[i]; p < row_ptr[i + 1]; ++p) {
+            int c = col[p];
+            double v = 0.0;                                        /* cudaMemset 0, :2130 */
+            if (i == 0) {
+                if (c == 0) v = +high_G;
+                if (c == 1) v = -loop_G;
+                if (c > N_full - n_gnd) v = -high_G;
+            }
+            if (i == 1) {
+                if (c == 0) v = -loop_G;
+                if (c >= 2 || (c > N_full - n_gnd)) v = -high_G;
+            }
+            if (i >= 2) {
+                int a = i - 2;
+                if (i == c) {
+                    double d = site_dist(ax[a], ay[a], az[a], ax[N_atom - 1], ay[N_atom - 1], az[N_atom - 1], lat, pbc);
+                    if (d < nn_dist) v = +high_G;
+                }
+                if (c == 0 && i > N_full - n_gnd) v = -high_G;
+                if (c == 1 && i < n_src + 2) v = -high_G;
+                if (c >= 2 && c != i) {
+                    int b = c - 2;
+                    double dA = site_dist(ax[a], ay[a], az[a], ax[b], ay[b], az[b], lat, pbc);
+                    int neighbor = dA < nn_dist;
+                    if (!neighbor) {
+                        int kind = tunnel_kind(a, b, ael, acb, metals, nm, nlc, n_src, n_gnd, N_full, tol);
+                        if (kind) {
+                            double drop = fabs(acb[a] - acb[b]);
+                            double prefac = -(sqrt(2 * m_e) / H_BAR) * (2.0 / 3.0);
+                            double dist = 1e-10 * dA;
+                            if (kind == 1) {
+                                double dE = Q_E * 0.01, T = 0.0;
+                                for (double iv = 0; iv < drop; iv += dE) {
+                                    double E1 = Q_E * V0 + iv, E2 = E1 - drop;
+                                    if (E2 > 0) T += exp(prefac * (dist / drop) * (pow(E1, 1.5) - pow(E2, 1.5)));
+                                    if (E2 < 0) T += exp(prefac * (dist / drop) * (pow(E1, 1.5)));
+                                }
+                                v = -T;
+                            } else {
+                                double E1 = Q_E * V0, E2 = E1 - drop;
+                                if (E2 > 0) v = -exp(prefac * (dist / fabs(E1 - E2)) * (pow(E1, 1.5) - pow(E2, 1.5)));
+                                if (E2 < 0) v = -exp(prefac * (dist / fabs(E1 - E2)) * (pow(E1, 1.5)));
+                            }
+                        }
+                    } else {
+                        int m1 = is_metal(ael[a], metals, nm), m2 = is_metal(ael[b], metals, nm);
+                        int cv1 = (ael[a] == VACANCY) && (aq[a] == 0), cv2 = (ael[b] == VACANCY) && (aq[b] == 0);
+                        v = ((m1 && m2) || (cv1 && cv2)) ? -high_G : -low_G;
+                    }
+                }
+            }
+            data[p] = v;
+        }
+        /* calc_diagonal_X_gpu: diag += -sum(off-diagonals) */
+        double tmp = 0.0; int dpos = -1;
+        for (int p = row_ptr[i]; p < row_ptr[i + 1]; ++p) { if (col[p] != i) tmp += data[p]; else dpos = p; }
+        if (dpos >= 0) data[dpos] += -tmp;
+    }
+}
+
+/* I_macro: get_imacro_sparse (current_solver_gpu.cu:781-821): injected current through row 1.
+ * m already scaled by G0 (:1015-1016). */
+double okmc_imacro_row1(const int *row_ptr, const int *col, const double *data, const double *m)
+{
+    double s = 0.0;
+    for (int p = row_ptr[1] + 2; p < row_ptr[2]; ++p) if (col[p] >= 2) s += data[p] * (m[col[p]] - m[1]);
+    return s;
+}
+
+/* CPU-path variant (current_solver.cpp:254-263): extracted current through row 0, including the
+ * ground atom (m = 0) with conductance high_G that the sparse form folds into X[0,0]. */
+double okmc_imacro_row0(const int *row_ptr, const int *col, const double *data, const double *m, double high_G)
+{
+    double s = 0.0;
+    for (int p = row_ptr[0]; p < row_ptr[1]; ++p) if (col[p] >= 2) s += data[p] * (m[0] - m[col[p]]);
+    s += -high_G * (m[0] - 0.0);
+    return s;
+}
+
+/* Dissipated power on X's pattern, host formula current_solver.cpp:288-357 restricted to the
+ * atoms kept in the sparse system (rows/cols >= 2; the ground atom is not in the pattern).
+ * m (length Na + 2, already * G0) is shifted in place by |min(m[2..Na+1])| like update_m
+ * (current_solver_gpu.cu:447-457, :1044-1047; the never-solved last entry takes part).
+ * site_power[atom_site[a]] = -alpha * P[a] for non-metal atoms (copy_pdisp :460-472). */
+void okmc_dissipated_power(int Na, const int *row_ptr, const int *col, const double *data, double *m,
+                           double Vd, const int *ael, const int *atom_site, const int *metals, int nm,
+                           double alpha, double *site_power)
+{
+    double minv = m[2];
+    for (int i = 2; i < Na + 2; ++i) if (m[i] < minv) minv = m[i];
+    for (int i = 0; i < Na + 2; ++i) m[i] += fabs(minv);
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int i = 2; i < Na + 1; ++i) {
+        int a = i - 2;
+        /* row a of I_neg: off-diagonals -I_cal where the bond current is "forward"; diagonal = -sum(off) */
+        double p = 0.0, diag = 0.0;
+        for (int q = row_ptr[i]; q < row_ptr[i + 1]; ++q) {
+            int c = col[q]; if (c < 2 || c == i) continue;
+            double ical = data[q] * (m[i] - m[c]);
+            double v = 0.0;
+            if ((ical < 0 && Vd > 0) || (ical > 0 && Vd < 0)) v = -ical;
+            diag += -v;
+            p += v * m[c];
+        }
+        p += diag * m[i];
+        if (!is_metal(ael[a], metals, nm)) site_power[atom_site[a]] = -1 * alpha * p;
+    }
+}
+
+/* Global temperature.  mode 0: as run by the reference (host, heat_solver.cpp:322-334);
+ * mode 1: the unused device kernel (heat_solver_gpu.cu:42-48). */
+double okmc_temperature_global(int N, const double *site_power, double T_bg, double step_time, int mode,
+                               double dissipation_constant, double background_temp, double t_ox, double A,
+                               double c_p, double small_step, double *P_tot_out)
+{
+    double C = A * t_ox * c_p * 1e6, P = 0.0;
+    for (int i = 0; i < N; ++i) P += site_power[i];
+    if (P_tot_out) *P_tot_out = P;
+    if (mode == 0) {
+        double a = dissipation_constant / C;
+        double c = (dissipation_constant / C) * T_bg + (1 / C) * P;
+        return (c / a) + (T_bg - c / a) * exp(-a * step_time);
+    }
+    double number_steps = step_time / small_step;
+    double a = -dissipation_constant * 1 / C * small_step + 1;
+    double b = dissipation_constant * 1 / C * small_step * background_temp;
+    double c = b + P / C * small_step;
+    int step = (int)number_steps;
+    return c * (1.0 - pow(a, (double)step)) / (1.0 - a) + pow(a, (double)step) * T_bg;
+}

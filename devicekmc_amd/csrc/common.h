@@ -1,0 +1,148 @@
+// common.h -- shared device helpers and the process-wide engine state (one GPU per process).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include "../../include/devicekmc_hip.h"
+
+// ELEMENT / EVENTTYPE (utils.h:37-60)
+enum { DEFECT = 0, OXYGEN_DEFECT = 1, VACANCY = 2, O_EL = 3, Hf_EL = 4, Ni_EL = 5, Ti_EL = 6, Pt_EL = 7, N_EL = 8, NULL_ELEMENT = 9 };
+enum { EV_GEN = 0, EV_REC = 1, EV_VDIFF = 2, EV_IDIFF = 3, EV_NULL = 4 };
+
+#define DKMC_KB 8.617333262e-5       // kmc_events.cu:4
+#define DKMC_Q 1.60217663e-19        // gpu_solvers.h:261
+#define DKMC_HBAR 1.054571817e-34    // iterative_solvers_gpu.cu:8
+#define DKMC_MAX_METALS 8
+#define DKMC_MAX_LAYERS 5            // kmc_events.cu:7
+#define WAVE 64
+
+struct MetalSet { int n; int e[DKMC_MAX_METALS]; };
+
+__device__ __forceinline__ bool is_metal(int el, const MetalSet &ms)
+{
+    bool r = false;
+#pragma unroll
+    for (int t = 0; t < DKMC_MAX_METALS; ++t) r |= (t < ms.n) && (ms.e[t] == el);
+    return r;
+}
+
+// gpu_solvers.h:225-257
+__device__ __forceinline__ double site_dist(double x1, double y1, double z1, double x2, double y2, double z2,
+                                            double laty, double latz, int pbc)
+{
+    if (pbc) {
+        double dx = x1 - x2;
+        double fy = (y1 - y2) / laty; fy -= round(fy);
+        double fz = (z1 - z2) / latz; fz -= round(fz);
+        double dy = fy * laty, dz = fz * latz;
+        return sqrt(dx * dx + dy * dy + dz * dz);
+    }
+    double dx = x2 - x1, dy = y2 - y1, dz = z2 - z1;
+    return sqrt(dx * dx + dy * dy + dz * dz);
+}
+
+// gpu_solvers.h:259-265
+__device__ __forceinline__ double v_solve(double r, int charge, double sigma, double k)
+{
+    return (double)charge * erfc(r / (sigma * sqrt(2.0))) * k * DKMC_Q / r;
+}
+
+// ---- wave64 / block reductions with a fixed combination order (deterministic) -----------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+    return v;   // valid in lane 0
+}
+__device__ __forceinline__ double wave_sum_all(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;   // same value in every lane
+}
+__device__ __forceinline__ int wave_sum_all_i(int v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+// inclusive scan across the wave
+__device__ __forceinline__ double wave_scan_incl(double v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) { double t = __shfl_up(v, off, WAVE); if (lane >= off) v += t; }
+    return v;
+}
+__device__ __forceinline__ int wave_scan_incl_i(int v, int lane)
+{
+#pragma unroll
+    for (int off = 1; off < WAVE; off <<= 1) { int t = __shfl_up(v, off, WAVE); if (lane >= off) v += t; }
+    return v;
+}
+
+// block sum, result broadcast to all threads; red must hold blockDim.x/64 doubles
+template <int NT>
+__device__ __forceinline__ double block_sum_all(double v, double *red)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < NT / 64; ++i) s += red[i];
+    return s;
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+struct Arena {
+    char *base = nullptr; size_t cap = 0, off = 0;
+};
+
+struct Engine {
+    hipStream_t stream = nullptr;
+    int device = 0;
+    double cg_tol = 1e-6;
+    int current_warm_start = 0;
+    dkmc_stats stats{};
+    char err[512] = {0};
+    int err_code = 0;
+    // per-layer energies (copytoConstMemory)
+    double E_gen[DKMC_MAX_LAYERS] = {0}, E_rec[DKMC_MAX_LAYERS] = {0}, E_Vdiff[DKMC_MAX_LAYERS] = {0}, E_Odiff[DKMC_MAX_LAYERS] = {0};
+    int num_layers = 0;
+    // pinned host mailbox for small D2H reads
+    double *h_mail = nullptr;     // 64 doubles
+    // named persistent device buffers (grown on demand, never shrunk)
+    static const int NBUF = 64;
+    void *buf[NBUF] = {nullptr};
+    size_t bufsz[NBUF] = {0};
+};
+
+Engine &eng();
+int dkmc_fail(int code, const char *what, const char *file, int line);
+// persistent scratch: returns a device buffer of at least `bytes`, identified by slot
+void *scratch(int slot, size_t bytes);
+MetalSet load_metals(const int *d_metals, int num_metals);   // small D2H (cached by pointer)
+
+#define HIPCHK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return dkmc_fail((int)e__, hipGetErrorString(e__), __FILE__, __LINE__); } while (0)
+#define KCHK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return dkmc_fail((int)e__, hipGetErrorString(e__), __FILE__, __LINE__); } while (0)
+
+// scratch slots
+enum {
+    S_CG_S = 0, S_CG_R, S_CG_P, S_CG_T, S_CG_PART, S_CG_CTRL,
+    S_K_DATA, S_K_RHS, S_K_DIAGPOS,
+    S_PW_LIST, S_PW_CNT,
+    S_EV_PROB, S_EV_ROWSUM, S_EV_G2, S_EV_G3, S_EV_CTRL, S_EV_UNI, S_EV_LOG, S_EV_TYPE,
+    S_SCAN_TMP, S_SCAN_TMP2,
+    S_AT_FLAG, S_AT_SITE, S_AT_OFSITE, S_AT_NEIGH,
+    S_X_ROWPTR, S_X_COL, S_X_DATA, S_X_DATA2, S_X_CNT, S_X_SLIST, S_X_SCB, S_X_SFLAG, S_X_RHS, S_X_WARM, S_X_SRANK,
+    S_P_IMACRO, S_HEAT,
+    S_MISC0, S_MISC1, S_MISC2, S_MISC3
+};
+
+// shared primitives (scan.hip)
+// exclusive prefix sum of n ints (in -> out, out may alias in); total written to d_total (device int) if non-null
+int dkmc_exclusive_scan_i32(const int *d_in, int *d_out, int n, int *d_total);

@@ -1,0 +1,490 @@
+// current.hip -- current / dissipated-power solve.  Replaces update_power_gpu_sparse
+// (current_solver_gpu.cu:854-1147) together with Assemble_X_sparsity / Assemble_X2
+// (iterative_solvers_gpu.cu:1909-1983, 2113-2156) and the kernels they launch.
+//
+// X is the conductance matrix over nodes {0: extraction driver, 1: injection driver, a+2: atom a};
+// the last atom is the ground and is dropped (Nsub = N_atom + 1 rows).  The reference rebuilds its
+// sparsity every step with two O(N_atom^2) scans (thread per row over ALL columns).  Only two kinds
+// of entries exist: neighbour pairs -- already in the padded neighbour index -- and tunnelling pairs
+// among the set S = {vacancies} U {inner-contact metals}.  So the pattern is built from the
+// neighbour rows (O(N_atom * nn)) plus an |S| x |S| sweep done by one workgroup per S-row with the
+// S arrays streamed through coalesced loads; rows come out column-sorted exactly as the reference's.
+#include "common.h"
+#include <vector>
+
+int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, double *x, double *y,
+                    int uniform_rows, int *iters_out, double *rr_out);
+
+enum { AF_V = 1, AF_MP_PAT = 2, AF_MP_VAL = 4, AF_METAL = 8, AF_CVAC = 16 };
+
+struct XParams {
+    int Na, nn, n_src, n_gnd, nlc, pbc;
+    double tol, nn_dist, high_G, low_G, loop_G, m_e, V0, laty, latz;
+};
+
+// ---- site -> atom compaction (current_solver_gpu.cu:869-879: thrust::sequence + 7x copy_if) ------
+__global__ void k_atom_flags(int N, const int *__restrict__ element, int *flag)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) { const int e = element[i]; flag[i] = (e != DEFECT) && (e != OXYGEN_DEFECT); }
+}
+
+__global__ void k_atom_gather(int N, const int *__restrict__ flag, const int *__restrict__ off,
+                              const double *__restrict__ sx, const double *__restrict__ sy, const double *__restrict__ sz,
+                              const int *__restrict__ sq, const int *__restrict__ sel, const double *__restrict__ scb,
+                              double *ax, double *ay, double *az, int *aq, int *ael, double *acb, int *atom_site, int *site_atom)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    if (flag[i]) {
+        const int a = off[i];
+        ax[a] = sx[i]; ay[a] = sy[i]; az[a] = sz[i]; aq[a] = sq[i]; ael[a] = sel[i]; acb[a] = scb[i];
+        atom_site[a] = i; site_atom[i] = a;
+    } else site_atom[i] = -1;
+}
+
+// per-atom class flags + neighbour rows in atom numbering (ground atom removed), ascending, -1 padded
+__global__ void k_atom_rows(XParams P, const int *__restrict__ neigh, const int *__restrict__ atom_site, const int *__restrict__ site_atom,
+                            const int *__restrict__ ael, const int *__restrict__ aq, MetalSet ms,
+                            int *__restrict__ aflag, int *__restrict__ aneigh, int *__restrict__ ancnt, int *__restrict__ inS)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= P.Na) return;
+    const int el = ael[a];
+    const bool metal = is_metal(el, ms);
+    const int N_full = P.Na + 2;
+    int f = 0;
+    if (el == VACANCY) f |= AF_V;
+    if (metal) f |= AF_METAL;
+    if (el == VACANCY && aq[a] == 0) f |= AF_CVAC;
+    // inner-contact window: bound = Natom in the pattern kernels (iterative_solvers_gpu.cu:894-900,1102-1108),
+    // N_full in the value kernel (:1630-1636)
+    if (metal && a > (P.nlc - 1) * P.n_src && a < P.Na - (P.nlc - 1) * P.n_gnd) f |= AF_MP_PAT;
+    if (metal && a > (P.nlc - 1) * P.n_src && a < N_full - (P.nlc - 1) * P.n_gnd) f |= AF_MP_VAL;
+    aflag[a] = f;
+    inS[a] = (a < P.Na - 1) && (f & (AF_V | AF_MP_PAT)) ? 1 : 0;
+    const int *row = neigh + (size_t)atom_site[a] * P.nn;
+    int n = 0;
+    for (int s = 0; s < P.nn; ++s) {
+        const int j = row[s];
+        if (j < 0) continue;
+        const int b = site_atom[j];
+        if (b >= 0 && b != P.Na - 1) aneigh[(size_t)a * P.nn + n++] = b;
+    }
+    ancnt[a] = n;
+    for (; n < P.nn; ++n) aneigh[(size_t)a * P.nn + n] = -1;
+}
+
+struct __attribute__((aligned(16))) SEntry { double cb; int idx; int flag; };
+
+__global__ void k_S_scatter(int Na, const int *__restrict__ inS, const int *__restrict__ off, const int *__restrict__ aflag,
+                            const double *__restrict__ acb, SEntry *S, int *srank)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= Na) return;
+    if (inS[a]) { SEntry e; e.cb = acb[a]; e.idx = a; e.flag = aflag[a]; S[off[a]] = e; srank[a] = off[a]; }
+    else srank[a] = -1;
+}
+
+// tunnelling predicate (iterative_solvers_gpu.cu:887-912, 1095-1121, 1624-1646); MPBIT selects the window
+template <int MPBIT>
+__device__ __forceinline__ int tunnel_kind(int fa, int fb, double cba, double cbb, double tol)
+{
+    const bool v1 = fa & AF_V, v2 = fb & AF_V, m1 = fa & MPBIT, m2 = fb & MPBIT;
+    const bool t2t = v1 && v2, c2t = (v1 && m2) || (v2 && m1), c2c = m1 && m2;
+    if ((t2t || c2t || c2c) && (fabs(cba - cbb) > tol)) return c2t ? 1 : 2;
+    return 0;
+}
+
+// ---- pattern: rows outside S (thread per row) ----------------------------------------------------
+// MODE 0: count, MODE 1: fill
+template <int MODE>
+__global__ void k_xpat_plain(XParams P, const int *__restrict__ inS, const int *__restrict__ aneigh, const int *__restrict__ ancnt,
+                             int *__restrict__ cnt, const int *__restrict__ rp, int *__restrict__ col)
+{
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    const int Nsub = P.Na + 1, N_full = P.Na + 2;
+    if (row >= Nsub) return;
+    if (row == 0) {                                                // :1035-1045
+        int n = 0;
+        if (MODE == 0) { cnt[0] = 2 + max(0, (N_full - 2) - max(N_full - P.n_gnd, 1)); return; }
+        col[rp[0] + n++] = 0; col[rp[0] + n++] = 1;
+        for (int j = max(N_full - P.n_gnd + 1, 2); j < N_full - 1; ++j) col[rp[0] + n++] = j;
+        return;
+    }
+    if (row == 1) {                                                // :1047-1054
+        if (MODE == 0) { cnt[1] = P.n_src + 2; return; }
+        for (int j = 0; j < P.n_src + 2; ++j) col[rp[1] + j] = j;
+        return;
+    }
+    const int a = row - 2;
+    if (inS[a]) return;                                            // handled by k_xpat_S
+    const int pre0 = row > N_full - P.n_gnd, pre1 = row < P.n_src + 2;
+    const int nnb = ancnt[a];
+    if (MODE == 0) { cnt[row] = pre0 + pre1 + nnb + 1; return; }
+    int p = rp[row];
+    if (pre0) col[p++] = 0;
+    if (pre1) col[p++] = 1;
+    bool self_done = false;
+    for (int s = 0; s < nnb; ++s) {
+        const int b = aneigh[(size_t)a * P.nn + s];
+        if (!self_done && b > a) { col[p++] = a + 2; self_done = true; }
+        col[p++] = b + 2;
+    }
+    if (!self_done) col[p++] = a + 2;
+}
+
+// ---- pattern: rows of S (one workgroup per row) ----------------------------------------------------
+#define XS_NT 256
+template <int MODE>
+__global__ __launch_bounds__(XS_NT) void k_xpat_S(XParams P, int ns, const SEntry *__restrict__ S, const int *__restrict__ aneigh,
+                                                  const int *__restrict__ ancnt, int *__restrict__ cnt, const int *__restrict__ rp,
+                                                  int *__restrict__ col)
+{
+    __shared__ int nb[72], hist[72], wtot[XS_NT / 64], s_total;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const SEntry me = S[blockIdx.x];
+    const int a = me.idx, row = a + 2, N_full = P.Na + 2;
+    const int nnb = ancnt[a], nN = nnb + 1;
+    if (tid == 0) {                                                // N' = neighbours U {a}, ascending
+        int n = 0; bool self_done = false;
+        for (int s = 0; s < nnb; ++s) { const int b = aneigh[(size_t)a * P.nn + s]; if (!self_done && b > a) { nb[n++] = a; self_done = true; } nb[n++] = b; }
+        if (!self_done) nb[n++] = a;
+        s_total = 0;
+    }
+    if (tid < 72) hist[tid] = 0;
+    __syncthreads();
+    const int pre = (row > N_full - P.n_gnd) + (row < P.n_src + 2);
+    const int row_start = (MODE == 1) ? rp[row] : 0;
+    int total_before = 0;
+    for (int base = 0; base < ns; base += XS_NT) {
+        const int k = base + tid;
+        bool match = false; int lt = 0; int b = -1;
+        if (k < ns) {
+            const SEntry o = S[k];
+            b = o.idx;
+            int lo = 0, hi = nN;                                   // lower_bound in N'
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (nb[mid] < b) lo = mid + 1; else hi = mid; }
+            lt = lo;
+            const bool is_nb = (lt < nN) && (nb[lt] == b);        // neighbours and self are "direct"/diagonal terms
+            match = !is_nb && tunnel_kind<AF_MP_PAT>(me.flag, o.flag, me.cb, o.cb, P.tol) != 0;
+        }
+        const unsigned long long bal = __ballot(match);
+        const int wexcl = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wtot[w] = __popcll(bal);
+        __syncthreads();
+        int wbase = 0, ctot = 0;
+#pragma unroll
+        for (int q = 0; q < XS_NT / 64; ++q) { if (q < w) wbase += wtot[q]; ctot += wtot[q]; }
+        if (MODE == 1 && match) {
+            col[row_start + pre + total_before + wbase + wexcl + lt] = b + 2;
+            atomicAdd(&hist[lt], 1);
+        }
+        total_before += ctot;
+        __syncthreads();
+    }
+    if (MODE == 0) { if (tid == 0) cnt[row] = pre + nN + total_before; return; }
+    if (tid == 0) { int p = row_start; if (row > N_full - P.n_gnd) col[p++] = 0; if (row < P.n_src + 2) col[p++] = 1; }
+    if (tid < nN) {
+        int cum = 0;
+        for (int t = 0; t <= tid; ++t) cum += hist[t];
+        col[row_start + pre + tid + cum] = nb[tid] + 2;
+    }
+}
+
+// ---- values (populate_sparse_X_gpu2 :1525-1721 + calc_diagonal_X_gpu :2053-2076) ---------------------
+__device__ __forceinline__ double pow15(double e) { return e * sqrt(e); }
+
+__device__ __forceinline__ double wkb_T(int kind, double dist, double drop, double prefac, double V0)
+{
+    if (kind == 1) {                                               // contact -> trap: integrate over the occupied levels
+        const double dE = DKMC_Q * 0.01;
+        double T = 0.0;
+        const double c = prefac * (dist / drop);
+        for (double iv = 0; iv < drop; iv += dE) {
+            const double E1 = DKMC_Q * V0 + iv, E2 = E1 - drop;
+            if (E2 > 0) T += exp(c * (pow15(E1) - pow15(E2)));
+            if (E2 < 0) T += exp(c * pow15(E1));
+        }
+        return T;
+    }
+    const double E1 = DKMC_Q * V0, E2 = E1 - drop;
+    const double c = prefac * (dist / fabs(E1 - E2));
+    if (E2 > 0) return exp(c * (pow15(E1) - pow15(E2)));
+    if (E2 < 0) return exp(c * pow15(E1));
+    return 0.0;
+}
+
+// value of entry (row i >= 2, column c); returns the value, flags the diagonal
+__device__ __forceinline__ double x_entry(const XParams &P, int i, int c, const double *__restrict__ ax, const double *__restrict__ ay,
+                                          const double *__restrict__ az, const int *__restrict__ aflag, const double *__restrict__ acb,
+                                          double xa, double ya, double za, int fa, double cba, double prefac)
+{
+    const int N_full = P.Na + 2;
+    if (c == 0) return (i > N_full - P.n_gnd) ? -P.high_G : 0.0;  // :1602-1605
+    if (c == 1) return (i < P.n_src + 2) ? -P.high_G : 0.0;       // :1608-1611
+    if (c == i) {                                                  // :1588-1599 (ground = last atom)
+        const int g = P.Na - 1;
+        const double d = site_dist(xa, ya, za, ax[g], ay[g], az[g], P.laty, P.latz, P.pbc);
+        return d < P.nn_dist ? P.high_G : 0.0;
+    }
+    const int b = c - 2;
+    const double dA = site_dist(xa, ya, za, ax[b], ay[b], az[b], P.laty, P.latz, P.pbc);
+    const int fb = aflag[b];
+    if (dA < P.nn_dist) {                                          // direct terms :1698-1716
+        const bool mm = (fa & AF_METAL) && (fb & AF_METAL), cc = (fa & AF_CVAC) && (fb & AF_CVAC);
+        return (mm || cc) ? -P.high_G : -P.low_G;
+    }
+    const double cbb = acb[b];
+    const int kind = tunnel_kind<AF_MP_VAL>(fa, fb, cba, cbb, P.tol);
+    if (!kind) return 0.0;
+    return -wkb_T(kind, 1e-10 * dA, fabs(cba - cbb), prefac, P.V0);
+}
+
+// LPR lanes per row over a row list (rows == nullptr: rows 0..nrows-1 are node rows 0..)
+template <int LPR>
+__global__ __launch_bounds__(256) void k_xval(XParams P, int nrows, const SEntry *__restrict__ S, int use_S,
+                                              const int *__restrict__ inS, const int *__restrict__ rp, const int *__restrict__ ci,
+                                              const double *__restrict__ ax, const double *__restrict__ ay, const double *__restrict__ az,
+                                              const int *__restrict__ aflag, const double *__restrict__ acb, double *__restrict__ data)
+{
+    const int gpb = 256 / LPR, g = threadIdx.x / LPR, l = threadIdx.x % LPR;
+    const int ridx = blockIdx.x * gpb + g;
+    if (ridx >= nrows) return;
+    int i;
+    if (use_S) i = S[ridx].idx + 2;
+    else { i = ridx; if (i >= 2 && inS[i - 2]) return; }
+    const int N_full = P.Na + 2;
+    const int p0 = rp[i], p1 = rp[i + 1];
+    const double prefac = -(sqrt(2 * P.m_e) / DKMC_HBAR) * (2.0 / 3.0);
+    double off = 0.0, dval = 0.0; int dpos = -1;
+    if (i == 0) {                                                  // :1550-1567
+        for (int p = p0 + l; p < p1; p += LPR) {
+            const int c = ci[p]; double v = 0.0;
+            if (c == 0) v = +P.high_G;
+            if (c == 1) v = -P.loop_G;
+            if (c > N_full - P.n_gnd) v = -P.high_G;
+            if (c == 0) { dpos = p; dval = v; } else { data[p] = v; off += v; }
+        }
+    } else if (i == 1) {                                           // :1570-1582
+        for (int p = p0 + l; p < p1; p += LPR) {
+            const int c = ci[p]; double v = 0.0;
+            if (c == 0) v = -P.loop_G;
+            if (c >= 2 || (c > N_full - P.n_gnd)) v = -P.high_G;
+            if (c == 1) { dpos = p; dval = v; } else { data[p] = v; off += v; }
+        }
+    } else {
+        const int a = i - 2;
+        const double xa = ax[a], ya = ay[a], za = az[a], cba = acb[a];
+        const int fa = aflag[a];
+        for (int p = p0 + l; p < p1; p += LPR) {
+            const int c = ci[p];
+            const double v = x_entry(P, i, c, ax, ay, az, aflag, acb, xa, ya, za, fa, cba, prefac);
+            if (c == i) { dpos = p; dval = v; } else { data[p] = v; off += v; }
+        }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) off += __shfl_xor(off, o, LPR);
+    if (dpos >= 0) data[dpos] = dval + -off;                       // calc_diagonal_X_gpu
+}
+
+// ---- post-solve ------------------------------------------------------------------------------------
+__global__ void k_set_rhs(double *m, int n, double loop_G, double Vd)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) m[i] = (i == 0) ? -loop_G * Vd : (i == 1) ? loop_G * Vd : 0.0;
+}
+__global__ void k_scale(double *v, int n, double s)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = v[i] * s;
+}
+// get_imacro_sparse (current_solver_gpu.cu:781-821): single block, fixed-order reduction
+__global__ __launch_bounds__(256) void k_imacro(const double *__restrict__ xv, const int *__restrict__ rp, const int *__restrict__ ci,
+                                                const double *__restrict__ m, double *imacro)
+{
+    __shared__ double red[4];
+    const int row_start = rp[1] + 2, row_end = rp[2];
+    double s = 0.0;
+    for (int p = row_start + threadIdx.x; p < row_end; p += 256) { const int c = ci[p]; if (c >= 2) s += xv[p] * (m[c] - m[1]); }
+    const double t = block_sum_all<256>(s, red);
+    if (threadIdx.x == 0) *imacro = t;
+}
+// update_m (current_solver_gpu.cu:447-457, 1044-1047): m += |min(m[2 .. Na+1])|
+__global__ __launch_bounds__(256) void k_min_m(const double *m, int lo, int hi, double *out)
+{
+    __shared__ double red[256];
+    double v = INFINITY;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) v = fmin(v, m[i]);
+    red[threadIdx.x] = v; __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] = fmin(red[threadIdx.x], red[threadIdx.x + s]); __syncthreads(); }
+    if (threadIdx.x == 0) *out = fabs(red[0]);
+}
+__global__ void k_shift(double *m, int n, const double *shift)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) m[i] += *shift;
+}
+// Dissipated power on X's pattern: host formula (current_solver.cpp:288-357) restricted to the atoms kept
+// in the sparse system; set_ineg_sparse + reduce_rows_into_diag + SpMV + copy_pdisp fused (see SURVEY B8/B9
+// for the index slips of the CUDA kernels this replaces).
+template <int LPR>
+__global__ __launch_bounds__(256) void k_power(int Na, int nrows, const int *__restrict__ rows, const int *__restrict__ rp,
+                                               const int *__restrict__ ci, const double *__restrict__ xv, const double *__restrict__ m,
+                                               double Vd, const int *__restrict__ aflag, const int *__restrict__ atom_site,
+                                               double alpha, double *__restrict__ site_power)
+{
+    const int gpb = 256 / LPR, g = threadIdx.x / LPR, l = threadIdx.x % LPR;
+    const int ridx = blockIdx.x * gpb + g;
+    if (ridx >= nrows) return;
+    const int i = rows[ridx];
+    if (i < 2) return;
+    const double mi = m[i];
+    double p = 0.0;
+    for (int q = rp[i] + l; q < rp[i + 1]; q += LPR) {
+        const int c = ci[q];
+        if (c < 2 || c == i) continue;
+        const double ical = xv[q] * (mi - m[c]);
+        double v = 0.0;
+        if ((ical < 0 && Vd > 0) || (ical > 0 && Vd < 0)) v = -ical;
+        p += v * (m[c] - mi);
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) p += __shfl_xor(p, o, LPR);
+    const int a = i - 2;
+    if (l == 0 && !(aflag[a] & AF_METAL)) site_power[atom_site[a]] = -1 * alpha * p;
+}
+__global__ void k_iota_rows(int n, int *rows, const int *inS, int want_S)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rows[i] = i;
+}
+
+// state of the last call (for dkmc_get_last_X and the private warm start)
+static int g_last_rows = 0; static long long g_last_nnz = 0;
+static double *g_warm = nullptr; static int g_warm_n = 0;
+
+extern "C" int dkmc_update_power_gpu_sparse(dkmc_gpubuf *buf, int n_src, int n_gnd, int nlc, double Vd, int pbc,
+                                            double high_G, double low_G, double loop_G, double G0, double tol, double nn_dist,
+                                            double m_e, double V0, int num_metals, double *h_imacro,
+                                            int heat_local, int heat_global, double alpha_disp)
+{
+    Engine &e = eng(); hipStream_t st = e.stream;
+    const int N = buf->N_, nn = buf->nn_;
+    if (nn > 64) return dkmc_fail(11, "update_power: more than 64 neighbours per site is not supported", __FILE__, __LINE__);
+    MetalSet ms = load_metals(buf->metal_types, num_metals);
+    // ---- 1. atoms ----
+    int *flag = (int *)scratch(S_AT_FLAG, (size_t)N * 4), *off = (int *)scratch(S_AT_OFSITE, (size_t)(N + 4) * 4);
+    int *atom_site = (int *)scratch(S_AT_SITE, (size_t)N * 4 * 2);
+    if (!flag || !off || !atom_site) return e.err_code;
+    int *site_atom = atom_site + N;
+    const int nb = (N + 255) / 256;
+    hipLaunchKernelGGL(k_atom_flags, dim3(nb), dim3(256), 0, st, N, buf->site_element, flag);
+    int rc = dkmc_exclusive_scan_i32(flag, off, N, off + N); if (rc) return rc;
+    int Na = 0;
+    HIPCHK(hipMemcpyAsync(&Na, off + N, sizeof(int), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_atom_gather, dim3(nb), dim3(256), 0, st, N, flag, off, buf->site_x, buf->site_y, buf->site_z, buf->site_charge,
+                       buf->site_element, buf->site_CB_edge, buf->atom_x, buf->atom_y, buf->atom_z, buf->atom_charge, buf->atom_element,
+                       buf->atom_CB_edge, atom_site, site_atom);
+    HIPCHK(hipStreamSynchronize(st));
+    if (Na < 3) return dkmc_fail(8, "update_power: fewer than 3 atoms", __FILE__, __LINE__);
+    if (Na > buf->N_atom_) return dkmc_fail(9, "update_power: more atoms than GPUBuffers was sized for (N_atom_)", __FILE__, __LINE__);
+    e.stats.N_atom = Na;
+    const int Nsub = Na + 1;
+    double lat[3];
+    HIPCHK(hipMemcpy(lat, buf->lattice, 3 * sizeof(double), hipMemcpyDeviceToHost));
+    XParams P; P.Na = Na; P.nn = nn; P.n_src = n_src; P.n_gnd = n_gnd; P.nlc = nlc; P.pbc = pbc; P.tol = tol; P.nn_dist = nn_dist;
+    P.high_G = high_G; P.low_G = low_G; P.loop_G = loop_G; P.m_e = m_e; P.V0 = V0; P.laty = lat[1]; P.latz = lat[2];
+
+    // ---- 2. atom rows, class flags, S ----
+    int *aneigh = (int *)scratch(S_AT_NEIGH, (size_t)Na * nn * 4);
+    int *aflag = (int *)scratch(S_X_SFLAG, (size_t)Na * 4 * 4);
+    SEntry *S = (SEntry *)scratch(S_X_SLIST, (size_t)Na * sizeof(SEntry));
+    if (!aneigh || !aflag || !S) return e.err_code;
+    int *ancnt = aflag + Na, *inS = aflag + 2 * Na, *srank = aflag + 3 * Na;
+    int *soff = (int *)scratch(S_X_SRANK, (size_t)(Na + 4) * 4);
+    if (!soff) return e.err_code;
+    const int nba = (Na + 255) / 256;
+    hipLaunchKernelGGL(k_atom_rows, dim3(nba), dim3(256), 0, st, P, buf->neigh_idx, atom_site, site_atom, buf->atom_element, buf->atom_charge,
+                       ms, aflag, aneigh, ancnt, inS);
+    rc = dkmc_exclusive_scan_i32(inS, soff, Na, soff + Na); if (rc) return rc;
+    int ns = 0;
+    HIPCHK(hipMemcpyAsync(&ns, soff + Na, sizeof(int), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_S_scatter, dim3(nba), dim3(256), 0, st, Na, inS, soff, aflag, buf->atom_CB_edge, S, srank);
+    HIPCHK(hipStreamSynchronize(st));
+
+    // ---- 3. sparsity: counts -> row_ptr -> columns ----
+    int *cnt = (int *)scratch(S_X_CNT, (size_t)(Nsub + 4) * 4);
+    int *rp = (int *)scratch(S_X_ROWPTR, (size_t)(Nsub + 4) * 4);
+    if (!cnt || !rp) return e.err_code;
+    const int nbr = (Nsub + 255) / 256;
+    hipLaunchKernelGGL((k_xpat_plain<0>), dim3(nbr), dim3(256), 0, st, P, inS, aneigh, ancnt, cnt, (const int *)nullptr, (int *)nullptr);
+    if (ns > 0) hipLaunchKernelGGL((k_xpat_S<0>), dim3(ns), dim3(XS_NT), 0, st, P, ns, S, aneigh, ancnt, cnt, (const int *)nullptr, (int *)nullptr);
+    // nnz can exceed int32 for very large tunnelling blocks: sum in 64 bit on the host side of the scan
+    rc = dkmc_exclusive_scan_i32(cnt, rp, Nsub, rp + Nsub); if (rc) return rc;
+    int nnz_i = 0;
+    HIPCHK(hipMemcpyAsync(&nnz_i, rp + Nsub, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (nnz_i <= 0) return dkmc_fail(10, "update_power: X has more than 2^31-1 non-zeros (int32 CSR, as in the reference)", __FILE__, __LINE__);
+    const long long nnz = nnz_i;
+    e.stats.X_nnz = nnz;
+    int *col = (int *)scratch(S_X_COL, (size_t)nnz * 4);
+    double *data = (double *)scratch(S_X_DATA, (size_t)nnz * 8), *data2 = (double *)scratch(S_X_DATA2, (size_t)nnz * 8);
+    if (!col || !data || !data2) return e.err_code;
+    hipLaunchKernelGGL((k_xpat_plain<1>), dim3(nbr), dim3(256), 0, st, P, inS, aneigh, ancnt, cnt, rp, col);
+    if (ns > 0) hipLaunchKernelGGL((k_xpat_S<1>), dim3(ns), dim3(XS_NT), 0, st, P, ns, S, aneigh, ancnt, cnt, rp, col);
+    // ---- 4. values ----
+    hipLaunchKernelGGL((k_xval<16>), dim3((Nsub + 15) / 16), dim3(256), 0, st, P, Nsub, S, 0, inS, rp, col, buf->atom_x, buf->atom_y, buf->atom_z,
+                       aflag, buf->atom_CB_edge, data);
+    if (ns > 0) hipLaunchKernelGGL((k_xval<64>), dim3((ns + 3) / 4), dim3(256), 0, st, P, ns, S, 1, inS, rp, col, buf->atom_x, buf->atom_y, buf->atom_z,
+                                   aflag, buf->atom_CB_edge, data);
+    KCHK();
+    g_last_rows = Nsub; g_last_nnz = nnz;
+
+    // ---- 5. solve X m = rhs (current_solver_gpu.cu:963-994) ----
+    double *rhs = (double *)scratch(S_X_RHS, (size_t)(Na + 2) * 8);
+    if (!rhs) return e.err_code;
+    hipLaunchKernelGGL(k_set_rhs, dim3((Na + 2 + 255) / 256), dim3(256), 0, st, rhs, Na + 2, loop_G, Vd);
+    HIPCHK(hipMemcpyAsync(data2, data, (size_t)nnz * 8, hipMemcpyDeviceToDevice, st));
+    double *m = buf->atom_virtual_potentials;
+    if (e.current_warm_start == 1) {
+        if (g_warm && g_warm_n == Nsub) HIPCHK(hipMemcpyAsync(m, g_warm, (size_t)Nsub * 8, hipMemcpyDeviceToDevice, st));
+    }
+    rc = cg_solve_jacobi(data2, rp, col, (int)nnz, Nsub, rhs, m, 0, &e.stats.cg_iters_X, &e.stats.cg_rr_X);
+    if (rc) return rc;
+    if (e.current_warm_start == 1) {
+        if (g_warm_n != Nsub) { if (g_warm) (void)hipFree(g_warm); HIPCHK(hipMalloc((void **)&g_warm, (size_t)Nsub * 8)); g_warm_n = Nsub; }
+        HIPCHK(hipMemcpyAsync(g_warm, m, (size_t)Nsub * 8, hipMemcpyDeviceToDevice, st));
+    }
+    // ---- 6. I_macro (:1015-1029) ----
+    hipLaunchKernelGGL(k_scale, dim3((Na + 2 + 255) / 256), dim3(256), 0, st, m, Na + 2, G0);
+    double *d_im = (double *)scratch(S_P_IMACRO, 2 * sizeof(double));
+    if (!d_im) return e.err_code;
+    hipLaunchKernelGGL(k_imacro, dim3(1), dim3(256), 0, st, data, rp, col, m, d_im);
+    HIPCHK(hipMemcpyAsync(h_imacro, d_im, sizeof(double), hipMemcpyDeviceToHost, st));
+    // ---- 7. dissipated power (:1041-1136) ----
+    if (heat_local || heat_global) {
+        hipLaunchKernelGGL(k_min_m, dim3(1), dim3(256), 0, st, m, 2, Na + 2, d_im + 1);
+        hipLaunchKernelGGL(k_shift, dim3((Na + 2 + 255) / 256), dim3(256), 0, st, m, Na + 2, d_im + 1);
+        int *rows = (int *)scratch(S_MISC0, (size_t)Nsub * 4);
+        if (!rows) return e.err_code;
+        hipLaunchKernelGGL(k_iota_rows, dim3(nbr), dim3(256), 0, st, Nsub, rows, inS, 0);
+        hipLaunchKernelGGL((k_power<64>), dim3((Nsub + 3) / 4), dim3(256), 0, st, Na, Nsub, rows, rp, col, data, m, Vd, aflag, atom_site,
+                           alpha_disp, buf->site_power);
+    }
+    KCHK();
+    HIPCHK(hipStreamSynchronize(st));
+    return e.err_code;
+}
+
+extern "C" int dkmc_get_last_X(int *rows_out, long long *nnz_out, int *h_rp, int *h_col, double *h_data)
+{
+    Engine &e = eng();
+    if (rows_out) *rows_out = g_last_rows;
+    if (nnz_out) *nnz_out = g_last_nnz;
+    HIPCHK(hipStreamSynchronize(e.stream));
+    if (h_rp) HIPCHK(hipMemcpy(h_rp, e.buf[S_X_ROWPTR], (size_t)(g_last_rows + 1) * 4, hipMemcpyDeviceToHost));
+    if (h_col) HIPCHK(hipMemcpy(h_col, e.buf[S_X_COL], (size_t)g_last_nnz * 4, hipMemcpyDeviceToHost));
+    if (h_data) HIPCHK(hipMemcpy(h_data, e.buf[S_X_DATA], (size_t)g_last_nnz * 8, hipMemcpyDeviceToHost));
+    return 0;
+}

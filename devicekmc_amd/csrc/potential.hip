@@ -1,0 +1,309 @@
+// potential.hip -- charge rule, K sparsity + assembly, background potential / CB edge solves,
+// screened-Coulomb pair sum.  Replaces potential_solver_gpu.cu (live parts) and the K-pattern
+// builders of iterative_solvers_gpu.cu.
+#include "common.h"
+
+int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, double *x, double *y,
+                    int uniform_rows, int *iters_out, double *rr_out);
+
+// ------------------------------------------------------------------------------------------------
+// update_charge (potential_solver_gpu.cu:10-52).  One thread per site; only vacancies and oxygen
+// ions (a few % of the sites) touch their neighbour row.  Padded slots (-1) are skipped: the
+// reference reads element[-1] there.
+__global__ __launch_bounds__(256) void k_update_charge(int N, int nn, const int *__restrict__ element, int *__restrict__ charge,
+                                                       const int *__restrict__ neigh, MetalSet ms)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const int el = element[i];
+    if (el != VACANCY && el != OXYGEN_DEFECT) return;
+    const int *row = neigh + (size_t)i * nn;
+    int vnn = 0; bool metal = false;
+    for (int s = 0; s < nn; ++s) {
+        const int j = row[s];
+        if (j < 0) continue;
+        const int ej = element[j];
+        vnn += (ej == VACANCY);
+        metal |= is_metal(ej, ms);
+    }
+    int c;
+    if (el == VACANCY) c = (metal || vnn >= 2) ? 0 : 2;
+    else c = metal ? 0 : -2;
+    charge[i] = c;
+}
+
+extern "C" int dkmc_update_charge_gpu(const int *el, int *q, const int *neigh, int N, int nn, const int *d_metals, int nm)
+{
+    MetalSet ms = load_metals(d_metals, nm);
+    hipLaunchKernelGGL(k_update_charge, dim3((N + 255) / 256), dim3(256), 0, eng().stream, N, nn, el, q, neigh, ms);
+    KCHK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K sparsity (Assemble_K_sparsity, iterative_solvers_gpu.cu:2158-2208).  The reference scans all
+// m columns per row (O(m^2) site_dist calls).  The padded neighbour index already holds exactly
+// the pairs with dist < nn_dist (same cutoff, kmc_main.cpp:121), ascending in j, so the three CSR
+// blocks are a filtered copy of it: O(N * nn).
+__global__ void k_kpat_count(int m, int N_left, int nn, const int *__restrict__ neigh, int *cd, int *cl, int *cr)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    const int *row = neigh + (size_t)(N_left + r) * nn;
+    int d = 1, l = 0, rr = 0;       // diagonal is part of the device block (dist = 0 < cutoff)
+    for (int s = 0; s < nn; ++s) {
+        const int j = row[s];
+        if (j < 0) continue;
+        if (j < N_left) ++l; else if (j >= N_left + m) ++rr; else ++d;
+    }
+    cd[r] = d; cl[r] = l; cr[r] = rr;
+}
+
+__global__ void k_kpat_fill(int m, int N_left, int nn, const int *__restrict__ neigh,
+                            const int *rpd, const int *rpl, const int *rpr, int *cold, int *coll, int *colr, int *diagpos)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= m) return;
+    const int i = N_left + r;
+    const int *row = neigh + (size_t)i * nn;
+    int pd = rpd[r], pl = rpl[r], pr = rpr[r];
+    bool diag_done = false;
+    for (int s = 0; s < nn; ++s) {
+        const int j = row[s];
+        if (j < 0) continue;
+        if (j < N_left) coll[pl++] = j;
+        else if (j >= N_left + m) colr[pr++] = j - (N_left + m);
+        else {
+            if (!diag_done && j > i) { diagpos[r] = pd; cold[pd++] = r; diag_done = true; }
+            cold[pd++] = j - N_left;
+        }
+    }
+    if (!diag_done) { diagpos[r] = pd; cold[pd++] = r; }
+}
+
+__global__ void k_set_last(int *rp, int m, const int *total) { if (threadIdx.x == 0 && blockIdx.x == 0) rp[m] = *total; }
+
+static int *g_diagpos = nullptr; static int g_diagpos_m = 0; static int g_kpat_N_left = -1;
+
+extern "C" int dkmc_initialize_sparsity(dkmc_gpubuf *buf, int pbc, double nn_dist, int num_atoms_contact)
+{
+    (void)pbc; (void)nn_dist;
+    Engine &e = eng(); hipStream_t st = e.stream;
+    const int N = buf->N_, nn = buf->nn_, N_left = num_atoms_contact, m = N - 2 * num_atoms_contact;
+    if (m <= 0) return dkmc_fail(5, "initialize_sparsity: no device rows", __FILE__, __LINE__);
+    int *cnt = (int *)scratch(S_MISC0, (size_t)3 * m * sizeof(int));
+    int *tot = (int *)scratch(S_MISC1, 4 * sizeof(int));
+    if (!cnt || !tot) return e.err_code;
+    int **rps[3] = { &buf->Device_row_ptr_d, &buf->contact_left_row_ptr, &buf->contact_right_row_ptr };
+    int **cis[3] = { &buf->Device_col_indices_d, &buf->contact_left_col_indices, &buf->contact_right_col_indices };
+    for (int b = 0; b < 3; ++b) {
+        if (*rps[b]) (void)hipFree(*rps[b]);
+        if (*cis[b]) { (void)hipFree(*cis[b]); *cis[b] = nullptr; }
+        HIPCHK(hipMalloc((void **)rps[b], (size_t)(m + 1) * sizeof(int)));
+    }
+    const int blocks = (m + 255) / 256;
+    hipLaunchKernelGGL(k_kpat_count, dim3(blocks), dim3(256), 0, st, m, N_left, nn, buf->neigh_idx, cnt, cnt + m, cnt + 2 * m);
+    int h_tot[3];
+    for (int b = 0; b < 3; ++b) {
+        int rc = dkmc_exclusive_scan_i32(cnt + (size_t)b * m, *rps[b], m, tot + b); if (rc) return rc;
+        hipLaunchKernelGGL(k_set_last, dim3(1), dim3(1), 0, st, *rps[b], m, tot + b);
+    }
+    HIPCHK(hipMemcpyAsync(h_tot, tot, 3 * sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    buf->Device_nnz = h_tot[0]; buf->contact_left_nnz = h_tot[1]; buf->contact_right_nnz = h_tot[2];
+    for (int b = 0; b < 3; ++b) HIPCHK(hipMalloc((void **)cis[b], (size_t)(h_tot[b] > 0 ? h_tot[b] : 1) * sizeof(int)));
+    if (g_diagpos) (void)hipFree(g_diagpos);
+    HIPCHK(hipMalloc((void **)&g_diagpos, (size_t)m * sizeof(int)));
+    g_diagpos_m = m; g_kpat_N_left = N_left;
+    hipLaunchKernelGGL(k_kpat_fill, dim3(blocks), dim3(256), 0, st, m, N_left, nn, buf->neigh_idx,
+                       buf->Device_row_ptr_d, buf->contact_left_row_ptr, buf->contact_right_row_ptr,
+                       buf->Device_col_indices_d, buf->contact_left_col_indices, buf->contact_right_col_indices, g_diagpos);
+    KCHK();
+    HIPCHK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K values + rhs in one pass (Assemble_A / Assemble_A_CB + calc_rhs_for_A,
+// potential_solver_gpu.cu:187-593).  16 lanes per row; the 6 reference kernels (off-diagonals,
+// reduce_rows_into_diag, 2x contact row reductions, 2x add_vector_to_diagonal) and the rhs kernel
+// collapse into this one.
+template <int CB>
+__device__ __forceinline__ double k_cond(int ei, int ej, int qi, int qj, const MetalSet &ms, double high_G, double low_G)
+{
+    const bool m1 = is_metal(ei, ms), m2 = is_metal(ej, ms);
+    if (CB) return (m1 || m2) ? high_G : low_G;                         // :239-249
+    const bool cv1 = (ei == VACANCY) && (qi == 0), cv2 = (ej == VACANCY) && (qj == 0);
+    return ((m1 && m2) || (cv1 && cv2)) ? high_G : low_G;               // :202-217
+}
+
+template <int CB>
+__global__ __launch_bounds__(256) void k_assemble_K(int m, int N_left, const int *__restrict__ element, const int *__restrict__ charge,
+                                                    MetalSet ms, double high_G, double low_G,
+                                                    const int *__restrict__ rp, const int *__restrict__ ci,
+                                                    const int *__restrict__ lrp, const int *__restrict__ lci,
+                                                    const int *__restrict__ rrp, const int *__restrict__ rci,
+                                                    const int *__restrict__ diagpos, double VL, double VR,
+                                                    double *__restrict__ data, double *__restrict__ rhs)
+{
+    const int LPR = 16;
+    const int g = threadIdx.x / LPR, l = threadIdx.x % LPR;
+    const int r = blockIdx.x * (256 / LPR) + g;
+    if (r >= m) return;
+    const int i = N_left + r;
+    const int ei = element[i], qi = charge[i];
+    double off = 0.0, kl = 0.0, kr = 0.0;
+    for (int p = rp[r] + l; p < rp[r + 1]; p += LPR) {
+        const int c = ci[p];
+        if (c == r) continue;
+        const int j = N_left + c;
+        const double gg = k_cond<CB>(ei, element[j], qi, charge[j], ms, high_G, low_G);
+        data[p] = -gg;
+        off += gg;
+    }
+    for (int p = lrp[r] + l; p < lrp[r + 1]; p += LPR) { const int j = lci[p]; kl += k_cond<CB>(ei, element[j], qi, charge[j], ms, high_G, low_G); }
+    for (int p = rrp[r] + l; p < rrp[r + 1]; p += LPR) { const int j = N_left + m + rci[p]; kr += k_cond<CB>(ei, element[j], qi, charge[j], ms, high_G, low_G); }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) { off += __shfl_xor(off, o, LPR); kl += __shfl_xor(kl, o, LPR); kr += __shfl_xor(kr, o, LPR); }
+    if (l == 0) {
+        double d = off;      // reduce_rows_into_diag: -(sum of off-diagonals)
+        d += kl;             // add_vector_to_diagonal (left)
+        d += kr;             // add_vector_to_diagonal (right)
+        data[diagpos[r]] = d;
+        rhs[r] = kl * VL + kr * VR;
+    }
+}
+
+__global__ void k_fill_contacts(double *field, int N, int N_left, int N_right, double vl, double vr, double scale_all)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    double v = field[i];
+    if (i < N_left) v = vl; else if (i >= N - N_right) v = vr;
+    field[i] = v * scale_all;
+}
+
+static int solve_K(dkmc_gpubuf *buf, int N, int N_left, int N_right, double VL, double VR, int cb,
+                   double high_G, double low_G, int num_metals, double *field, int *iters, double *rr)
+{
+    Engine &e = eng(); hipStream_t st = e.stream;
+    const int m = N - N_left - N_right;
+    if (!buf->Device_row_ptr_d || g_diagpos_m != m || g_kpat_N_left != N_left)
+        return dkmc_fail(6, "K sparsity not initialised for this contact size (call initialize_sparsity)", __FILE__, __LINE__);
+    double *data = (double *)scratch(S_K_DATA, (size_t)buf->Device_nnz * 8);
+    double *rhs = (double *)scratch(S_K_RHS, (size_t)m * 8);
+    if (!data || !rhs) return e.err_code;
+    MetalSet ms = load_metals(buf->metal_types, num_metals);
+    const int blocks = (m + 15) / 16;
+    if (cb) hipLaunchKernelGGL((k_assemble_K<1>), dim3(blocks), dim3(256), 0, st, m, N_left, buf->site_element, buf->site_charge, ms,
+                               high_G, low_G, buf->Device_row_ptr_d, buf->Device_col_indices_d, buf->contact_left_row_ptr,
+                               buf->contact_left_col_indices, buf->contact_right_row_ptr, buf->contact_right_col_indices,
+                               g_diagpos, VL, VR, data, rhs);
+    else hipLaunchKernelGGL((k_assemble_K<0>), dim3(blocks), dim3(256), 0, st, m, N_left, buf->site_element, buf->site_charge, ms,
+                            high_G, low_G, buf->Device_row_ptr_d, buf->Device_col_indices_d, buf->contact_left_row_ptr,
+                            buf->contact_left_col_indices, buf->contact_right_row_ptr, buf->contact_right_col_indices,
+                            g_diagpos, VL, VR, data, rhs);
+    KCHK();
+    return cg_solve_jacobi(data, buf->Device_row_ptr_d, buf->Device_col_indices_d, buf->Device_nnz, m, rhs, field + N_left, 1, iters, rr);
+}
+
+// background_potential_gpu_sparse (potential_solver_gpu.cu:696-781)
+extern "C" int dkmc_background_potential_gpu_sparse(dkmc_gpubuf *buf, int N, int N_left, int N_right, double Vd, int pbc,
+                                                    double high_G, double low_G, double nn_dist, int num_metals, int kmc_step_count)
+{
+    (void)pbc; (void)nn_dist; (void)kmc_step_count;
+    Engine &e = eng();
+    int rc = solve_K(buf, N, N_left, N_right, -Vd / 2, Vd / 2, 0, high_G, low_G, num_metals, buf->site_potential_boundary,
+                     &e.stats.cg_iters_K, &e.stats.cg_rr_K);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fill_contacts, dim3((N + 255) / 256), dim3(256), 0, e.stream, buf->site_potential_boundary, N, N_left, N_right,
+                       -Vd / 2, Vd / 2, 1.0);
+    KCHK();
+    return 0;
+}
+
+// update_CB_edge_gpu_sparse (potential_solver_gpu.cu:595-694); result scaled by eV_to_J (:674)
+extern "C" int dkmc_update_CB_edge_gpu_sparse(dkmc_gpubuf *buf, int N, int N_left, int N_right, double Vd, int pbc,
+                                              double high_G, double low_G, double nn_dist, int num_metals)
+{
+    (void)pbc; (void)nn_dist;
+    Engine &e = eng();
+    int rc = solve_K(buf, N, N_left, N_right, Vd / 2, -Vd / 2, 1, high_G, low_G, num_metals, buf->site_CB_edge,
+                     &e.stats.cg_iters_CB, &e.stats.cg_rr_CB);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_fill_contacts, dim3((N + 255) / 256), dim3(256), 0, e.stream, buf->site_CB_edge, N, N_left, N_right,
+                       Vd / 2, -Vd / 2, DKMC_Q);
+    KCHK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// poisson_gridless (potential_solver_gpu.cu:908-978).  The reference launches N x ceil(N/512)
+// blocks (N^2 threads), though only columns with a non-zero charge contribute, and combines block
+// sums with atomicAdd in arrival order.  Here: (1) the charged sites are compacted, in ascending
+// site order, into a packed {x,y,z,q,idx} list; (2) each thread owns one site and sweeps the list
+// through an LDS tile, accumulating in list order -- the sequential order of the host twin
+// (potential_solver.cpp:412-432), no atomics, no memset.
+struct __attribute__((aligned(32))) ChargedSite { double x, y, z; int q, idx; };
+
+__global__ void k_charge_flags(int N, const int *charge, int *flag)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) flag[i] = charge[i] != 0;
+}
+__global__ void k_charge_scatter(int N, const int *__restrict__ charge, const int *__restrict__ off,
+                                 const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                 ChargedSite *list)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N && charge[i] != 0) { ChargedSite c; c.x = x[i]; c.y = y[i]; c.z = z[i]; c.q = charge[i]; c.idx = i; list[off[i]] = c; }
+}
+
+#define PW_NT 256
+__global__ __launch_bounds__(PW_NT) void k_pairwise(int N, const double *__restrict__ x, const double *__restrict__ y,
+                                                    const double *__restrict__ z, const double *__restrict__ lattice, int pbc,
+                                                    const double *__restrict__ sigma_p, const double *__restrict__ k_p,
+                                                    const ChargedSite *__restrict__ list, const int *__restrict__ ncharged,
+                                                    double *__restrict__ out)
+{
+    __shared__ ChargedSite tile[PW_NT];
+    const int i = blockIdx.x * PW_NT + threadIdx.x;
+    const int nc = *ncharged;
+    const double sigma = *sigma_p, kk = *k_p, laty = lattice[1], latz = lattice[2];
+    const double xi = i < N ? x[i] : 0.0, yi = i < N ? y[i] : 0.0, zi = i < N ? z[i] : 0.0;
+    double v = 0.0;
+    for (int base = 0; base < nc; base += PW_NT) {
+        const int n = min(PW_NT, nc - base);
+        __syncthreads();
+        if (threadIdx.x < n) tile[threadIdx.x] = list[base + threadIdx.x];
+        __syncthreads();
+        if (i < N) {
+            for (int c = 0; c < n; ++c) {
+                const ChargedSite cs = tile[c];
+                if (cs.idx == i) continue;
+                const double r = 1e-10 * site_dist(xi, yi, zi, cs.x, cs.y, cs.z, laty, latz, pbc);
+                v += v_solve(r, cs.q, sigma, kk);
+            }
+        }
+    }
+    if (i < N) out[i] = v;
+}
+
+extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, const double *lattice, const double *sigma,
+                                         const double *k, const double *x, const double *y, const double *z,
+                                         const int *charge, double *out)
+{
+    (void)num_atoms_contact;
+    Engine &e = eng(); hipStream_t st = e.stream;
+    int *flag = (int *)scratch(S_MISC0, (size_t)N * 4), *off = (int *)scratch(S_MISC1, (size_t)N * 4);
+    int *cnt = (int *)scratch(S_PW_CNT, 16);
+    ChargedSite *list = (ChargedSite *)scratch(S_PW_LIST, (size_t)N * sizeof(ChargedSite));
+    if (!flag || !off || !cnt || !list) return e.err_code;
+    const int blocks = (N + 255) / 256;
+    hipLaunchKernelGGL(k_charge_flags, dim3(blocks), dim3(256), 0, st, N, charge, flag);
+    int rc = dkmc_exclusive_scan_i32(flag, off, N, cnt); if (rc) return rc;
+    hipLaunchKernelGGL(k_charge_scatter, dim3(blocks), dim3(256), 0, st, N, charge, off, x, y, z, list);
+    hipLaunchKernelGGL(k_pairwise, dim3((N + PW_NT - 1) / PW_NT), dim3(PW_NT), 0, st, N, x, y, z, lattice, pbc, sigma, k, list, cnt, out);
+    KCHK();
+    return 0;
+}

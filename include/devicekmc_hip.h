@@ -1,0 +1,174 @@
+/*
+ * devicekmc_hip.h -- C ABI of the MI355X (gfx950) KMC-superstep engine.
+ *
+ * Drop-in boundary for DeviceKMC's GPU path: every entry point below replaces one symbol of the
+ * reference's gpu_solvers.h / gpu_buffers.h surface (cited per function, paths relative to
+ * /root/reference/src).  Plain C types only: device pointers, sizes and scalars.  The C++ shim
+ * include/gpu_solvers.h + include/gpu_buffers.h re-exposes the reference's own names and
+ * signatures (GPUBuffers&, std::vector, RandomNumberGenerator&) on top of this header.
+ *
+ * Conventions
+ *  - all pointers named d_* are DEVICE pointers; h_* are host pointers;
+ *  - ELEMENT / EVENTTYPE are 4-byte ints with the reference's enum values (utils.h:37-60);
+ *  - one process drives one GPU; all work is enqueued on one HIP stream (dkmc_set_stream);
+ *  - functions return 0 on success, non-zero HIP/engine error code otherwise; the message is
+ *    available from dkmc_last_error().  (The reference prints CUDA errors and carries on,
+ *    utils.h:145-153; the shim does the same with the message.)
+ */
+#ifndef DEVICEKMC_HIP_H
+#define DEVICEKMC_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Mirror of the public members of class GPUBuffers (gpu_buffers.h:16-52). */
+typedef struct dkmc_gpubuf {
+    int *site_charge;
+    double *site_power, *site_potential_boundary, *site_potential_charge, *site_temperature;
+    double *site_CB_edge;
+    double *T_bg;
+    double *atom_power;
+    double *atom_CB_edge;
+    double *atom_virtual_potentials;
+    int *atom_charge;
+    int *site_element;
+    int *atom_element;
+    double *site_x, *site_y, *site_z;
+    double *atom_x, *atom_y, *atom_z;
+    int *metal_types;
+    double *sigma, *k, *lattice, *freq;
+    int *neigh_idx, *site_layer;
+    int *Device_row_ptr_d, *Device_col_indices_d;
+    int *contact_left_row_ptr, *contact_left_col_indices;
+    int *contact_right_row_ptr, *contact_right_col_indices;
+    int Device_nnz, contact_left_nnz, contact_right_nnz;
+    int num_metal_types_, N_, nn_, N_atom_;
+} dkmc_gpubuf;
+
+/* Per-call statistics of the last solver invocations (no reference twin; the reference prints
+ * "# CG steps" to stdout, iterative_solvers_gpu.cu:456). */
+typedef struct dkmc_stats {
+    int cg_iters_K, cg_iters_CB, cg_iters_X;
+    double cg_rr_K, cg_rr_CB, cg_rr_X;     /* final ||r||^2 of the scaled system */
+    int n_events;                          /* events executed by the last execute_kmc_step */
+    int n_charged;                         /* charged sites seen by the last poisson_gridless */
+    int N_atom;                            /* atoms found by the last update_power */
+    long long X_nnz;
+    double psum_last;                      /* sum of rates before the last executed event */
+} dkmc_stats;
+
+const char *dkmc_last_error(void);
+void dkmc_clear_error(void);
+const dkmc_stats *dkmc_get_stats(void);
+
+/* kmc_events.cu:15-32 */
+int dkmc_get_gpu_info(char *gpu_string, int capacity, int dev);
+int dkmc_set_gpu(int dev);
+/* stream all kernels are enqueued on (hipStream_t); NULL = the null stream (reference behaviour) */
+int dkmc_set_stream(void *hip_stream);
+int dkmc_synchronize(void);
+/* tolerance of solve_sparse_CG_Jacobi; the reference hard-codes 1e-6 (iterative_solvers_gpu.cu:322) */
+void dkmc_set_cg_tolerance(double tol);
+/* 0 (default): warm-start the current solve from gpubuf.atom_virtual_potentials exactly as the
+ * reference does (the buffer holds G0*m of the previous step, current_solver_gpu.cu:1015-1016);
+ * 1: warm-start from a private unscaled copy of the previous solution. */
+void dkmc_set_current_warm_start(int mode);
+
+/* ---- GPUBuffers (gpu_buffers.h:73-158, gpu_buffers.cpp:10-118) ---------------------------- */
+/* allocates every array of the struct with hipMalloc and uploads the constant ones */
+int dkmc_gpubuf_create(dkmc_gpubuf *buf, int N, int N_atom, int nn, int num_metal_types,
+                       const int *h_site_layer, const double *h_site_x, const double *h_site_y,
+                       const double *h_site_z, const int *h_neigh_idx, const int *h_metals,
+                       double freq, double sigma, double k, const double *h_lattice);
+int dkmc_gpubuf_free(dkmc_gpubuf *buf);
+/* sync_HostToGPU / sync_GPUToHost: the nine arrays of gpu_buffers.cpp:10-55 */
+int dkmc_gpubuf_sync_host_to_gpu(dkmc_gpubuf *buf, const int *h_site_element, const int *h_site_charge,
+                                 const double *h_site_power, const double *h_site_CB_edge,
+                                 const double *h_site_potential_boundary, const double *h_site_potential_charge,
+                                 const double *h_site_temperature, const double *h_atom_CB_edge, double T_bg);
+int dkmc_gpubuf_sync_gpu_to_host(const dkmc_gpubuf *buf, int *h_site_element, int *h_site_charge,
+                                 double *h_site_power, double *h_site_CB_edge,
+                                 double *h_site_potential_boundary, double *h_site_potential_charge,
+                                 double *h_site_temperature, double *h_atom_CB_edge, double *T_bg);
+int dkmc_copy_power_from_gpu(const dkmc_gpubuf *buf, double *h_power);          /* gpu_buffers.cpp:58-72 */
+int dkmc_copy_charge_to_gpu(dkmc_gpubuf *buf, const int *h_charge);             /* :88-93 */
+int dkmc_copy_Tbg_to_gpu(dkmc_gpubuf *buf, double T_bg);                        /* :75-80 */
+
+/* copytoConstMemory (kmc_events.cu:369-375): per-layer zero-field energies, at most 5 layers */
+int dkmc_copy_to_const_memory(const double *h_E_gen, const double *h_E_rec, const double *h_E_Vdiff,
+                              const double *h_E_Odiff, int num_layers);
+
+/* ---- sparsity of K: initialize_sparsity (iterative_solvers_gpu.cu:96-109) ------------------- */
+/* fills Device_*, contact_left_*, contact_right_* of buf (allocated by the library) */
+int dkmc_initialize_sparsity(dkmc_gpubuf *buf, int pbc, double nn_dist, int num_atoms_contact);
+
+/* ---- potential ------------------------------------------------------------------------------ */
+/* update_charge_gpu (potential_solver_gpu.cu:54-63) */
+int dkmc_update_charge_gpu(const int *d_site_element, int *d_site_charge, const int *d_neigh_idx,
+                           int N, int nn, const int *d_metals, int num_metals);
+/* update_CB_edge_gpu_sparse (potential_solver_gpu.cu:595-694) */
+int dkmc_update_CB_edge_gpu_sparse(dkmc_gpubuf *buf, int N, int N_left_tot, int N_right_tot, double Vd,
+                                   int pbc, double high_G, double low_G, double nn_dist, int num_metals);
+/* background_potential_gpu_sparse (potential_solver_gpu.cu:696-781) */
+int dkmc_background_potential_gpu_sparse(dkmc_gpubuf *buf, int N, int N_left_tot, int N_right_tot, double Vd,
+                                         int pbc, double high_G, double low_G, double nn_dist,
+                                         int num_metals, int kmc_step_count);
+/* poisson_gridless_gpu (potential_solver_gpu.cu:960-978) */
+int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, const double *d_lattice,
+                              const double *d_sigma, const double *d_k,
+                              const double *d_posx, const double *d_posy, const double *d_posz,
+                              const int *d_site_charge, double *d_site_potential_charge);
+
+/* solve_sparse_CG_Jacobi (iterative_solvers_gpu.cu:309-480): solves A y = x; overwrites A_data
+ * (scaled) and x (scaled rhs); y holds the warm start on entry and the solution on exit. */
+int dkmc_solve_sparse_CG_Jacobi(double *d_A_data, const int *d_A_row_ptr, const int *d_A_col_indices,
+                                int A_nnz, int m, double *d_x, double *d_y, int *iters_out, double *rr_out);
+
+/* ---- KMC events: execute_kmc_step_gpu (kmc_events.cu:146-365) ------------------------------- */
+/* The reference draws two numbers per executed event from the host RandomNumberGenerator
+ * (kmc_events.cu:221,348).  Here the caller passes the next n_uniform numbers of that stream
+ * (h_uniform[2e] selects event e, h_uniform[2e+1] draws its waiting time); *n_events_out tells how
+ * many events ran, i.e. 2 * n_events numbers were consumed.  If the stream runs out before the
+ * stop criterion (event_time >= 1/freq) is met, *exhausted_out is set and the call can be repeated
+ * with more numbers (state is kept in the site arrays).  h_event_log (optional, 4 ints per event):
+ * slot index, i, j, event type.  Returns the last event time through *event_time_out. */
+int dkmc_execute_kmc_step_gpu(int N, int nn, const int *d_neigh_idx, const int *d_site_layer,
+                              const double *d_lattice, int pbc, const double *d_T_bg, const double *d_freq,
+                              const double *d_sigma, const double *d_k,
+                              const double *d_posx, const double *d_posy, const double *d_posz,
+                              const double *d_site_potential_boundary, const double *d_site_potential_charge,
+                              const double *d_site_temperature, int *d_site_element, int *d_site_charge,
+                              const double *h_uniform, int n_uniform, int resume,
+                              int *n_events_out, int *exhausted_out, int *h_event_log, double *event_time_out);
+/* build_event_list only (kmc_events.cu:34-126); d_event_type may be NULL */
+int dkmc_build_event_list(int N, int nn, const int *d_neigh_idx, const int *d_site_layer,
+                          const double *d_lattice, int pbc, const double *d_T_bg, const double *d_freq,
+                          const double *d_sigma, const double *d_k,
+                          const double *d_posx, const double *d_posy, const double *d_posz,
+                          const double *d_site_potential_boundary, const double *d_site_potential_charge,
+                          const int *d_site_element, const int *d_site_charge,
+                          int *d_event_type, double *d_event_prob);
+
+/* ---- current / power: update_power_gpu_sparse (current_solver_gpu.cu:854-1147) --------------- */
+int dkmc_update_power_gpu_sparse(dkmc_gpubuf *buf, int num_source_inj, int num_ground_ext, int num_layers_contact,
+                                 double Vd, int pbc, double high_G, double low_G, double loop_G, double G0,
+                                 double tol, double nn_dist, double m_e, double V0, int num_metals,
+                                 double *h_imacro, int solve_heating_local, int solve_heating_global, double alpha_disp);
+/* Assemble_X_sparsity + Assemble_X2 of the last update_power call, copied to host for inspection
+ * (dump_csr_matrix_txt twin, iterative_solvers_gpu.cu:142-169).  Pass NULL pointers to query sizes. */
+int dkmc_get_last_X(int *rows_out, long long *nnz_out, int *h_row_ptr, int *h_col, double *h_data);
+
+/* ---- heat ------------------------------------------------------------------------------------ */
+/* update_temperatureglobal_gpu (heat_solver_gpu.cu:52-69), the reference's (uncalled) device form */
+int dkmc_update_temperatureglobal_gpu(const double *d_site_power, double *d_T_bg, int N, double a_coeff,
+                                      double b_coeff, double number_steps, double C_thermal, double small_step);
+/* the form the reference actually runs, on the host (heat_solver.cpp:316-350), done on the device */
+int dkmc_update_temperature_global_analytic(const double *d_site_power, double *d_T_bg, int N, double event_time,
+                                            double dissipation_constant, double t_ox, double A, double c_p,
+                                            double *h_P_tot);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

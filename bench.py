@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""KMC supersteps/s of the DeviceKMC hot path on MI355X.
+
+One "step" = one KMC superstep (kmc_main.cpp:175-279): charge update, background potential (K assembly +
+Jacobi-CG) + screened-Coulomb pair sum, event table + residence-time event loop, current solve (X assembly
++ Jacobi-CG + I_macro + dissipated power) and the global temperature update, on a synthetic device whose
+site fields are resident in HBM before the timed region.
+
+Workloads (config.workload):
+  7.5nm   the reference's own 85 071-site single device (structures/single_devices/timing_7.5nm; the
+          configuration its only full-step timing log is quoted on), V = 5, rnd_seed = 5   [default]
+  2.5nm   9 399 sites (configs[0], plumbing)
+  tile:K  the 2.5 nm cell tiled K x K laterally, e.g. tile:3 = 84 591 sites
+
+Contract: python bench.py --gpus N --steps K --warmup W ; prints ONE JSON line on rank 0.
+N > 1 (launched with torch.distributed.run): the reference has no multi-GPU path and this round shards nothing:
+every rank runs an independent replica of the workload on its own GPU ("replicas only"); value is the
+aggregate steps/s over all replicas.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def make_workload(name):
+    from devicekmc_amd import params, structure
+    g = os.path.join(ROOT, "tests", "golden")
+    if name == "7.5nm":
+        s = structure.load_structure(os.path.join(g, "device_7.5nm.npz"))
+        p = params.KMCParameters(rnd_seed=5, lattice=tuple(s.meta["lattice"]), num_atoms_first_layer=1296,
+                                 num_atoms_contact=12960, A=76.725e-10 * 76.725e-10)
+    elif name == "2.5nm":
+        s = structure.load_structure(os.path.join(g, "device_2.5nm.npz"))
+        p = params.KMCParameters()
+    elif name.startswith("tile:"):
+        k = int(name.split(":")[1])
+        cell = structure.load_structure(os.path.join(g, "device_2.5nm.npz"))
+        s = structure.tile_structure(cell, k, 25.575, 25.575, 1440)
+        p = params.KMCParameters().for_tiling(k)
+    else:
+        raise SystemExit("unknown workload " + name)
+    p.solve_heating_global = True
+    return s, p
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="7.5nm")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--warm-start", type=int, default=0, help="dkmc_set_current_warm_start mode (0 = reference)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    devname = "cuda:%d" % local_rank
+
+    from devicekmc_amd import host, lib
+    L = lib.load()
+    Vd = 5.0
+    s, p = make_workload(args.workload)
+    p.rnd_seed_kmc = 1 + rank                      # replicas follow different event streams
+    dev = host.Device(s, p)
+    sim = host.KMCProcess(dev, p.freq)
+    gb = dev.make_gpubuf(devname)
+    L.dkmc_set_current_warm_start(args.warm_start)
+    dev.setLaplacePotential(gb, p, Vd)
+    gb.sync_HostToGPU(dev)
+
+    phases = {"charge": 0.0, "potential": 0.0, "rates": 0.0, "current": 0.0, "heat": 0.0}
+    counters = {"events": 0, "cg_iters_K": 0, "cg_iters_X": 0}
+    prof = {"long_ms": 0.0, "long_n": 0, "short_ms": 0.0, "short_n": 0}
+
+    def sync():
+        torch.cuda.synchronize()
+
+    def step(k, timed):
+        t0 = time.perf_counter()
+        dev.updateCharge(gb)
+        if timed: sync()
+        t1 = time.perf_counter()
+        dev.updatePotential(gb, p, Vd, k)
+        if timed: sync()
+        t2 = time.perf_counter()
+        _, dt = sim.executeKMCStep(gb, dev)
+        t3 = time.perf_counter()
+        dev.updatePower(gb, p, Vd)
+        t4 = time.perf_counter()
+        dev.updateTemperature(gb, p, dt)
+        sync()
+        t5 = time.perf_counter()
+        if timed:
+            st = host.get_stats()
+            for key, v in zip(phases, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
+                phases[key] += v
+            counters["events"] += sim.last_n_events
+            counters["cg_iters_K"] += st["cg_iters_K"]
+            counters["cg_iters_X"] += st["cg_iters_X"]
+            prof["long_ms"] += st["spmv_long_ms"]; prof["long_n"] += st["spmv_long_launches"]
+            prof["short_ms"] += st["spmv_short_ms"]; prof["short_n"] += st["spmv_short_launches"]
+        return dt
+
+    for k in range(args.warmup):
+        step(k, False)
+    L.dkmc_set_profiling(1)
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t_start = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k, True)
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t_start
+    L.dkmc_set_profiling(0)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=devname)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    st = host.get_stats()
+    # ---- roofline of the dominant kernel: k_spmv<64, M_AP> (wave-per-row CSR SpMV over the tunnelling rows of X) ----
+    roof = None
+    if prof["long_n"] > 0:
+        avg_ms = prof["long_ms"] / prof["long_n"]
+        # algorithmic bytes per launch: 12 B per stored non-zero (value + column) + per row 8 B of row pointers,
+        # 8 B result written, 8 B of p read for the fused dot
+        bytes_per_launch = 12.0 * st["spmv_long_nnz"] + 24.0 * st["spmv_long_rows"]
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get("k_spmv_long_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": "k_spmv<64,M_AP>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "avg_launch_us": round(avg_ms * 1e3, 2), "launches": prof["long_n"],
+                "algorithmic_bytes_per_launch": bytes_per_launch}
+
+    # ---- CPU baseline: the oracle (own OpenMP port of the same step) on this box's host cores, rank 0, N=1 only ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as oc
+        ncores = os.cpu_count() or 1
+        os.environ.setdefault("OMP_NUM_THREADS", str(ncores))
+        o = oc.OracleKMC(s.element, s.x, s.y, s.z, p)
+        o.set_laplace_potential(Vd)
+        o.superstep(Vd)                              # untimed: cold-start CG of the first step
+        t0 = time.perf_counter()
+        nsamp = 1 if s.N > 30000 else 5
+        for _ in range(nsamp):
+            o.superstep(Vd)
+        tc = (time.perf_counter() - t0) / nsamp
+        cpu = {"value": round(1.0 / tc, 5), "unit": "KMC steps/s", "cores": ncores, "kind": "port",
+               "sample": "%d superstep(s) of the same workload after one untimed step (oracle/kmc_oracle.c, OpenMP)" % nsamp,
+               "ms_per_step": round(tc * 1e3, 1),
+               "split_ms": {k: round(v * 1e3, 2) for k, v in o.timing.items()}}
+
+    if rank == 0:
+        n = args.steps
+        out = {
+            "metric": "KMC steps/sec", "value": round(world * n / elapsed, 4), "unit": "KMC steps/s",
+            "n_gpus": world, "steps": n, "warmup": args.warmup, "ms_per_step": round(elapsed / n * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": args.workload, "sites": int(s.N), "nn": int(dev.max_num_neighbors), "atoms": int(dev.N_atom),
+                       "Vd": Vd, "phases": "charge+potential+rates+current+heat", "parallelism": "replicas x%d" % world,
+                       "current_warm_start": args.warm_start, "cg_tol": p.cg_tol},
+            "split_ms": {k: round(v / n * 1e3, 3) for k, v in phases.items()},
+            "per_step": {"events": counters["events"] / n, "cg_iters_K": counters["cg_iters_K"] / n,
+                         "cg_iters_X": counters["cg_iters_X"] / n, "X_nnz": int(st["X_nnz"])},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,7 @@
 //     read as contiguous 64/128-byte segments.
 // HBM traffic per iteration (algorithmic): 12*nnz + 4*(m+1) + 96*m bytes.
 #include "common.h"
+#include <vector>
 
 #define CG_NT 256
 #define CG_MAX_PART 1024        // max blocks writing partials per kernel family
@@ -224,23 +225,58 @@ int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, dou
     hipLaunchKernelGGL(k_cg_check0, dim3(1), dim3(CG_NT), 0, st, part_rr, np_spmv, ctrl, tol2);
     KCHK();
 
+    // ---- optional kernel profile: HIP events around every A*p launch (bench.py roofline) ----
+    const bool prof = e.profiling && !uniform_rows;
+    static hipEvent_t evs[3 * 64]; static bool evs_ready = false;
+    double prof_short_ms = 0.0, prof_long_ms = 0.0; int prof_short_n = 0, prof_long_n = 0;
+    if (prof) {
+        if (!evs_ready) { for (auto &ev : evs) HIPCHK(hipEventCreate(&ev)); evs_ready = true; }
+        std::vector<int> hrp((size_t)m + 1);
+        HIPCHK(hipMemcpy(hrp.data(), rp, ((size_t)m + 1) * 4, hipMemcpyDeviceToHost));
+        long long nl = 0, nsh = 0;
+        for (int i = 0; i < m; ++i) { const int c = hrp[i + 1] - hrp[i]; if (c > LONG_ROW_NNZ) nl += c; else nsh += c; }
+        e.stats.spmv_long_nnz = nl; e.stats.spmv_short_nnz = nsh; e.stats.spmv_long_rows = n_long; e.stats.spmv_short_rows = n_short;
+    }
     // ---- iterations, launched in batches; the host polls the control block between batches ----
-    int it = 0, batch = 8;
+    int it = 0, batch = 8, launched = 0;
     CgCtrl h{};
     for (;;) {
         HIPCHK(hipMemcpyAsync(&h, ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        if (prof && launched) {       // only launches that did work (iteration index below the final count) are counted
+            for (int b = 0; b < launched; ++b) {
+                if (it - launched + b >= h.iters) break;
+                float ms = 0.f;
+                if (gs) { HIPCHK(hipEventElapsedTime(&ms, evs[3 * b], evs[3 * b + 1])); prof_short_ms += ms; ++prof_short_n; }
+                if (gl) { HIPCHK(hipEventElapsedTime(&ms, evs[3 * b + 1], evs[3 * b + 2])); prof_long_ms += ms; ++prof_long_n; }
+            }
+        }
         if (h.done) break;
         if (it >= 200000) { dkmc_fail(4, "CG: no convergence after 200000 iterations", __FILE__, __LINE__); break; }
         for (int b = 0; b < batch; ++b, ++it) {
-            SPMV(M_AP, (const double *)p, t, (double *)nullptr, (double *)nullptr, part_pAp);
+            if (prof) {
+                HIPCHK(hipEventRecord(evs[3 * b], st));
+                if (gs) hipLaunchKernelGGL((k_spmv<16, M_AP>), dim3(gs), dim3(CG_NT), 0, st, n_short, short_rows, rp, ci, a, (const double *)p, t,
+                                           (double *)nullptr, (double *)nullptr, part_pAp, ctrl);
+                HIPCHK(hipEventRecord(evs[3 * b + 1], st));
+                if (gl) hipLaunchKernelGGL((k_spmv<64, M_AP>), dim3(gl), dim3(CG_NT), 0, st, n_long, long_rows, rp, ci, a, (const double *)p, t,
+                                           (double *)nullptr, (double *)nullptr, part_pAp + gs, ctrl);
+                HIPCHK(hipEventRecord(evs[3 * b + 2], st));
+            } else {
+                SPMV(M_AP, (const double *)p, t, (double *)nullptr, (double *)nullptr, part_pAp);
+            }
             hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(CG_NT), 0, st, m, it, part_pAp, np_spmv, p, t, y, r, part_rr, ctrl);
             hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(CG_NT), 0, st, m, it, part_rr, gv, r, p, ctrl, tol2);
         }
+        launched = batch;
         KCHK();
         if (batch < 64) batch *= 2;
     }
 #undef SPMV
+    if (prof) {
+        e.stats.spmv_long_ms = prof_long_ms; e.stats.spmv_short_ms = prof_short_ms;
+        e.stats.spmv_long_launches = prof_long_n; e.stats.spmv_short_launches = prof_short_n;
+    }
     // ---- un-scale the solution (:459) ----
     hipLaunchKernelGGL(k_vec_mul, dim3(gv), dim3(CG_NT), 0, st, m, y, s);
     KCHK();

@@ -107,6 +107,7 @@ struct Engine {
     int device = 0;
     double cg_tol = 1e-6;
     int current_warm_start = 0;
+    int profiling = 0;
     dkmc_stats stats{};
     char err[512] = {0};
     int err_code = 0;

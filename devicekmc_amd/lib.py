@@ -29,7 +29,11 @@ class dkmc_stats(C.Structure):
     _fields_ = [("cg_iters_K", C.c_int), ("cg_iters_CB", C.c_int), ("cg_iters_X", C.c_int),
                 ("cg_rr_K", C.c_double), ("cg_rr_CB", C.c_double), ("cg_rr_X", C.c_double),
                 ("n_events", C.c_int), ("n_charged", C.c_int), ("N_atom", C.c_int),
-                ("X_nnz", C.c_longlong), ("psum_last", C.c_double)]
+                ("X_nnz", C.c_longlong), ("psum_last", C.c_double),
+                ("spmv_long_ms", C.c_double), ("spmv_short_ms", C.c_double),
+                ("spmv_long_launches", C.c_int), ("spmv_short_launches", C.c_int),
+                ("spmv_long_nnz", C.c_longlong), ("spmv_short_nnz", C.c_longlong),
+                ("spmv_long_rows", C.c_int), ("spmv_short_rows", C.c_int)]
 
 
 # every symbol include/devicekmc_hip.h declares: name -> (restype, argtypes)
@@ -44,6 +48,7 @@ SYMBOLS = {
     "dkmc_synchronize": (_I, []),
     "dkmc_set_cg_tolerance": (None, [_D]),
     "dkmc_set_current_warm_start": (None, [_I]),
+    "dkmc_set_profiling": (None, [_I]),
     "dkmc_gpubuf_create": (_I, [C.POINTER(dkmc_gpubuf), _I, _I, _I, _I, vp, vp, vp, vp, vp, vp, _D, _D, _D, vp]),
     "dkmc_gpubuf_free": (_I, [C.POINTER(dkmc_gpubuf)]),
     "dkmc_gpubuf_sync_host_to_gpu": (_I, [C.POINTER(dkmc_gpubuf), vp, vp, vp, vp, vp, vp, vp, vp, _D]),

@@ -56,6 +56,12 @@ typedef struct dkmc_stats {
     int N_atom;                            /* atoms found by the last update_power */
     long long X_nnz;
     double psum_last;                      /* sum of rates before the last executed event */
+    /* kernel profile (dkmc_set_profiling(1)): HIP-event time of the SpMV launches (A*p) of the last CG solve
+     * on X, split into the wave-per-row kernel (long rows) and the 16-lanes-per-row kernel (short rows) */
+    double spmv_long_ms, spmv_short_ms;
+    int spmv_long_launches, spmv_short_launches;
+    long long spmv_long_nnz, spmv_short_nnz;
+    int spmv_long_rows, spmv_short_rows;
 } dkmc_stats;
 
 const char *dkmc_last_error(void);
@@ -74,6 +80,9 @@ void dkmc_set_cg_tolerance(double tol);
  * reference does (the buffer holds G0*m of the previous step, current_solver_gpu.cu:1015-1016);
  * 1: warm-start from a private unscaled copy of the previous solution. */
 void dkmc_set_current_warm_start(int mode);
+/* 1: bracket every SpMV launch of the CG solves with HIP events on the engine's stream and accumulate
+ * their durations into dkmc_stats (measurement aid for bench.py; off by default) */
+void dkmc_set_profiling(int on);
 
 /* ---- GPUBuffers (gpu_buffers.h:73-158, gpu_buffers.cpp:10-118) ---------------------------- */
 /* allocates every array of the struct with hipMalloc and uploads the constant ones */

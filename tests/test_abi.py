@@ -1,0 +1,50 @@
+"""The C-ABI library loads and exports exactly what include/devicekmc_hip.h declares (no GPU needed)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "devicekmc_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dkmc_\w+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from devicekmc_amd import lib
+    L = lib.load()
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(L, n), n
+    assert set(names) == set(lib.SYMBOLS), set(names) ^ set(lib.SYMBOLS)
+
+
+def test_struct_layout_matches_header():
+    from devicekmc_amd import lib
+    src = open(os.path.join(ROOT, "include", "devicekmc_hip.h")).read()
+    body = src[src.index("typedef struct dkmc_gpubuf {"):src.index("} dkmc_gpubuf;")]
+    fields = []
+    for line in body.splitlines()[1:]:
+        line = line.split("/*")[0].strip().rstrip(";")
+        if not line:
+            continue
+        typ, rest = line.split(None, 1)
+        for f in rest.split(","):
+            fields.append(f.strip().lstrip("*"))
+    assert fields == [f[0] for f in lib.dkmc_gpubuf._fields_]
+    assert ctypes.sizeof(lib.dkmc_gpubuf) == 32 * 8 + 7 * 4 + 4      # 32 pointers, 7 ints, tail padding
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from devicekmc_amd import lib
+    monkeypatch.setattr(lib, "_lib", None)
+    monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError):
+        lib.load()

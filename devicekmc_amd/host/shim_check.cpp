@@ -1,0 +1,32 @@
+// Compile-only check that the C++ drop-in headers are self-consistent and usable from plain host C++
+// (no HIP headers needed by the caller).  Mirrors one KMC superstep of kmc_main.cpp:175-279.
+#include "gpu_solvers.h"
+
+struct HostDevice {             // the subset of Device (Device.h:66-106) the shim touches
+    int N = 0, N_atom = 0, max_num_neighbors = 0;
+    double T_bg = 300.0;
+    std::vector<ELEMENT> site_element;
+    std::vector<int> site_charge, neigh_idx;
+    std::vector<double> site_x, site_y, site_z, site_power, site_CB_edge, site_potential_boundary, site_potential_charge,
+        site_temperature, atom_CB_edge;
+};
+
+double kmc_superstep(HostDevice &device, GPUBuffers &gpubuf, RandomNumberGenerator &rng, double Vd, int n_first_layer, int pbc,
+                     double nn_dist, int step)
+{
+    dkmc_handle_t h = nullptr;
+    update_charge_gpu(reinterpret_cast<ELEMENT *>(gpubuf.site_element), gpubuf.site_charge, gpubuf.neigh_idx, gpubuf.N_, gpubuf.nn_,
+                      reinterpret_cast<const ELEMENT *>(gpubuf.metal_types), gpubuf.num_metal_types_);
+    background_potential_gpu_sparse(h, h, gpubuf, device.N, n_first_layer, n_first_layer, Vd, pbc, 1.0, 1e-8, nn_dist, gpubuf.num_metal_types_, step);
+    poisson_gridless_gpu(n_first_layer, pbc, gpubuf.N_, gpubuf.lattice, gpubuf.sigma, gpubuf.k, gpubuf.site_x, gpubuf.site_y, gpubuf.site_z,
+                         gpubuf.site_charge, gpubuf.site_potential_charge);
+    double dt = execute_kmc_step_gpu(device.N, device.max_num_neighbors, gpubuf.neigh_idx, gpubuf.site_layer, gpubuf.lattice, pbc, gpubuf.T_bg,
+                                     gpubuf.freq, gpubuf.sigma, gpubuf.k, gpubuf.site_x, gpubuf.site_y, gpubuf.site_z,
+                                     gpubuf.site_potential_boundary, gpubuf.site_potential_charge, gpubuf.site_temperature,
+                                     reinterpret_cast<ELEMENT *>(gpubuf.site_element), gpubuf.site_charge, rng, device.neigh_idx.data());
+    double imacro = 0.0;
+    update_power_gpu_sparse(h, h, gpubuf, n_first_layer, n_first_layer, 10, Vd, pbc, 1e5, 1e-8, 1e7, 2 * 3.8612e-5 * 1e-5, 1.60217663e-19 * 0.01,
+                            nn_dist, 0.85 * 9.11e-31, 1.6, gpubuf.num_metal_types_, &imacro, false, true, 1.0);
+    gpubuf.sync_GPUToHost(device);
+    return dt;
+}

@@ -140,25 +140,40 @@ def main():
         elapsed = float(tt.item())
 
     st = host.get_stats()
-    # ---- roofline of the dominant kernel: k_spmv<64, M_AP> (wave-per-row CSR SpMV over the tunnelling rows of X) ----
+    # ---- roofline of the dominant kernel: k_spmv_ap (CSR SpMV t = X p of the current solve's CG, fused p.t) ----
     roof = None
     if prof["long_n"] > 0:
         avg_ms = prof["long_ms"] / prof["long_n"]
         # algorithmic bytes per launch: 12 B per stored non-zero (value + column) + per row 8 B of row pointers,
-        # 8 B result written, 8 B of p read for the fused dot
-        bytes_per_launch = 12.0 * st["spmv_long_nnz"] + 24.0 * st["spmv_long_rows"]
+        # 8 B result written, 8 B of p read for the fused dot; one launch covers every row of X
+        nnz_all = st["spmv_long_nnz"] + st["spmv_short_nnz"]
+        rows_all = st["spmv_long_rows"] + st["spmv_short_rows"]
+        if st["spmv_segments"] > 0:
+            # dense-run mode: the dominant kernel is k_spmv_segs (one wave per <= 2048-entry segment of a tunnelling row);
+            # its layout moves 8 B per entry (value only; the direction vector is compacted over S and stays in L2),
+            # 16 B per segment descriptor and 8 B per segment result.  The CSR formulation of the same product
+            #  would move 12 B per entry.
+            kname = "k_spmv_segs"
+            bytes_per_launch = 8.0 * st["spmv_segment_entries"] + 24.0 * st["spmv_segments"]
+            csr_equiv = 12.0 * st["spmv_segment_entries"] + 24.0 * st["spmv_long_rows"]
+        else:
+            kname = "k_spmv_ap"
+            bytes_per_launch = 12.0 * nnz_all + 24.0 * rows_all
+            csr_equiv = bytes_per_launch
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_r01.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.workload, {}).get("k_spmv_long_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(args.workload, {}).get(kname + "_bytes_per_launch")
             except Exception:
                 traffic = None
-        roof = {"bound": "hbm", "kernel": "k_spmv<64,M_AP>", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "avg_launch_us": round(avg_ms * 1e3, 2), "launches": prof["long_n"],
-                "algorithmic_bytes_per_launch": bytes_per_launch}
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "csr_equivalent_GBps": round(csr_equiv / (avg_ms * 1e-3) / 1e9, 1),
+                "row_kernel_us": round(prof["short_ms"] / max(prof["short_n"], 1) * 1e3, 2)}
 
     # ---- CPU baseline: the oracle (own OpenMP port of the same step) on this box's host cores, rank 0, N=1 only ----
     cpu = None

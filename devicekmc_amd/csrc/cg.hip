@@ -15,9 +15,10 @@
 // HBM traffic per iteration (algorithmic): 12*nnz + 4*(m+1) + 96*m bytes.
 #include "common.h"
 #include <vector>
+#include <stdlib.h>
 
 #define CG_NT 256
-#define CG_MAX_PART 1024        // max blocks writing partials per kernel family
+#define CG_MAX_PART 2048        // max blocks writing partials per kernel family
 #define LONG_ROW_NNZ 192        // rows with more entries go to the wave-per-row bin
 
 struct CgCtrl {                 // device-resident control block
@@ -28,6 +29,12 @@ struct CgCtrl {                 // device-resident control block
 };
 
 enum { M_SCALE = 0, M_INIT = 1, M_AP = 2, M_DIAG = 3 };
+
+// dense-run view of long rows (see k_build_runs)
+#define RUN_MIN_LEN 32
+#define REM_SEG_LEN 256
+#define SEG_LEN 2048           // entries per segment = work item of one wave in k_spmv_segs
+struct __attribute__((aligned(16))) RunDesc { int pos, len, sr0, pad; };
 
 // block-uniform read of the stop flag (only the last kernel of an iteration ever sets it)
 __device__ __forceinline__ bool cg_done(const CgCtrl *ctrl)
@@ -99,6 +106,82 @@ __global__ __launch_bounds__(CG_NT) void k_spmv(int nrows, const int *__restrict
     }
 }
 
+// ---- hot kernel of the CG loop: t = A p with the partial p.t, short and long rows in ONE launch -------------------
+// Blocks [0, gs) take the short rows (16 lanes per row, 64 rows per pass), blocks [gs, gs+gl) the long rows
+// (one wave64 per row, 4 independent 64-entry strips in flight per lane).  1024-thread workgroups: 16 waves per
+// workgroup keep <= 1024 partials while every CU holds 32 waves; the matrix stream (12 B per non-zero, read once per
+// launch) uses non-temporal loads so that it does not evict the gathered vector from L2.
+#define SPMV_NT 1024
+template <int VAR, int RUNS>
+__global__ __launch_bounds__(SPMV_NT) void k_spmv_ap(int n_short, const int *__restrict__ short_rows, int gs,
+                                                     int n_long, const int *__restrict__ long_rows,
+                                                     const int *__restrict__ rp, const int *__restrict__ ci,
+                                                     const double *__restrict__ a, const double *__restrict__ p,
+                                                     double *__restrict__ t, double *__restrict__ part, const CgCtrl *ctrl,
+                                                     const RunDesc *__restrict__ runs, const int *__restrict__ nruns,
+                                                     const int *__restrict__ rem, const int *__restrict__ nrem,
+                                                     const double *__restrict__ pS, const int *__restrict__ seg_off)
+{
+    __shared__ double red[SPMV_NT / 64];
+    __shared__ int sdone;
+    if (threadIdx.x == 0) sdone = ctrl->done;
+    __syncthreads();
+    if (sdone) return;
+    double acc = 0.0;
+    if ((int)blockIdx.x < gs) {
+        const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+        for (int ridx = blockIdx.x * (SPMV_NT / 16) + g; ridx < n_short; ridx += gs * (SPMV_NT / 16)) {
+            const int row = short_rows ? short_rows[ridx] : ridx;
+            const int p0 = rp[row], p1 = rp[row + 1];
+            double s = 0.0;
+            for (int q = p0 + l; q < p1; q += 16) s += a[q] * p[ci[q]];
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+            if (l == 0) { t[row] = s; acc += p[row] * s; }
+        }
+    } else if (RUNS) {
+        // stage 2 of the long-row product: 16 lanes per row add the row's segment partials (fixed order) and its few
+        // entries outside long runs (columns outside S, boundary columns)
+        const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+        const int gl = gridDim.x - gs;
+        for (int ridx = (blockIdx.x - gs) * (SPMV_NT / 16) + g; ridx < n_long; ridx += gl * (SPMV_NT / 16)) {
+            const int row = long_rows[ridx];
+            double s = 0.0;
+            const int nsg = nruns[ridx];
+            const double *sp = pS + seg_off[ridx];            // pS slot carries the segment partials in this mode
+            for (int j = l; j < nsg; j += 16) s += sp[j];
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+            if (l == 0) { t[row] = s; acc += p[row] * s; }
+        }
+    } else {
+        const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int gl = gridDim.x - gs;
+        // rows are dealt to waves with stride gl, so that every workgroup gets a mix of the heavy rows (left-contact
+        // and vacancy rows, ~3x the entries) and the light ones instead of 16 neighbours of the same class
+        for (int ridx = w * gl + (blockIdx.x - gs); ridx < n_long; ridx += gl * (SPMV_NT / 64)) {
+            const int row = long_rows[ridx];
+            const int p0 = rp[row], p1 = rp[row + 1];
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int q = p0 + lane;
+            for (; q + 192 < p1; q += 256) {
+                const int c0 = __builtin_nontemporal_load(ci + q), c1 = __builtin_nontemporal_load(ci + q + 64);
+                const int c2 = __builtin_nontemporal_load(ci + q + 128), c3 = __builtin_nontemporal_load(ci + q + 192);
+                const double a0 = __builtin_nontemporal_load(a + q), a1 = __builtin_nontemporal_load(a + q + 64);
+                const double a2 = __builtin_nontemporal_load(a + q + 128), a3 = __builtin_nontemporal_load(a + q + 192);
+                if (VAR == 1) { s0 += a0 * (double)c0; s1 += a1 * (double)c1; s2 += a2 * (double)c2; s3 += a3 * (double)c3; }
+                else { s0 += a0 * p[c0]; s1 += a1 * p[c1]; s2 += a2 * p[c2]; s3 += a3 * p[c3]; }
+            }
+            for (; q < p1; q += 64) s0 += __builtin_nontemporal_load(a + q) * p[__builtin_nontemporal_load(ci + q)];
+            double s = (s0 + s1) + (s2 + s3);
+            s = wave_sum(s);
+            if (lane == 0) { t[row] = s; acc += p[row] * s; }
+        }
+    }
+    const double tot = block_sum_all<SPMV_NT>(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
 // after M_INIT: rr0 and the first stop test on the 2-norm (cublasDnrm2, :418)
 __global__ __launch_bounds__(CG_NT) void k_cg_check0(const double *part, int npart, CgCtrl *ctrl, double tol2)
 {
@@ -131,13 +214,17 @@ __global__ __launch_bounds__(CG_NT) void k_cg_update(int m, int it, const double
 // beta = rr' / rr ; p = beta p - r ; stop test on rr' (cublasDdot :448)
 __global__ __launch_bounds__(CG_NT) void k_cg_direction(int m, int it, const double *__restrict__ part_rr, int npart,
                                                         const double *__restrict__ r, double *__restrict__ p,
-                                                        CgCtrl *ctrl, double tol2)
+                                                        CgCtrl *ctrl, double tol2, const int *__restrict__ srank, double *__restrict__ pS)
 {
     __shared__ double red[CG_NT / 64];
     if (cg_done(ctrl)) return;
     const double rr_new = reduce_partials(part_rr, npart, red);
     const double beta = rr_new / ctrl->rr[it & 1];
-    for (int i = blockIdx.x * CG_NT + threadIdx.x; i < m; i += gridDim.x * CG_NT) p[i] = p[i] * beta - r[i];
+    for (int i = blockIdx.x * CG_NT + threadIdx.x; i < m; i += gridDim.x * CG_NT) {
+        const double pn = p[i] * beta - r[i];
+        p[i] = pn;
+        if (srank) { const int k = srank[i]; if (k >= 0) pS[k] = pn; }      // compact copy over the tunnelling set
+    }
     // Block 0 publishes the scalars of the next iteration.  Setting `done` while other blocks of this
     // launch may still be starting is harmless: a block that sees it skips a p update nobody reads.
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -150,6 +237,118 @@ __global__ __launch_bounds__(CG_NT) void k_cg_direction(int m, int it, const dou
 __global__ __launch_bounds__(CG_NT) void k_vec_mul(int m, double *__restrict__ y, const double *__restrict__ s)
 {
     for (int i = blockIdx.x * CG_NT + threadIdx.x; i < m; i += gridDim.x * CG_NT) y[i] = y[i] * s[i];
+}
+
+// ---- index-free "dense run" view of the long rows (tunnelling block of X) ------------------------------------------------
+// In a long row of X nearly every entry belongs to a long sequence of consecutive columns *in the numbering of the
+// tunnelling set S* (99 % of the entries at 85 k sites sit in runs of >= 32): the block is dense up to class structure.
+// A run (pos, len, sr0) says: a[pos .. pos+len) multiplies pS[sr0 .. sr0+len), where pS is the direction vector compacted
+// over S.  The hot kernel then streams 8 B per entry (values only), reads pS with contiguous loads and needs no column
+// indices; the few entries outside long runs (neighbours outside S, boundary columns) go through a per-row remainder list.
+
+__global__ __launch_bounds__(256) void k_build_runs(int n_long, const int *__restrict__ long_rows, const int *__restrict__ rp,
+                                                    const int *__restrict__ ci, const int *__restrict__ srank,
+                                                    RunDesc *__restrict__ runs, int *__restrict__ nruns,
+                                                    int *__restrict__ rem, int *__restrict__ nrem)
+{
+    const int lane = threadIdx.x & 63;
+    const int ridx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ridx >= n_long) return;
+    const int row = long_rows[ridx];
+    const int p0 = rp[row], p1 = rp[row + 1];
+    const int run_base = p0 / RUN_MIN_LEN + ridx;
+    int nr = 0, nrm = 0;
+    int cur_start = p0, cur_sr0 = -1, carry = -2;
+    auto finalize = [&](int sA, int eA, int sr0) {
+        const int len = eA - sA;
+        if (len <= 0) return;
+        if (len >= RUN_MIN_LEN && sr0 >= 0) {       // long run: emitted as segments of at most SEG_LEN entries
+            for (int c = 0; c < len; c += SEG_LEN) {
+                if (lane == 0) { RunDesc d; d.pos = sA + c; d.len = min(SEG_LEN, len - c); d.sr0 = sr0 + c; d.pad = ridx; runs[run_base + nr] = d; }
+                ++nr;
+            }
+        } else {
+            for (int k = lane; k < len; k += WAVE) rem[p0 + nrm + k] = sA + k;
+            nrm += len;
+        }
+    };
+    for (int c0 = p0; c0 < p1; c0 += WAVE) {
+        const int q = c0 + lane;
+        const bool valid = q < p1;
+        const int sr = valid ? srank[ci[q]] : -1;
+        int prev = __shfl_up(sr, 1, WAVE);
+        if (lane == 0) prev = carry;
+        const bool brk = valid && (q == p0 || sr < 0 || prev < 0 || sr != prev + 1);
+        unsigned long long mask = __ballot(brk);
+        while (mask) {
+            const int b = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int s_new = c0 + b;
+            finalize(cur_start, s_new, cur_sr0);
+            cur_start = s_new;
+            cur_sr0 = __shfl(sr, b, WAVE);
+        }
+        carry = __shfl(sr, 63, WAVE);
+    }
+    finalize(cur_start, p1, cur_sr0);
+    // the entries outside long runs become "gather segments" (sr0 = -1): chunks of the row's remainder list
+    for (int c = 0; c < nrm; c += REM_SEG_LEN) {
+        if (lane == 0) { RunDesc d; d.pos = p0 + c; d.len = min(REM_SEG_LEN, nrm - c); d.sr0 = -1; d.pad = ridx; runs[run_base + nr] = d; }
+        ++nr;
+    }
+    if (lane == 0) { nruns[ridx] = nr; nrem[ridx] = nrm; }
+}
+
+__global__ __launch_bounds__(256) void k_compact_pS(int m, const int *__restrict__ srank, const double *__restrict__ p, double *__restrict__ pS)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < m) { const int r = srank[i]; if (r >= 0) pS[r] = p[i]; }
+}
+
+// gather the per-row descriptor lists (stored at capacity offsets) into one dense segment array
+__global__ __launch_bounds__(256) void k_compact_segs(int n_long, const int *__restrict__ long_rows, const int *__restrict__ rp,
+                                                      const RunDesc *__restrict__ runs, const int *__restrict__ nruns,
+                                                      const int *__restrict__ seg_off, RunDesc *__restrict__ segs)
+{
+    const int lane = threadIdx.x & 63;
+    const int ridx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ridx >= n_long) return;
+    const RunDesc *src = runs + (rp[long_rows[ridx]] / RUN_MIN_LEN + ridx);
+    RunDesc *dst = segs + seg_off[ridx];
+    for (int j = lane; j < nruns[ridx]; j += WAVE) dst[j] = src[j];
+}
+
+// stage 1 of the long-row product: one wave64 per segment, seg_part[seg] = sum a[pos+k] * pS[sr0+k].
+// Streams 8 B per entry with 4 independent 512-byte strips in flight per wave; every wave has the same amount of work.
+#define SEGK_NT 256
+__global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *__restrict__ segs, const double *__restrict__ a,
+                                                       const double *__restrict__ pS, double *__restrict__ seg_part, const CgCtrl *ctrl,
+                                                       const int *__restrict__ rem, const int *__restrict__ ci, const double *__restrict__ p)
+{
+    if (ctrl->done) return;                  // no barrier in this kernel: a per-wave read is fine
+    const int lane = threadIdx.x & 63;
+    const int seg = blockIdx.x * (SEGK_NT / 64) + (threadIdx.x >> 6);
+    if (seg >= nseg) return;
+    const RunDesc d = segs[seg];
+    if (d.sr0 < 0) {                         // gather segment: entries outside long runs (<1 % of the matrix)
+        double g = 0.0;
+        for (int k = lane; k < d.len; k += 64) { const int q = rem[d.pos + k]; g += a[q] * p[ci[q]]; }
+        g = wave_sum(g);
+        if (lane == 0) seg_part[seg] = g;
+        return;
+    }
+    const double *av = a + d.pos, *pv = pS + d.sr0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = lane;
+    for (; k + 192 < d.len; k += 256) {
+        const double a0 = __builtin_nontemporal_load(av + k), a1 = __builtin_nontemporal_load(av + k + 64);
+        const double a2 = __builtin_nontemporal_load(av + k + 128), a3 = __builtin_nontemporal_load(av + k + 192);
+        s0 += a0 * pv[k]; s1 += a1 * pv[k + 64]; s2 += a2 * pv[k + 128]; s3 += a3 * pv[k + 192];
+    }
+    for (; k < d.len; k += 64) s0 += __builtin_nontemporal_load(av + k) * pv[k];
+    double s = (s0 + s1) + (s2 + s3);
+    s = wave_sum(s);
+    if (lane == 0) seg_part[seg] = s;
 }
 
 // row binning: flag long rows, build the two row lists
@@ -172,9 +371,10 @@ static inline int grid_for(int work_items, int per_block)
     return (int)b;
 }
 
-// Internal entry: uniform_rows != 0 skips the binning (K: every row is short).
+// Internal entry: uniform_rows != 0 skips the binning (K: every row is short).  srank (optional, per row/column of
+// the system: rank in the tunnelling set or -1) enables the dense-run view of the long rows.
 int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, double *x, double *y,
-                    int uniform_rows, int *iters_out, double *rr_out)
+                    int uniform_rows, const int *srank, int ns, int *iters_out, double *rr_out)
 {
     Engine &e = eng(); hipStream_t st = e.stream;
     if (m <= 0) { if (iters_out) *iters_out = 0; if (rr_out) *rr_out = 0; return 0; }
@@ -208,6 +408,11 @@ int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, dou
     const int gl = n_long > 0 ? grid_for(n_long, CG_NT / 64) : 0;      // long-row blocks
     const int gv = grid_for(m, CG_NT);                                 // vector-kernel blocks
     const int np_spmv = gs + gl;
+    // hot SpMV (k_spmv_ap): 1024-thread workgroups, short rows 64 per pass, long rows 16 per pass
+    const int hs = n_short > 0 ? grid_for(n_short, SPMV_NT / 16) : 0;
+    const int hl = n_long > 0 ? grid_for(n_long, SPMV_NT / 64) : 0;
+    const int hl2 = n_long > 0 ? grid_for(n_long, SPMV_NT / 16) : 0;    // long rows in the two-stage (segment) mode
+    int np_ap = hs + hl;
 
 #define SPMV(MODE, vin, vout, a0, a1, partp)                                                                          \
     do {                                                                                                             \
@@ -217,12 +422,38 @@ int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, dou
                                    vin, vout, a0, a1, (partp) ? (partp) + gs : nullptr, ctrl);                       \
     } while (0)
 
+    // ---- dense-run view of the long rows ----
+    static const int use_runs_env = getenv("DKMC_NO_RUNS") ? 0 : 1;
+    const bool use_runs = use_runs_env && srank && n_long > 0 && ns > 0;
+    RunDesc *runs = nullptr, *segs = nullptr; int *nruns = nullptr, *rem = nullptr, *nrem = nullptr, *seg_off = nullptr; double *pS = nullptr, *seg_part = nullptr;
+    int nseg = 0;
+    if (use_runs) {
+        runs = (RunDesc *)scratch(S_CG_RUNS, ((size_t)nnz / RUN_MIN_LEN + n_long + 2) * sizeof(RunDesc));
+        rem = (int *)scratch(S_CG_REM, (size_t)nnz * 4);
+        nruns = (int *)scratch(S_CG_NRUNS, (size_t)n_long * 2 * 4);
+        pS = (double *)scratch(S_CG_PS, (size_t)ns * 8);
+        if (!runs || !rem || !nruns || !pS) return e.err_code;
+        nrem = nruns + n_long;
+        hipLaunchKernelGGL(k_build_runs, dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, ci, srank, runs, nruns, rem, nrem);
+        seg_off = (int *)scratch(S_CG_SEGOFF, (size_t)(n_long + 4) * 4);
+        if (!seg_off) return e.err_code;
+        int rc = dkmc_exclusive_scan_i32(nruns, seg_off, n_long, seg_off + n_long); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(&nseg, seg_off + n_long, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        segs = (RunDesc *)scratch(S_CG_SEGS, (size_t)(nseg + 1) * sizeof(RunDesc));
+        seg_part = (double *)scratch(S_CG_SEGPART, (size_t)(nseg + 1) * 8);
+        if (!segs || !seg_part) return e.err_code;
+        hipLaunchKernelGGL(k_compact_segs, dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, (const RunDesc *)runs,
+                           (const int *)nruns, (const int *)seg_off, segs);
+    }
+    if (use_runs) np_ap = hs + hl2;
     // ---- Jacobi scaling ----
     SPMV(M_DIAG, (const double *)nullptr, s, x, y, (double *)nullptr);
     SPMV(M_SCALE, (const double *)s, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr);
     // ---- r = A y - x, p = -r ----
     SPMV(M_INIT, (const double *)y, r, x, p, part_rr);
     hipLaunchKernelGGL(k_cg_check0, dim3(1), dim3(CG_NT), 0, st, part_rr, np_spmv, ctrl, tol2);
+    if (use_runs) hipLaunchKernelGGL(k_compact_pS, dim3((m + 255) / 256), dim3(256), 0, st, m, srank, (const double *)p, pS);
     KCHK();
 
     // ---- optional kernel profile: HIP events around every A*p launch (bench.py roofline) ----
@@ -236,9 +467,17 @@ int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, dou
         long long nl = 0, nsh = 0;
         for (int i = 0; i < m; ++i) { const int c = hrp[i + 1] - hrp[i]; if (c > LONG_ROW_NNZ) nl += c; else nsh += c; }
         e.stats.spmv_long_nnz = nl; e.stats.spmv_short_nnz = nsh; e.stats.spmv_long_rows = n_long; e.stats.spmv_short_rows = n_short;
+        e.stats.spmv_segments = nseg; e.stats.spmv_segment_entries = 0;
+        if (use_runs && nseg > 0) {
+            std::vector<RunDesc> hs_((size_t)nseg);
+            HIPCHK(hipMemcpy(hs_.data(), segs, (size_t)nseg * sizeof(RunDesc), hipMemcpyDeviceToHost));
+            long long tot = 0; for (auto &d : hs_) tot += d.len;
+            e.stats.spmv_segment_entries = tot;
+        }
     }
     // ---- iterations, launched in batches; the host polls the control block between batches ----
     int it = 0, batch = 8, launched = 0;
+    static const int spmv_var = getenv("DKMC_SPMV_VAR") ? atoi(getenv("DKMC_SPMV_VAR")) : 0;   // experiments only
     CgCtrl h{};
     for (;;) {
         HIPCHK(hipMemcpyAsync(&h, ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
@@ -247,26 +486,30 @@ int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, dou
             for (int b = 0; b < launched; ++b) {
                 if (it - launched + b >= h.iters) break;
                 float ms = 0.f;
-                if (gs) { HIPCHK(hipEventElapsedTime(&ms, evs[3 * b], evs[3 * b + 1])); prof_short_ms += ms; ++prof_short_n; }
-                if (gl) { HIPCHK(hipEventElapsedTime(&ms, evs[3 * b + 1], evs[3 * b + 2])); prof_long_ms += ms; ++prof_long_n; }
+                if (use_runs) {
+                    HIPCHK(hipEventElapsedTime(&ms, evs[3 * b], evs[3 * b + 1])); prof_long_ms += ms; ++prof_long_n;
+                    HIPCHK(hipEventElapsedTime(&ms, evs[3 * b + 1], evs[3 * b + 2])); prof_short_ms += ms; ++prof_short_n;
+                } else { HIPCHK(hipEventElapsedTime(&ms, evs[3 * b], evs[3 * b + 2])); prof_long_ms += ms; ++prof_long_n; }
             }
         }
         if (h.done) break;
         if (it >= 200000) { dkmc_fail(4, "CG: no convergence after 200000 iterations", __FILE__, __LINE__); break; }
         for (int b = 0; b < batch; ++b, ++it) {
-            if (prof) {
-                HIPCHK(hipEventRecord(evs[3 * b], st));
-                if (gs) hipLaunchKernelGGL((k_spmv<16, M_AP>), dim3(gs), dim3(CG_NT), 0, st, n_short, short_rows, rp, ci, a, (const double *)p, t,
-                                           (double *)nullptr, (double *)nullptr, part_pAp, ctrl);
-                HIPCHK(hipEventRecord(evs[3 * b + 1], st));
-                if (gl) hipLaunchKernelGGL((k_spmv<64, M_AP>), dim3(gl), dim3(CG_NT), 0, st, n_long, long_rows, rp, ci, a, (const double *)p, t,
-                                           (double *)nullptr, (double *)nullptr, part_pAp + gs, ctrl);
-                HIPCHK(hipEventRecord(evs[3 * b + 2], st));
-            } else {
-                SPMV(M_AP, (const double *)p, t, (double *)nullptr, (double *)nullptr, part_pAp);
+            if (prof) HIPCHK(hipEventRecord(evs[3 * b], st));
+#define AP_ARGS(vec) n_short, short_rows, hs, n_long, long_rows, rp, ci, (const double *)a, (const double *)p, t, part_pAp, ctrl, \
+                (const RunDesc *)runs, (const int *)nruns, (const int *)rem, (const int *)nrem, (const double *)(vec), (const int *)seg_off
+            if (use_runs) {
+                hipLaunchKernelGGL(k_spmv_segs, dim3((nseg + SEGK_NT / 64 - 1) / (SEGK_NT / 64)), dim3(SEGK_NT), 0, st, nseg, (const RunDesc *)segs,
+                                   (const double *)a, (const double *)pS, seg_part, ctrl, (const int *)rem, ci, (const double *)p);
+                if (prof) HIPCHK(hipEventRecord(evs[3 * b + 1], st));
+                hipLaunchKernelGGL((k_spmv_ap<0, 1>), dim3(hs + hl2), dim3(SPMV_NT), 0, st, AP_ARGS(seg_part));
             }
-            hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(CG_NT), 0, st, m, it, part_pAp, np_spmv, p, t, y, r, part_rr, ctrl);
-            hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(CG_NT), 0, st, m, it, part_rr, gv, r, p, ctrl, tol2);
+            else if (spmv_var == 1) hipLaunchKernelGGL((k_spmv_ap<1, 0>), dim3(np_ap), dim3(SPMV_NT), 0, st, AP_ARGS(pS));
+            else hipLaunchKernelGGL((k_spmv_ap<0, 0>), dim3(np_ap), dim3(SPMV_NT), 0, st, AP_ARGS(pS));
+#undef AP_ARGS
+            if (prof) HIPCHK(hipEventRecord(evs[3 * b + 2], st));
+            hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(CG_NT), 0, st, m, it, part_pAp, np_ap, p, t, y, r, part_rr, ctrl);
+            hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(CG_NT), 0, st, m, it, part_rr, gv, r, p, ctrl, tol2, use_runs ? srank : (const int *)nullptr, pS);
         }
         launched = batch;
         KCHK();
@@ -288,5 +531,5 @@ int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, dou
 extern "C" int dkmc_solve_sparse_CG_Jacobi(double *A, const int *rp, const int *ci, int nnz, int m, double *x, double *y,
                                            int *iters_out, double *rr_out)
 {
-    return cg_solve_jacobi(A, rp, ci, nnz, m, x, y, 0, iters_out, rr_out);
+    return cg_solve_jacobi(A, rp, ci, nnz, m, x, y, 0, nullptr, 0, iters_out, rr_out);
 }

@@ -13,7 +13,7 @@
 #include <vector>
 
 int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, double *x, double *y,
-                    int uniform_rows, int *iters_out, double *rr_out);
+                    int uniform_rows, const int *srank, int ns, int *iters_out, double *rr_out);
 
 enum { AF_V = 1, AF_MP_PAT = 2, AF_MP_VAL = 4, AF_METAL = 8, AF_CVAC = 16 };
 
@@ -354,6 +354,12 @@ __global__ __launch_bounds__(256) void k_power(int Na, int nrows, const int *__r
     const int a = i - 2;
     if (l == 0 && !(aflag[a] & AF_METAL)) site_power[atom_site[a]] = -1 * alpha * p;
 }
+// rank in S per system node (0, 1 = drivers: -1; a + 2 = atom a)
+__global__ void k_node_srank(int Nsub, const int *__restrict__ srank, int *__restrict__ node_srank)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Nsub) node_srank[i] = i < 2 ? -1 : srank[i - 2];
+}
 __global__ void k_iota_rows(int n, int *rows, const int *inS, int want_S)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -450,7 +456,10 @@ extern "C" int dkmc_update_power_gpu_sparse(dkmc_gpubuf *buf, int n_src, int n_g
     if (e.current_warm_start == 1) {
         if (g_warm && g_warm_n == Nsub) HIPCHK(hipMemcpyAsync(m, g_warm, (size_t)Nsub * 8, hipMemcpyDeviceToDevice, st));
     }
-    rc = cg_solve_jacobi(data2, rp, col, (int)nnz, Nsub, rhs, m, 0, &e.stats.cg_iters_X, &e.stats.cg_rr_X);
+    int *node_srank = (int *)scratch(S_X_SCB, (size_t)(Nsub + 4) * 4);
+    if (!node_srank) return e.err_code;
+    hipLaunchKernelGGL(k_node_srank, dim3(nbr), dim3(256), 0, st, Nsub, srank, node_srank);
+    rc = cg_solve_jacobi(data2, rp, col, (int)nnz, Nsub, rhs, m, 0, node_srank, ns, &e.stats.cg_iters_X, &e.stats.cg_rr_X);
     if (rc) return rc;
     if (e.current_warm_start == 1) {
         if (g_warm_n != Nsub) { if (g_warm) (void)hipFree(g_warm); HIPCHK(hipMalloc((void **)&g_warm, (size_t)Nsub * 8)); g_warm_n = Nsub; }

@@ -4,7 +4,7 @@
 #include "common.h"
 
 int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, double *x, double *y,
-                    int uniform_rows, int *iters_out, double *rr_out);
+                    int uniform_rows, const int *srank, int ns, int *iters_out, double *rr_out);
 
 // ------------------------------------------------------------------------------------------------
 // update_charge (potential_solver_gpu.cu:10-52).  One thread per site; only vacancies and oxygen
@@ -204,7 +204,7 @@ static int solve_K(dkmc_gpubuf *buf, int N, int N_left, int N_right, double VL, 
                             buf->contact_left_col_indices, buf->contact_right_row_ptr, buf->contact_right_col_indices,
                             g_diagpos, VL, VR, data, rhs);
     KCHK();
-    return cg_solve_jacobi(data, buf->Device_row_ptr_d, buf->Device_col_indices_d, buf->Device_nnz, m, rhs, field + N_left, 1, iters, rr);
+    return cg_solve_jacobi(data, buf->Device_row_ptr_d, buf->Device_col_indices_d, buf->Device_nnz, m, rhs, field + N_left, 1, nullptr, 0, iters, rr);
 }
 
 // background_potential_gpu_sparse (potential_solver_gpu.cu:696-781)

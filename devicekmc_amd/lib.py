@@ -33,7 +33,8 @@ class dkmc_stats(C.Structure):
                 ("spmv_long_ms", C.c_double), ("spmv_short_ms", C.c_double),
                 ("spmv_long_launches", C.c_int), ("spmv_short_launches", C.c_int),
                 ("spmv_long_nnz", C.c_longlong), ("spmv_short_nnz", C.c_longlong),
-                ("spmv_long_rows", C.c_int), ("spmv_short_rows", C.c_int)]
+                ("spmv_long_rows", C.c_int), ("spmv_short_rows", C.c_int),
+                ("spmv_segments", C.c_int), ("spmv_pad", C.c_int), ("spmv_segment_entries", C.c_longlong)]
 
 
 # every symbol include/devicekmc_hip.h declares: name -> (restype, argtypes)

@@ -62,6 +62,10 @@ typedef struct dkmc_stats {
     int spmv_long_launches, spmv_short_launches;
     long long spmv_long_nnz, spmv_short_nnz;
     int spmv_long_rows, spmv_short_rows;
+    /* dense-run mode: k_spmv_segs work items and the matrix entries they cover (spmv_long_ms then times that kernel alone,
+     * spmv_short_ms the row kernel that follows it) */
+    int spmv_segments, spmv_pad;
+    long long spmv_segment_entries;
 } dkmc_stats;
 
 const char *dkmc_last_error(void);

@@ -11,6 +11,7 @@
 // S arrays streamed through coalesced loads; rows come out column-sorted exactly as the reference's.
 #include "common.h"
 #include <vector>
+#include <stdlib.h>
 
 int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, double *x, double *y,
                     int uniform_rows, const int *srank, int ns, int *iters_out, double *rr_out);
@@ -192,6 +193,20 @@ __global__ __launch_bounds__(XS_NT) void k_xpat_S(XParams P, int ns, const SEntr
     }
 }
 
+// ---- cache of contact->trap tunnelling coefficients ------------------------------------------------------------------
+// The contact->trap entries integrate up to 500 energy levels each (iterative_solvers_gpu.cu:1652-1676) and are 95 % of the
+// value-assembly time, yet T(vacancy site, contact atom) depends only on the two positions and the two CB edges, which are
+// fixed for a bias point: per KMC step only the handful of sites that BECAME vacancies need new integrals.  One cache row
+// per vacancy site (slot_of_site), one column per inner-contact metal (mrank of the atom).  Rows are filled by the same
+// wkb_T() the direct path uses, so cached and recomputed values are bit-identical.  The cache validates itself every step
+// against the current CB edges (metal snapshot + per-row vacancy CB) and is dropped on any mismatch.
+struct TCacheView {
+    int enabled, nM, cap;
+    const int *slot_of_site;      // [N]   cache row of a site, -1 if none
+    const int *mrank_atom;        // [Na]  cache column of an atom, -1 if it is not an inner-contact metal
+    const double *vals;           // [cap][nM]
+};
+
 // ---- values (populate_sparse_X_gpu2 :1525-1721 + calc_diagonal_X_gpu :2053-2076) ---------------------
 __device__ __forceinline__ double pow15(double e) { return e * sqrt(e); }
 
@@ -218,7 +233,8 @@ __device__ __forceinline__ double wkb_T(int kind, double dist, double drop, doub
 // value of entry (row i >= 2, column c); returns the value, flags the diagonal
 __device__ __forceinline__ double x_entry(const XParams &P, int i, int c, const double *__restrict__ ax, const double *__restrict__ ay,
                                           const double *__restrict__ az, const int *__restrict__ aflag, const double *__restrict__ acb,
-                                          double xa, double ya, double za, int fa, double cba, double prefac)
+                                          double xa, double ya, double za, int fa, double cba, double prefac,
+                                          const TCacheView &TC, const int *__restrict__ atom_site)
 {
     const int N_full = P.Na + 2;
     if (c == 0) return (i > N_full - P.n_gnd) ? -P.high_G : 0.0;  // :1602-1605
@@ -238,6 +254,11 @@ __device__ __forceinline__ double x_entry(const XParams &P, int i, int c, const 
     const double cbb = acb[b];
     const int kind = tunnel_kind<AF_MP_VAL>(fa, fb, cba, cbb, P.tol);
     if (!kind) return 0.0;
+    if (kind == 1 && TC.enabled) {
+        const int va = (fa & AF_V) ? i - 2 : b, ma = (fa & AF_V) ? b : i - 2;       // vacancy atom, metal atom
+        const int slot = TC.slot_of_site[atom_site[va]], mr = TC.mrank_atom[ma];
+        if (slot >= 0 && mr >= 0) return -TC.vals[(size_t)slot * TC.nM + mr];
+    }
     return -wkb_T(kind, 1e-10 * dA, fabs(cba - cbb), prefac, P.V0);
 }
 
@@ -246,7 +267,8 @@ template <int LPR>
 __global__ __launch_bounds__(256) void k_xval(XParams P, int nrows, const SEntry *__restrict__ S, int use_S,
                                               const int *__restrict__ inS, const int *__restrict__ rp, const int *__restrict__ ci,
                                               const double *__restrict__ ax, const double *__restrict__ ay, const double *__restrict__ az,
-                                              const int *__restrict__ aflag, const double *__restrict__ acb, double *__restrict__ data)
+                                              const int *__restrict__ aflag, const double *__restrict__ acb, double *__restrict__ data,
+                                              TCacheView TC, const int *__restrict__ atom_site)
 {
     const int gpb = 256 / LPR, g = threadIdx.x / LPR, l = threadIdx.x % LPR;
     const int ridx = blockIdx.x * gpb + g;
@@ -279,13 +301,156 @@ __global__ __launch_bounds__(256) void k_xval(XParams P, int nrows, const SEntry
         const int fa = aflag[a];
         for (int p = p0 + l; p < p1; p += LPR) {
             const int c = ci[p];
-            const double v = x_entry(P, i, c, ax, ay, az, aflag, acb, xa, ya, za, fa, cba, prefac);
+            const double v = x_entry(P, i, c, ax, ay, az, aflag, acb, xa, ya, za, fa, cba, prefac, TC, atom_site);
             if (c == i) { dpos = p; dval = v; } else { data[p] = v; off += v; }
         }
     }
 #pragma unroll
     for (int o = LPR / 2; o > 0; o >>= 1) off += __shfl_xor(off, o, LPR);
     if (dpos >= 0) data[dpos] = dval + -off;                       // calc_diagonal_X_gpu
+}
+
+// ---- cache maintenance ------------------------------------------------------------------------------------------------
+// flags[0] = 1 if the static tables (metal ranks / metal CB snapshot) no longer match the current atoms
+__global__ void k_tc_validate(int Na, const int *__restrict__ aflag, const double *__restrict__ acb, const int *__restrict__ mrank_atom,
+                              const double *__restrict__ metal_cb, int *flags)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= Na) return;
+    const bool mp = aflag[a] & AF_MP_PAT;
+    const int r = mrank_atom[a];
+    if (mp != (r >= 0) || (mp && metal_cb[r] != acb[a])) flags[0] = 1;
+}
+__global__ void k_tc_mflags(int Na, const int *__restrict__ aflag, int *f)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a < Na) f[a] = (aflag[a] & AF_MP_PAT) ? 1 : 0;
+}
+__global__ void k_tc_mtables(int Na, const int *__restrict__ f, const int *__restrict__ off, const double *__restrict__ acb,
+                             int *mrank_atom, double *metal_cb, int *metal_atom)
+{
+    const int a = blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= Na) return;
+    if (f[a]) { mrank_atom[a] = off[a]; metal_cb[off[a]] = acb[a]; metal_atom[off[a]] = a; } else mrank_atom[a] = -1;
+}
+// every vacancy of S gets a cache row; rows that are new (or whose CB no longer matches) are queued for filling.
+// ctr: [0] rows in use, [1] overflow flag, [2] rows queued
+__global__ void k_tc_assign(int ns, const SEntry *__restrict__ S, const int *__restrict__ atom_site, int cap,
+                            int *slot_of_site, double *slot_cb, int *ctr, int2 *queue)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns) return;
+    const SEntry e = S[k];
+    if (!(e.flag & AF_V)) return;
+    const int site = atom_site[e.idx];
+    int slot = slot_of_site[site];
+    bool fill = false;
+    if (slot < 0) {
+        slot = atomicAdd(&ctr[0], 1);
+        if (slot >= cap) { ctr[1] = 1; return; }
+        slot_of_site[site] = slot; fill = true;
+    } else if (slot_cb[slot] != e.cb) fill = true;
+    if (fill) { slot_cb[slot] = e.cb; const int q = atomicAdd(&ctr[2], 1); queue[q] = make_int2(slot, e.idx); }
+}
+// one thread per (queued row, metal): the same integral the direct path evaluates
+__global__ __launch_bounds__(256) void k_tc_fill(XParams P, int nq, const int2 *__restrict__ queue, int nM, const int *__restrict__ metal_atom,
+                                                 const double *__restrict__ ax, const double *__restrict__ ay, const double *__restrict__ az,
+                                                 const double *__restrict__ acb, double *__restrict__ vals)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int qi = blockIdx.y;
+    if (r >= nM || qi >= nq) return;
+    const int2 q = queue[qi];
+    const int a = q.y, b = metal_atom[r];
+    const double prefac = -(sqrt(2 * P.m_e) / DKMC_HBAR) * (2.0 / 3.0);
+    const double dA = site_dist(ax[a], ay[a], az[a], ax[b], ay[b], az[b], P.laty, P.latz, P.pbc);
+    const double drop = fabs(acb[a] - acb[b]);
+    vals[(size_t)q.x * nM + r] = (drop > P.tol) ? wkb_T(1, 1e-10 * dA, drop, prefac, P.V0) : 0.0;
+}
+__global__ void k_fill_i32(int *p, int n, int v) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
+
+struct TCacheState {
+    int N = 0, Na = 0, nM = 0, cap = 0, valid = 0;
+    int *slot_of_site = nullptr, *mrank_atom = nullptr, *metal_atom = nullptr, *ctr = nullptr;
+    double *metal_cb = nullptr, *slot_cb = nullptr, *vals = nullptr;
+    int2 *queue = nullptr;
+};
+static TCacheState g_tc;
+static const int g_tc_enabled = getenv("DKMC_NO_TCACHE") ? 0 : 1;
+
+void tcache_invalidate() { g_tc.valid = 0; }     // new structure / new bias point (potential.hip)
+
+static void tc_release()
+{
+    void *ptrs[] = { g_tc.slot_of_site, g_tc.mrank_atom, g_tc.metal_atom, g_tc.ctr, g_tc.metal_cb, g_tc.slot_cb, g_tc.vals, g_tc.queue };
+    for (void *q : ptrs) if (q) (void)hipFree(q);
+    g_tc = TCacheState();
+}
+
+// (re)build the static tables and empty the cache
+static int tc_reset(const XParams &P, int N, const int *aflag, const double *acb, int n_vac)
+{
+    Engine &e = eng(); hipStream_t st = e.stream;
+    HIPCHK(hipStreamSynchronize(st));
+    tc_release();
+    const int Na = P.Na;
+    int *f = (int *)scratch(S_MISC0, (size_t)Na * 4), *off = (int *)scratch(S_MISC1, (size_t)(Na + 4) * 4);
+    if (!f || !off) return e.err_code;
+    const int nb = (Na + 255) / 256;
+    hipLaunchKernelGGL(k_tc_mflags, dim3(nb), dim3(256), 0, st, Na, aflag, f);
+    int rc = dkmc_exclusive_scan_i32(f, off, Na, off + Na); if (rc) return rc;
+    int nM = 0;
+    HIPCHK(hipMemcpyAsync(&nM, off + Na, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (nM <= 0) { g_tc.valid = 0; return 0; }
+    const int n_vacancies = n_vac - nM > 64 ? n_vac - nM : 64;          // n_vac carries |S| = vacancies + inner-contact metals
+    size_t cap = (size_t)4 * n_vacancies + 256;
+    const size_t budget = (size_t)8 << 30;                              // at most 8 GiB of cached coefficients
+    if (cap * nM * 8 > budget) cap = budget / ((size_t)nM * 8);
+    if (cap < (size_t)n_vacancies + 16) { g_tc.valid = 0; return 0; }         // does not fit: run uncached
+    g_tc.N = N; g_tc.Na = Na; g_tc.nM = nM; g_tc.cap = (int)cap;
+    HIPCHK(hipMalloc((void **)&g_tc.slot_of_site, (size_t)N * 4));
+    HIPCHK(hipMalloc((void **)&g_tc.mrank_atom, (size_t)Na * 4));
+    HIPCHK(hipMalloc((void **)&g_tc.metal_atom, (size_t)nM * 4));
+    HIPCHK(hipMalloc((void **)&g_tc.metal_cb, (size_t)nM * 8));
+    HIPCHK(hipMalloc((void **)&g_tc.slot_cb, cap * 8));
+    HIPCHK(hipMalloc((void **)&g_tc.vals, cap * nM * 8));
+    HIPCHK(hipMalloc((void **)&g_tc.queue, cap * sizeof(int2)));
+    HIPCHK(hipMalloc((void **)&g_tc.ctr, 4 * sizeof(int)));
+    HIPCHK(hipMemsetAsync(g_tc.ctr, 0, 4 * sizeof(int), st));
+    hipLaunchKernelGGL(k_fill_i32, dim3((N + 255) / 256), dim3(256), 0, st, g_tc.slot_of_site, N, -1);
+    hipLaunchKernelGGL(k_tc_mtables, dim3(nb), dim3(256), 0, st, Na, (const int *)f, (const int *)off, acb, g_tc.mrank_atom, g_tc.metal_cb, g_tc.metal_atom);
+    KCHK();
+    g_tc.valid = 1;
+    return 0;
+}
+
+// per step: validate, assign rows to the current vacancies, fill the new rows.  Leaves g_tc.valid = 0 if the cache cannot be used.
+static int tc_update(const XParams &P, int N, int ns, const SEntry *S, const int *aflag, const int *atom_site,
+                     const double *ax, const double *ay, const double *az, const double *acb, int n_vac_hint)
+{
+    Engine &e = eng(); hipStream_t st = e.stream;
+    if (!g_tc_enabled) { g_tc.valid = 0; return 0; }
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        if (!g_tc.valid || g_tc.N != N || g_tc.Na != P.Na) { int rc = tc_reset(P, N, aflag, acb, n_vac_hint); if (rc) return rc; if (!g_tc.valid) return 0; }
+        int h[4] = {0, 0, 0, 0};
+        int *flags = g_tc.ctr + 3;
+        HIPCHK(hipMemsetAsync(g_tc.ctr + 1, 0, 3 * sizeof(int), st));
+        hipLaunchKernelGGL(k_tc_validate, dim3((P.Na + 255) / 256), dim3(256), 0, st, P.Na, aflag, acb, (const int *)g_tc.mrank_atom,
+                           (const double *)g_tc.metal_cb, flags);
+        hipLaunchKernelGGL(k_tc_assign, dim3((ns + 255) / 256), dim3(256), 0, st, ns, S, atom_site, g_tc.cap, g_tc.slot_of_site, g_tc.slot_cb,
+                           g_tc.ctr, g_tc.queue);
+        HIPCHK(hipMemcpyAsync(h, g_tc.ctr, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (h[3] || h[1]) { g_tc.valid = 0; continue; }               // stale tables or full: rebuild once
+        if (h[2] > 0)
+            hipLaunchKernelGGL(k_tc_fill, dim3((g_tc.nM + 255) / 256, h[2]), dim3(256), 0, st, P, h[2], (const int2 *)g_tc.queue, g_tc.nM,
+                               (const int *)g_tc.metal_atom, ax, ay, az, acb, g_tc.vals);
+        KCHK();
+        return 0;
+    }
+    g_tc.valid = 0;
+    return 0;
 }
 
 // ---- post-solve ------------------------------------------------------------------------------------
@@ -440,10 +605,13 @@ extern "C" int dkmc_update_power_gpu_sparse(dkmc_gpubuf *buf, int n_src, int n_g
     hipLaunchKernelGGL((k_xpat_plain<1>), dim3(nbr), dim3(256), 0, st, P, inS, aneigh, ancnt, cnt, rp, col);
     if (ns > 0) hipLaunchKernelGGL((k_xpat_S<1>), dim3(ns), dim3(XS_NT), 0, st, P, ns, S, aneigh, ancnt, cnt, rp, col);
     // ---- 4. values ----
+    rc = tc_update(P, N, ns, S, aflag, atom_site, buf->atom_x, buf->atom_y, buf->atom_z, buf->atom_CB_edge, ns); if (rc) return rc;
+    TCacheView TC; TC.enabled = g_tc.valid; TC.nM = g_tc.nM; TC.cap = g_tc.cap; TC.slot_of_site = g_tc.slot_of_site;
+    TC.mrank_atom = g_tc.mrank_atom; TC.vals = g_tc.vals;
     hipLaunchKernelGGL((k_xval<16>), dim3((Nsub + 15) / 16), dim3(256), 0, st, P, Nsub, S, 0, inS, rp, col, buf->atom_x, buf->atom_y, buf->atom_z,
-                       aflag, buf->atom_CB_edge, data);
+                       aflag, buf->atom_CB_edge, data, TC, (const int *)atom_site);
     if (ns > 0) hipLaunchKernelGGL((k_xval<64>), dim3((ns + 3) / 4), dim3(256), 0, st, P, ns, S, 1, inS, rp, col, buf->atom_x, buf->atom_y, buf->atom_z,
-                                   aflag, buf->atom_CB_edge, data);
+                                   aflag, buf->atom_CB_edge, data, TC, (const int *)atom_site);
     KCHK();
     g_last_rows = Nsub; g_last_nnz = nnz;
 

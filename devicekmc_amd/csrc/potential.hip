@@ -5,6 +5,7 @@
 
 int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, double *x, double *y,
                     int uniform_rows, const int *srank, int ns, int *iters_out, double *rr_out);
+void tcache_invalidate();
 
 // ------------------------------------------------------------------------------------------------
 // update_charge (potential_solver_gpu.cu:10-52).  One thread per site; only vacancies and oxygen
@@ -88,6 +89,7 @@ static int *g_diagpos = nullptr; static int g_diagpos_m = 0; static int g_kpat_N
 extern "C" int dkmc_initialize_sparsity(dkmc_gpubuf *buf, int pbc, double nn_dist, int num_atoms_contact)
 {
     (void)pbc; (void)nn_dist;
+    tcache_invalidate();
     Engine &e = eng(); hipStream_t st = e.stream;
     const int N = buf->N_, nn = buf->nn_, N_left = num_atoms_contact, m = N - 2 * num_atoms_contact;
     if (m <= 0) return dkmc_fail(5, "initialize_sparsity: no device rows", __FILE__, __LINE__);
@@ -227,6 +229,7 @@ extern "C" int dkmc_update_CB_edge_gpu_sparse(dkmc_gpubuf *buf, int N, int N_lef
                                               double high_G, double low_G, double nn_dist, int num_metals)
 {
     (void)pbc; (void)nn_dist;
+    tcache_invalidate();
     Engine &e = eng();
     int rc = solve_K(buf, N, N_left, N_right, Vd / 2, -Vd / 2, 1, high_G, low_G, num_metals, buf->site_CB_edge,
                      &e.stats.cg_iters_CB, &e.stats.cg_rr_CB);

@@ -62,14 +62,9 @@ def main():
 
     import numpy as np
     import torch
-    import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    from devicekmc_amd import parallel
+    rank, world, local_rank = parallel.init("nccl")
     torch.cuda.set_device(local_rank)
     devname = "cuda:%d" % local_rank
 
@@ -77,7 +72,7 @@ def main():
     L = lib.load()
     Vd = 5.0
     s, p = make_workload(args.workload)
-    p.rnd_seed_kmc = 1 + rank                      # replicas follow different event streams
+    p.rnd_seed_kmc = parallel.replica_kmc_seed(p.rnd_seed_kmc, rank)   # replicas follow different event streams
     dev = host.Device(s, p)
     sim = host.KMCProcess(dev, p.freq)
     gb = dev.make_gpubuf(devname)
@@ -123,21 +118,18 @@ def main():
     L.dkmc_set_profiling(1)
     sync()
     if world > 1:
-        dist.barrier()
+        parallel.barrier()
     sync()
     t_start = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k, True)
     sync()
     if world > 1:
-        dist.barrier()
+        parallel.barrier()
     sync()
     elapsed = time.perf_counter() - t_start
     L.dkmc_set_profiling(0)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=devname)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = parallel.max_over_ranks(elapsed, devname)
 
     st = host.get_stats()
     # ---- roofline of the dominant kernel: k_spmv_ap (CSR SpMV t = X p of the current solve's CG, fused p.t) ----
@@ -197,7 +189,7 @@ def main():
     if rank == 0:
         n = args.steps
         out = {
-            "metric": "KMC steps/sec", "value": round(world * n / elapsed, 4), "unit": "KMC steps/s",
+            "metric": "KMC steps/sec", "value": round(parallel.aggregate_rate(n, world, elapsed), 4), "unit": "KMC steps/s",
             "n_gpus": world, "steps": n, "warmup": args.warmup, "ms_per_step": round(elapsed / n * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "sites": int(s.N), "nn": int(dev.max_num_neighbors), "atoms": int(dev.N_atom),
@@ -209,8 +201,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    parallel.finalize()
 
 
 if __name__ == "__main__":

@@ -323,9 +323,34 @@ __global__ __launch_bounds__(256) void k_compact_segs(int n_long, const int *__r
 #define SEGK_NT 256
 __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *__restrict__ segs, const double *__restrict__ a,
                                                        const double *__restrict__ pS, double *__restrict__ seg_part, const CgCtrl *ctrl,
-                                                       const int *__restrict__ rem, const int *__restrict__ ci, const double *__restrict__ p)
+                                                       const int *__restrict__ rem, const int *__restrict__ ci, const double *__restrict__ p,
+                                                       int nsb, int n_short, const int *__restrict__ short_rows, const int *__restrict__ rp,
+                                                       double *__restrict__ t, double *__restrict__ part)
 {
-    if (ctrl->done) return;                  // no barrier in this kernel: a per-wave read is fine
+    __shared__ double red[SEGK_NT / 64];
+    __shared__ int sdone;
+    if ((int)blockIdx.x >= nsb) {
+        // the short rows ride along in the same launch (independent of the segments): 16 lanes per row, p.t partial per block
+        if (threadIdx.x == 0) sdone = ctrl->done;
+        __syncthreads();
+        if (sdone) return;
+        const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+        const int nb = gridDim.x - nsb;
+        double acc = 0.0;
+        for (int ridx = (blockIdx.x - nsb) * (SEGK_NT / 16) + g; ridx < n_short; ridx += nb * (SEGK_NT / 16)) {
+            const int row = short_rows[ridx];
+            const int p0 = rp[row], p1 = rp[row + 1];
+            double s = 0.0;
+            for (int q = p0 + l; q < p1; q += 16) s += a[q] * p[ci[q]];
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+            if (l == 0) { t[row] = s; acc += p[row] * s; }
+        }
+        const double tot = block_sum_all<SEGK_NT>(acc, red);
+        if (threadIdx.x == 0) part[blockIdx.x - nsb] = tot;
+        return;
+    }
+    if (ctrl->done) return;                  // no barrier on this path: a per-wave read is fine
     const int lane = threadIdx.x & 63;
     const int seg = blockIdx.x * (SEGK_NT / 64) + (threadIdx.x >> 6);
     if (seg >= nseg) return;
@@ -337,15 +362,27 @@ __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *
         if (lane == 0) seg_part[seg] = g;
         return;
     }
-    const double *av = a + d.pos, *pv = pS + d.sr0;
+    // 16-byte loads of the matrix stream: peel one entry if the segment starts on an odd element, then every lane
+    // reads pairs (1 KiB per wave-instruction, 4 instructions in flight)
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    const int head = d.pos & 1;
+    const double *av = a + d.pos + head, *pv = pS + d.sr0 + head;
+    const int len = d.len - head;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (head && lane == 0) s0 = a[d.pos] * pS[d.sr0];
+    const int npair = len >> 1;
+    const dbl2 *av2 = reinterpret_cast<const dbl2 *>(av);
     int k = lane;
-    for (; k + 192 < d.len; k += 256) {
-        const double a0 = __builtin_nontemporal_load(av + k), a1 = __builtin_nontemporal_load(av + k + 64);
-        const double a2 = __builtin_nontemporal_load(av + k + 128), a3 = __builtin_nontemporal_load(av + k + 192);
-        s0 += a0 * pv[k]; s1 += a1 * pv[k + 64]; s2 += a2 * pv[k + 128]; s3 += a3 * pv[k + 192];
+    for (; k + 192 < npair; k += 256) {
+        const dbl2 a0 = __builtin_nontemporal_load(av2 + k), a1 = __builtin_nontemporal_load(av2 + k + 64);
+        const dbl2 a2 = __builtin_nontemporal_load(av2 + k + 128), a3 = __builtin_nontemporal_load(av2 + k + 192);
+        s0 += a0.x * pv[2 * k] + a0.y * pv[2 * k + 1];
+        s1 += a1.x * pv[2 * (k + 64)] + a1.y * pv[2 * (k + 64) + 1];
+        s2 += a2.x * pv[2 * (k + 128)] + a2.y * pv[2 * (k + 128) + 1];
+        s3 += a3.x * pv[2 * (k + 192)] + a3.y * pv[2 * (k + 192) + 1];
     }
-    for (; k < d.len; k += 64) s0 += __builtin_nontemporal_load(av + k) * pv[k];
+    for (; k < npair; k += 64) { const dbl2 a0 = __builtin_nontemporal_load(av2 + k); s0 += a0.x * pv[2 * k] + a0.y * pv[2 * k + 1]; }
+    if ((len & 1) && lane == 1) s1 += av[len - 1] * pv[len - 1];
     double s = (s0 + s1) + (s2 + s3);
     s = wave_sum(s);
     if (lane == 0) seg_part[seg] = s;
@@ -446,7 +483,9 @@ int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, dou
         hipLaunchKernelGGL(k_compact_segs, dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, (const RunDesc *)runs,
                            (const int *)nruns, (const int *)seg_off, segs);
     }
-    if (use_runs) np_ap = hs + hl2;
+    const int nsb = (nseg + SEGK_NT / 64 - 1) / (SEGK_NT / 64);       // segment blocks of k_spmv_segs
+    const int hsA = (use_runs && n_short > 0) ? grid_for(n_short, SEGK_NT / 16) : 0;   // its short-row blocks
+    if (use_runs) np_ap = hsA + hl2;
     // ---- Jacobi scaling ----
     SPMV(M_DIAG, (const double *)nullptr, s, x, y, (double *)nullptr);
     SPMV(M_SCALE, (const double *)s, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr);
@@ -499,10 +538,13 @@ int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, dou
 #define AP_ARGS(vec) n_short, short_rows, hs, n_long, long_rows, rp, ci, (const double *)a, (const double *)p, t, part_pAp, ctrl, \
                 (const RunDesc *)runs, (const int *)nruns, (const int *)rem, (const int *)nrem, (const double *)(vec), (const int *)seg_off
             if (use_runs) {
-                hipLaunchKernelGGL(k_spmv_segs, dim3((nseg + SEGK_NT / 64 - 1) / (SEGK_NT / 64)), dim3(SEGK_NT), 0, st, nseg, (const RunDesc *)segs,
-                                   (const double *)a, (const double *)pS, seg_part, ctrl, (const int *)rem, ci, (const double *)p);
+                hipLaunchKernelGGL(k_spmv_segs, dim3(nsb + hsA), dim3(SEGK_NT), 0, st, nseg, (const RunDesc *)segs,
+                                   (const double *)a, (const double *)pS, seg_part, ctrl, (const int *)rem, ci, (const double *)p,
+                                   nsb, n_short, short_rows, rp, t, part_pAp);
                 if (prof) HIPCHK(hipEventRecord(evs[3 * b + 1], st));
-                hipLaunchKernelGGL((k_spmv_ap<0, 1>), dim3(hs + hl2), dim3(SPMV_NT), 0, st, AP_ARGS(seg_part));
+                hipLaunchKernelGGL((k_spmv_ap<0, 1>), dim3(hl2), dim3(SPMV_NT), 0, st, 0, short_rows, 0, n_long, long_rows, rp, ci, (const double *)a,
+                                   (const double *)p, t, part_pAp + hsA, ctrl, (const RunDesc *)runs, (const int *)nruns, (const int *)rem,
+                                   (const int *)nrem, (const double *)seg_part, (const int *)seg_off);
             }
             else if (spmv_var == 1) hipLaunchKernelGGL((k_spmv_ap<1, 0>), dim3(np_ap), dim3(SPMV_NT), 0, st, AP_ARGS(pS));
             else hipLaunchKernelGGL((k_spmv_ap<0, 0>), dim3(np_ap), dim3(SPMV_NT), 0, st, AP_ARGS(pS));

@@ -19,6 +19,7 @@
 
 #define CG_NT 256
 #define CG_MAX_PART 2048        // max blocks writing partials per kernel family
+#define PROF_STRIDE 8
 #define LONG_ROW_NNZ 192        // rows with more entries go to the wave-per-row bin
 
 struct CgCtrl {                 // device-resident control block
@@ -319,8 +320,11 @@ __global__ __launch_bounds__(256) void k_compact_segs(int n_long, const int *__r
 }
 
 // stage 1 of the long-row product: one wave64 per segment, seg_part[seg] = sum a[pos+k] * pS[sr0+k].
-// Streams 8 B per entry with 4 independent 512-byte strips in flight per wave; every wave has the same amount of work.
+// Streams 8 B per entry, 4 independent 1-KiB strips in flight per wave; every wave has the same amount of work.
+// Default cache policy on the matrix stream (NTL = 0): the same 240 MB are re-read every CG iteration and partly stay in
+// the 256 MiB Infinity Cache -- measured 45 us per launch against 53 us with non-temporal loads (NTL = 1, DKMC_SPMV_VAR=3).
 #define SEGK_NT 256
+template <int NTL>
 __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *__restrict__ segs, const double *__restrict__ a,
                                                        const double *__restrict__ pS, double *__restrict__ seg_part, const CgCtrl *ctrl,
                                                        const int *__restrict__ rem, const int *__restrict__ ci, const double *__restrict__ p,
@@ -365,6 +369,7 @@ __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *
     // 16-byte loads of the matrix stream: peel one entry if the segment starts on an odd element, then every lane
     // reads pairs (1 KiB per wave-instruction, 4 instructions in flight)
     typedef double dbl2 __attribute__((ext_vector_type(2)));
+#define LDM(ptr) (NTL ? __builtin_nontemporal_load(ptr) : *(ptr))
     const int head = d.pos & 1;
     const double *av = a + d.pos + head, *pv = pS + d.sr0 + head;
     const int len = d.len - head;
@@ -374,14 +379,14 @@ __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *
     const dbl2 *av2 = reinterpret_cast<const dbl2 *>(av);
     int k = lane;
     for (; k + 192 < npair; k += 256) {
-        const dbl2 a0 = __builtin_nontemporal_load(av2 + k), a1 = __builtin_nontemporal_load(av2 + k + 64);
-        const dbl2 a2 = __builtin_nontemporal_load(av2 + k + 128), a3 = __builtin_nontemporal_load(av2 + k + 192);
+        const dbl2 a0 = LDM(av2 + k), a1 = LDM(av2 + k + 64);
+        const dbl2 a2 = LDM(av2 + k + 128), a3 = LDM(av2 + k + 192);
         s0 += a0.x * pv[2 * k] + a0.y * pv[2 * k + 1];
         s1 += a1.x * pv[2 * (k + 64)] + a1.y * pv[2 * (k + 64) + 1];
         s2 += a2.x * pv[2 * (k + 128)] + a2.y * pv[2 * (k + 128) + 1];
         s3 += a3.x * pv[2 * (k + 192)] + a3.y * pv[2 * (k + 192) + 1];
     }
-    for (; k < npair; k += 64) { const dbl2 a0 = __builtin_nontemporal_load(av2 + k); s0 += a0.x * pv[2 * k] + a0.y * pv[2 * k + 1]; }
+    for (; k < npair; k += 64) { const dbl2 a0 = LDM(av2 + k); s0 += a0.x * pv[2 * k] + a0.y * pv[2 * k + 1]; }
     if ((len & 1) && lane == 1) s1 += av[len - 1] * pv[len - 1];
     double s = (s0 + s1) + (s2 + s3);
     s = wave_sum(s);
@@ -522,7 +527,7 @@ int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, dou
         HIPCHK(hipMemcpyAsync(&h, ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (prof && launched) {       // only launches that did work (iteration index below the final count) are counted
-            for (int b = 0; b < launched; ++b) {
+            for (int b = 0; b < launched; b += PROF_STRIDE) {
                 if (it - launched + b >= h.iters) break;
                 float ms = 0.f;
                 if (use_runs) {
@@ -534,14 +539,18 @@ int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, dou
         if (h.done) break;
         if (it >= 200000) { dkmc_fail(4, "CG: no convergence after 200000 iterations", __FILE__, __LINE__); break; }
         for (int b = 0; b < batch; ++b, ++it) {
-            if (prof) HIPCHK(hipEventRecord(evs[3 * b], st));
+            const bool pb = prof && (b % PROF_STRIDE == 0);      // events perturb the stream: sample 1 launch in 8
+            if (pb) HIPCHK(hipEventRecord(evs[3 * b], st));
 #define AP_ARGS(vec) n_short, short_rows, hs, n_long, long_rows, rp, ci, (const double *)a, (const double *)p, t, part_pAp, ctrl, \
                 (const RunDesc *)runs, (const int *)nruns, (const int *)rem, (const int *)nrem, (const double *)(vec), (const int *)seg_off
             if (use_runs) {
-                hipLaunchKernelGGL(k_spmv_segs, dim3(nsb + hsA), dim3(SEGK_NT), 0, st, nseg, (const RunDesc *)segs,
+                if (spmv_var != 3) hipLaunchKernelGGL((k_spmv_segs<0>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, nseg, (const RunDesc *)segs,
                                    (const double *)a, (const double *)pS, seg_part, ctrl, (const int *)rem, ci, (const double *)p,
                                    nsb, n_short, short_rows, rp, t, part_pAp);
-                if (prof) HIPCHK(hipEventRecord(evs[3 * b + 1], st));
+                else hipLaunchKernelGGL((k_spmv_segs<1>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, nseg, (const RunDesc *)segs,
+                                   (const double *)a, (const double *)pS, seg_part, ctrl, (const int *)rem, ci, (const double *)p,
+                                   nsb, n_short, short_rows, rp, t, part_pAp);
+                if (pb) HIPCHK(hipEventRecord(evs[3 * b + 1], st));
                 hipLaunchKernelGGL((k_spmv_ap<0, 1>), dim3(hl2), dim3(SPMV_NT), 0, st, 0, short_rows, 0, n_long, long_rows, rp, ci, (const double *)a,
                                    (const double *)p, t, part_pAp + hsA, ctrl, (const RunDesc *)runs, (const int *)nruns, (const int *)rem,
                                    (const int *)nrem, (const double *)seg_part, (const int *)seg_off);
@@ -549,7 +558,7 @@ int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, dou
             else if (spmv_var == 1) hipLaunchKernelGGL((k_spmv_ap<1, 0>), dim3(np_ap), dim3(SPMV_NT), 0, st, AP_ARGS(pS));
             else hipLaunchKernelGGL((k_spmv_ap<0, 0>), dim3(np_ap), dim3(SPMV_NT), 0, st, AP_ARGS(pS));
 #undef AP_ARGS
-            if (prof) HIPCHK(hipEventRecord(evs[3 * b + 2], st));
+            if (pb) HIPCHK(hipEventRecord(evs[3 * b + 2], st));
             hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(CG_NT), 0, st, m, it, part_pAp, np_ap, p, t, y, r, part_rr, ctrl);
             hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(CG_NT), 0, st, m, it, part_rr, gv, r, p, ctrl, tol2, use_runs ? srank : (const int *)nullptr, pS);
         }

@@ -170,9 +170,9 @@ def main():
     # ---- CPU baseline: the oracle (own OpenMP port of the same step) on this box's host cores, rank 0, N=1 only ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        ncores = min(16, os.cpu_count() or 1)         # the box's CPU share for one GPU; more threads only add contention
+        os.environ["OMP_NUM_THREADS"] = str(ncores)   # read by libgomp when the oracle library is loaded
         from oracle import oracle as oc
-        ncores = os.cpu_count() or 1
-        os.environ.setdefault("OMP_NUM_THREADS", str(ncores))
         o = oc.OracleKMC(s.element, s.x, s.y, s.z, p)
         o.set_laplace_potential(Vd)
         o.superstep(Vd)                              # untimed: cold-start CG of the first step

@@ -2,6 +2,8 @@
 #include "common.h"
 #include <stdlib.h>
 
+int events_upload_layers();      // events.hip
+
 static Engine g_engine;
 Engine &eng() { return g_engine; }
 
@@ -80,7 +82,7 @@ int dkmc_copy_to_const_memory(const double *E_gen, const double *E_rec, const do
     if (nl > DKMC_MAX_LAYERS) return dkmc_fail(3, "more than 5 layers (MAX_NUM_LAYERS, kmc_events.cu:7)", __FILE__, __LINE__);
     e.num_layers = nl;
     for (int i = 0; i < nl; ++i) { e.E_gen[i] = E_gen[i]; e.E_rec[i] = E_rec[i]; e.E_Vdiff[i] = E_Vdiff[i]; e.E_Odiff[i] = E_Odiff[i]; }
-    return 0;
+    return events_upload_layers();
 }
 
 // ---- GPUBuffers twin -----------------------------------------------------------------------------

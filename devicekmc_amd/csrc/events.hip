@@ -13,6 +13,9 @@
 #include "common.h"
 
 struct LayerEnergies { double gen[DKMC_MAX_LAYERS], rec[DKMC_MAX_LAYERS], vdiff[DKMC_MAX_LAYERS], odiff[DKMC_MAX_LAYERS]; };
+// per-layer zero-field energies in constant memory, like the reference (kmc_events.cu:10-13); a kernel-argument struct
+// indexed by layer[j] would be demoted to scratch memory
+__constant__ LayerEnergies c_layerE;
 
 struct EvOut {                 // device -> host mailbox
     double event_time, psum_last;
@@ -25,7 +28,7 @@ __device__ __forceinline__ int slot_rate(int i, int j, int N, const int *__restr
                                          const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                          const double *__restrict__ pb, const double *__restrict__ pc,
                                          const int *__restrict__ element, const int *__restrict__ charge,
-                                         const LayerEnergies &E, int ei, int qi, double xi, double yi, double zi, double phii,
+                                         int ei, int qi, double xi, double yi, double zi, double phii,
                                          double *prob)
 {
     int type = EV_NULL; double P = 0.0;
@@ -38,20 +41,20 @@ __device__ __forceinline__ int slot_rate(int i, int j, int N, const int *__restr
             const double dphi = phii - (pb[j] + pc[j]);
             const int qj = charge[j], lj = layer[j];
             double E0, En;
-            if (gen) { En = 2 * dphi; E0 = E.gen[lj]; type = EV_GEN; }
+            if (gen) { En = 2 * dphi; E0 = c_layerE.gen[lj]; type = EV_GEN; }
             else if (rec) {
                 const double self = v_solve(dist, 2, sigma, kk);
                 const int cs = qi - qj;
                 En = cs * (dphi + (cs / 2) * self);            // integer division (kmc_events.cu:77)
-                E0 = E.rec[lj]; type = EV_REC;
+                E0 = c_layerE.rec[lj]; type = EV_REC;
             } else if (vdf) {
                 const double self = (qi != 0) ? v_solve(dist, qi, sigma, kk) : 0.0;
                 En = (qi - qj) * (dphi + self);
-                E0 = E.vdiff[lj]; type = EV_VDIFF;             // layer of j (kmc_events.cu:98)
+                E0 = c_layerE.vdiff[lj]; type = EV_VDIFF;             // layer of j (kmc_events.cu:98)
             } else {
                 const double self = (qi != 0) ? v_solve(dist, 2, sigma, kk) : 0.0;
                 En = (qi - qj) * (dphi - self);
-                E0 = E.odiff[lj]; type = EV_IDIFF;
+                E0 = c_layerE.odiff[lj]; type = EV_IDIFF;
             }
             const double EA = E0 - En - 0;
             P = exp(-1 * EA / (DKMC_KB * T_bg)) * freq;
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(256) void k_ev_build(int N, int nn, const int *__re
                                                   const double *__restrict__ k_p, const double *__restrict__ x,
                                                   const double *__restrict__ y, const double *__restrict__ z,
                                                   const double *__restrict__ pb, const double *__restrict__ pc,
-                                                  const int *__restrict__ element, const int *__restrict__ charge, LayerEnergies E,
+                                                  const int *__restrict__ element, const int *__restrict__ charge,
                                                   int *__restrict__ ev_type, double *__restrict__ ev_prob, double *__restrict__ rowsum)
 {
     const int lane = threadIdx.x & 63;
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(256) void k_ev_build(int N, int nn, const int *__re
         const size_t idx = (size_t)i * nn + c;
         double P;
         const int type = slot_rate(i, neigh[idx], N, layer, laty, latz, pbc, T_bg, freq, sigma, kk, x, y, z, pb, pc, element, charge,
-                                   E, ei, qi, xi, yi, zi, phii, &P);
+                                   ei, qi, xi, yi, zi, phii, &P);
         ev_prob[idx] = P;
         if (ev_type) ev_type[idx] = type;
         s += P;
@@ -144,7 +147,7 @@ __device__ __forceinline__ int wave_pick(const double *__restrict__ v, int base,
     return last_pos;
 }
 
-#define EVL_NT 256
+#define EVL_NT 1024
 // The whole event loop of one KMC step (kmc_events.cu:210-349) in one resident workgroup.
 __global__ __launch_bounds__(EVL_NT) void k_ev_loop(int N, int nn, const int *__restrict__ neigh, double *__restrict__ ev_prob,
                                                     double *__restrict__ rowsum, double *__restrict__ g2, double *__restrict__ g3,
@@ -244,11 +247,13 @@ __global__ __launch_bounds__(EVL_NT) void k_ev_loop(int N, int nn, const int *__
     if (tid == 0) { out->event_time = event_time; out->psum_last = psum_last; out->n_events = n_events; out->exhausted = exhausted; out->bad = bad; }
 }
 
-static LayerEnergies layer_energies()
+// called by dkmc_copy_to_const_memory (engine.hip)
+int events_upload_layers()
 {
     Engine &e = eng(); LayerEnergies L;
     for (int i = 0; i < DKMC_MAX_LAYERS; ++i) { L.gen[i] = e.E_gen[i]; L.rec[i] = e.E_rec[i]; L.vdiff[i] = e.E_Vdiff[i]; L.odiff[i] = e.E_Odiff[i]; }
-    return L;
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(c_layerE), &L, sizeof(L)));
+    return 0;
 }
 
 extern "C" int dkmc_build_event_list(int N, int nn, const int *neigh, const int *layer, const double *lattice, int pbc,
@@ -257,7 +262,7 @@ extern "C" int dkmc_build_event_list(int N, int nn, const int *neigh, const int 
                                      const int *element, const int *charge, int *ev_type, double *ev_prob)
 {
     hipLaunchKernelGGL(k_ev_build, dim3((N + 3) / 4), dim3(256), 0, eng().stream, N, nn, neigh, layer, lattice, pbc, T_bg, freq, sigma, k,
-                       x, y, z, pb, pc, element, charge, layer_energies(), ev_type, ev_prob, (double *)nullptr);
+                       x, y, z, pb, pc, element, charge, ev_type, ev_prob, (double *)nullptr);
     KCHK();
     return 0;
 }
@@ -284,7 +289,7 @@ extern "C" int dkmc_execute_kmc_step_gpu(int N, int nn, const int *neigh, const 
     if (n_uniform > 0) HIPCHK(hipMemcpyAsync(uni, h_uniform, (size_t)n_uniform * 8, hipMemcpyHostToDevice, st));
     if (!resume) {
         hipLaunchKernelGGL(k_ev_build, dim3((N + 3) / 4), dim3(256), 0, st, N, nn, neigh, layer, lattice, pbc, T_bg, freq, sigma, k,
-                           x, y, z, pb, pc, element, charge, layer_energies(), (int *)nullptr, ev_prob, rowsum);
+                           x, y, z, pb, pc, element, charge, (int *)nullptr, ev_prob, rowsum);
         hipLaunchKernelGGL(k_ev_level, dim3((ng2 + 3) / 4), dim3(256), 0, st, N, rowsum, ng2, g2);
         hipLaunchKernelGGL(k_ev_level, dim3((ng3 + 3) / 4), dim3(256), 0, st, ng2, g2, ng3, g3);
     }

@@ -35,7 +35,7 @@ enum { M_SCALE = 0, M_INIT = 1, M_AP = 2, M_DIAG = 3 };
 #define RUN_MIN_LEN 32
 #define REM_SEG_LEN 256
 #define SEG_LEN 2048           // entries per segment = work item of one wave in k_spmv_segs
-struct __attribute__((aligned(16))) RunDesc { int pos, len, sr0, pad; };
+struct __attribute__((aligned(16))) RunDesc { long long pos; int len, sr0; };   // sr0 < 0: gather segment of long row -1-sr0
 
 // block-uniform read of the stop flag (only the last kernel of an iteration ever sets it)
 __device__ __forceinline__ bool cg_done(const CgCtrl *ctrl)
@@ -55,8 +55,8 @@ __device__ __forceinline__ double reduce_partials(const double *part, int n, dou
 }
 
 // One group of LPR lanes per row.  rows == nullptr: identity row list.
-template <int LPR, int MODE>
-__global__ __launch_bounds__(CG_NT) void k_spmv(int nrows, const int *__restrict__ rows, const int *__restrict__ rp,
+template <int LPR, int MODE, typename RP>
+__global__ __launch_bounds__(CG_NT) void k_spmv(int nrows, const int *__restrict__ rows, const RP *__restrict__ rp,
                                                 const int *__restrict__ ci, double *__restrict__ a,
                                                 const double *__restrict__ vin, double *__restrict__ vout,
                                                 double *__restrict__ aux0, double *__restrict__ aux1,
@@ -69,13 +69,13 @@ __global__ __launch_bounds__(CG_NT) void k_spmv(int nrows, const int *__restrict
     double acc = 0.0;
     for (int ridx = blockIdx.x * gpb + g; ridx < nrows; ridx += gridDim.x * gpb) {
         const int row = rows ? rows[ridx] : ridx;
-        const int p0 = rp[row], p1 = rp[row + 1];
+        const RP p0 = rp[row], p1 = rp[row + 1];
         if (MODE == M_SCALE) {                           // a <- S a S   (jacobi_precondition_matrix :272-291)
             const double si = vin[row];
-            for (int p = p0 + l; p < p1; p += LPR) a[p] = a[p] * si * vin[ci[p]];
+            for (RP p = p0 + l; p < p1; p += LPR) a[p] = a[p] * si * vin[ci[p]];
         } else if (MODE == M_DIAG) {                     // s = 1/sqrt(diag); x *= s; y /= s (:227-306)
             double d = 0.0;
-            for (int p = p0 + l; p < p1; p += LPR) if (ci[p] == row) d = a[p];
+            for (RP p = p0 + l; p < p1; p += LPR) if (ci[p] == row) d = a[p];
 #pragma unroll
             for (int off = LPR / 2; off > 0; off >>= 1) d += __shfl_xor(d, off, LPR);
             if (l == 0) {
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(CG_NT) void k_spmv(int nrows, const int *__restrict
             }
         } else {
             double s = 0.0;
-            for (int p = p0 + l; p < p1; p += LPR) s += a[p] * vin[ci[p]];
+            for (RP p = p0 + l; p < p1; p += LPR) s += a[p] * vin[ci[p]];
 #pragma unroll
             for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, LPR);
             if (l == 0) {
@@ -113,10 +113,10 @@ __global__ __launch_bounds__(CG_NT) void k_spmv(int nrows, const int *__restrict
 // workgroup keep <= 1024 partials while every CU holds 32 waves; the matrix stream (12 B per non-zero, read once per
 // launch) uses non-temporal loads so that it does not evict the gathered vector from L2.
 #define SPMV_NT 1024
-template <int VAR, int RUNS>
+template <int VAR, int RUNS, typename RP>
 __global__ __launch_bounds__(SPMV_NT) void k_spmv_ap(int n_short, const int *__restrict__ short_rows, int gs,
                                                      int n_long, const int *__restrict__ long_rows,
-                                                     const int *__restrict__ rp, const int *__restrict__ ci,
+                                                     const RP *__restrict__ rp, const int *__restrict__ ci,
                                                      const double *__restrict__ a, const double *__restrict__ p,
                                                      double *__restrict__ t, double *__restrict__ part, const CgCtrl *ctrl,
                                                      const RunDesc *__restrict__ runs, const int *__restrict__ nruns,
@@ -133,9 +133,9 @@ __global__ __launch_bounds__(SPMV_NT) void k_spmv_ap(int n_short, const int *__r
         const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
         for (int ridx = blockIdx.x * (SPMV_NT / 16) + g; ridx < n_short; ridx += gs * (SPMV_NT / 16)) {
             const int row = short_rows ? short_rows[ridx] : ridx;
-            const int p0 = rp[row], p1 = rp[row + 1];
+            const RP p0 = rp[row], p1 = rp[row + 1];
             double s = 0.0;
-            for (int q = p0 + l; q < p1; q += 16) s += a[q] * p[ci[q]];
+            for (RP q = p0 + l; q < p1; q += 16) s += a[q] * p[ci[q]];
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
             if (l == 0) { t[row] = s; acc += p[row] * s; }
@@ -162,9 +162,9 @@ __global__ __launch_bounds__(SPMV_NT) void k_spmv_ap(int n_short, const int *__r
         // and vacancy rows, ~3x the entries) and the light ones instead of 16 neighbours of the same class
         for (int ridx = w * gl + (blockIdx.x - gs); ridx < n_long; ridx += gl * (SPMV_NT / 64)) {
             const int row = long_rows[ridx];
-            const int p0 = rp[row], p1 = rp[row + 1];
+            const RP p0 = rp[row], p1 = rp[row + 1];
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            int q = p0 + lane;
+            RP q = p0 + lane;
             for (; q + 192 < p1; q += 256) {
                 const int c0 = __builtin_nontemporal_load(ci + q), c1 = __builtin_nontemporal_load(ci + q + 64);
                 const int c2 = __builtin_nontemporal_load(ci + q + 128), c3 = __builtin_nontemporal_load(ci + q + 192);
@@ -247,7 +247,8 @@ __global__ __launch_bounds__(CG_NT) void k_vec_mul(int m, double *__restrict__ y
 // over S.  The hot kernel then streams 8 B per entry (values only), reads pS with contiguous loads and needs no column
 // indices; the few entries outside long runs (neighbours outside S, boundary columns) go through a per-row remainder list.
 
-__global__ __launch_bounds__(256) void k_build_runs(int n_long, const int *__restrict__ long_rows, const int *__restrict__ rp,
+template <typename RP>
+__global__ __launch_bounds__(256) void k_build_runs(int n_long, const int *__restrict__ long_rows, const RP *__restrict__ rp,
                                                     const int *__restrict__ ci, const int *__restrict__ srank,
                                                     RunDesc *__restrict__ runs, int *__restrict__ nruns,
                                                     int *__restrict__ rem, int *__restrict__ nrem)
@@ -256,25 +257,25 @@ __global__ __launch_bounds__(256) void k_build_runs(int n_long, const int *__res
     const int ridx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ridx >= n_long) return;
     const int row = long_rows[ridx];
-    const int p0 = rp[row], p1 = rp[row + 1];
-    const int run_base = p0 / RUN_MIN_LEN + ridx;
+    const RP p0 = rp[row], p1 = rp[row + 1];
+    const long long run_base = (long long)(p0 / RUN_MIN_LEN) + ridx;
     int nr = 0, nrm = 0;
-    int cur_start = p0, cur_sr0 = -1, carry = -2;
-    auto finalize = [&](int sA, int eA, int sr0) {
-        const int len = eA - sA;
+    RP cur_start = p0; int cur_sr0 = -1, carry = -2;
+    auto finalize = [&](RP sA, RP eA, int sr0) {
+        const int len = (int)(eA - sA);
         if (len <= 0) return;
         if (len >= RUN_MIN_LEN && sr0 >= 0) {       // long run: emitted as segments of at most SEG_LEN entries
             for (int c = 0; c < len; c += SEG_LEN) {
-                if (lane == 0) { RunDesc d; d.pos = sA + c; d.len = min(SEG_LEN, len - c); d.sr0 = sr0 + c; d.pad = ridx; runs[run_base + nr] = d; }
+                if (lane == 0) { RunDesc d; d.pos = (long long)sA + c; d.len = min(SEG_LEN, len - c); d.sr0 = sr0 + c; runs[run_base + nr] = d; }
                 ++nr;
             }
         } else {
-            for (int k = lane; k < len; k += WAVE) rem[p0 + nrm + k] = sA + k;
+            for (int k = lane; k < len; k += WAVE) rem[p0 + nrm + k] = (int)(sA - p0) + k;      // offsets relative to the row start
             nrm += len;
         }
     };
-    for (int c0 = p0; c0 < p1; c0 += WAVE) {
-        const int q = c0 + lane;
+    for (RP c0 = p0; c0 < p1; c0 += WAVE) {
+        const RP q = c0 + lane;
         const bool valid = q < p1;
         const int sr = valid ? srank[ci[q]] : -1;
         int prev = __shfl_up(sr, 1, WAVE);
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void k_build_runs(int n_long, const int *__res
         while (mask) {
             const int b = __ffsll((long long)mask) - 1;
             mask &= mask - 1;
-            const int s_new = c0 + b;
+            const RP s_new = c0 + b;
             finalize(cur_start, s_new, cur_sr0);
             cur_start = s_new;
             cur_sr0 = __shfl(sr, b, WAVE);
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256) void k_build_runs(int n_long, const int *__res
     finalize(cur_start, p1, cur_sr0);
     // the entries outside long runs become "gather segments" (sr0 = -1): chunks of the row's remainder list
     for (int c = 0; c < nrm; c += REM_SEG_LEN) {
-        if (lane == 0) { RunDesc d; d.pos = p0 + c; d.len = min(REM_SEG_LEN, nrm - c); d.sr0 = -1; d.pad = ridx; runs[run_base + nr] = d; }
+        if (lane == 0) { RunDesc d; d.pos = (long long)p0 + c; d.len = min(REM_SEG_LEN, nrm - c); d.sr0 = -1 - ridx; runs[run_base + nr] = d; }
         ++nr;
     }
     if (lane == 0) { nruns[ridx] = nr; nrem[ridx] = nrm; }
@@ -307,14 +308,15 @@ __global__ __launch_bounds__(256) void k_compact_pS(int m, const int *__restrict
 }
 
 // gather the per-row descriptor lists (stored at capacity offsets) into one dense segment array
-__global__ __launch_bounds__(256) void k_compact_segs(int n_long, const int *__restrict__ long_rows, const int *__restrict__ rp,
+template <typename RP>
+__global__ __launch_bounds__(256) void k_compact_segs(int n_long, const int *__restrict__ long_rows, const RP *__restrict__ rp,
                                                       const RunDesc *__restrict__ runs, const int *__restrict__ nruns,
                                                       const int *__restrict__ seg_off, RunDesc *__restrict__ segs)
 {
     const int lane = threadIdx.x & 63;
     const int ridx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ridx >= n_long) return;
-    const RunDesc *src = runs + (rp[long_rows[ridx]] / RUN_MIN_LEN + ridx);
+    const RunDesc *src = runs + ((long long)(rp[long_rows[ridx]] / RUN_MIN_LEN) + ridx);
     RunDesc *dst = segs + seg_off[ridx];
     for (int j = lane; j < nruns[ridx]; j += WAVE) dst[j] = src[j];
 }
@@ -324,11 +326,12 @@ __global__ __launch_bounds__(256) void k_compact_segs(int n_long, const int *__r
 // Default cache policy on the matrix stream (NTL = 0): the same 240 MB are re-read every CG iteration and partly stay in
 // the 256 MiB Infinity Cache -- measured 45 us per launch against 53 us with non-temporal loads (NTL = 1, DKMC_SPMV_VAR=3).
 #define SEGK_NT 256
-template <int NTL>
+template <int NTL, typename RP>
 __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *__restrict__ segs, const double *__restrict__ a,
                                                        const double *__restrict__ pS, double *__restrict__ seg_part, const CgCtrl *ctrl,
                                                        const int *__restrict__ rem, const int *__restrict__ ci, const double *__restrict__ p,
-                                                       int nsb, int n_short, const int *__restrict__ short_rows, const int *__restrict__ rp,
+                                                       int nsb, int n_short, const int *__restrict__ short_rows, const RP *__restrict__ rp,
+                                                       const int *__restrict__ long_rows,
                                                        double *__restrict__ t, double *__restrict__ part)
 {
     __shared__ double red[SEGK_NT / 64];
@@ -343,9 +346,9 @@ __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *
         double acc = 0.0;
         for (int ridx = (blockIdx.x - nsb) * (SEGK_NT / 16) + g; ridx < n_short; ridx += nb * (SEGK_NT / 16)) {
             const int row = short_rows[ridx];
-            const int p0 = rp[row], p1 = rp[row + 1];
+            const RP p0 = rp[row], p1 = rp[row + 1];
             double s = 0.0;
-            for (int q = p0 + l; q < p1; q += 16) s += a[q] * p[ci[q]];
+            for (RP q = p0 + l; q < p1; q += 16) s += a[q] * p[ci[q]];
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
             if (l == 0) { t[row] = s; acc += p[row] * s; }
@@ -361,7 +364,8 @@ __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *
     const RunDesc d = segs[seg];
     if (d.sr0 < 0) {                         // gather segment: entries outside long runs (<1 % of the matrix)
         double g = 0.0;
-        for (int k = lane; k < d.len; k += 64) { const int q = rem[d.pos + k]; g += a[q] * p[ci[q]]; }
+        const RP rowp0 = rp[long_rows[-1 - d.sr0]];
+        for (int k = lane; k < d.len; k += 64) { const RP q = rowp0 + rem[d.pos + k]; g += a[q] * p[ci[q]]; }
         g = wave_sum(g);
         if (lane == 0) seg_part[seg] = g;
         return;
@@ -370,7 +374,7 @@ __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *
     // reads pairs (1 KiB per wave-instruction, 4 instructions in flight)
     typedef double dbl2 __attribute__((ext_vector_type(2)));
 #define LDM(ptr) (NTL ? __builtin_nontemporal_load(ptr) : *(ptr))
-    const int head = d.pos & 1;
+    const int head = (int)(d.pos & 1);
     const double *av = a + d.pos + head, *pv = pS + d.sr0 + head;
     const int len = d.len - head;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -394,7 +398,8 @@ __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *
 }
 
 // row binning: flag long rows, build the two row lists
-__global__ void k_row_flags(int m, const int *rp, int *is_long, int *is_short)
+template <typename RP>
+__global__ void k_row_flags(int m, const RP *rp, int *is_long, int *is_short)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < m) { int L = (rp[i + 1] - rp[i]) > LONG_ROW_NNZ; is_long[i] = L; is_short[i] = !L; }
@@ -415,8 +420,9 @@ static inline int grid_for(int work_items, int per_block)
 
 // Internal entry: uniform_rows != 0 skips the binning (K: every row is short).  srank (optional, per row/column of
 // the system: rank in the tunnelling set or -1) enables the dense-run view of the long rows.
-int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, double *x, double *y,
-                    int uniform_rows, const int *srank, int ns, int *iters_out, double *rr_out)
+template <typename RP>
+static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long nnz, int m, double *x, double *y,
+                             int uniform_rows, const int *srank, int ns, int *iters_out, double *rr_out)
 {
     Engine &e = eng(); hipStream_t st = e.stream;
     if (m <= 0) { if (iters_out) *iters_out = 0; if (rr_out) *rr_out = 0; return 0; }
@@ -435,7 +441,7 @@ int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, dou
         int *ol = (int *)scratch(S_MISC2, (size_t)(m + 2) * 4), *os = (int *)scratch(S_MISC3, (size_t)(m + 2) * 4);
         int *lists = (int *)scratch(S_SCAN_TMP2, (size_t)(m + 4) * 4);
         if (!fl || !fs || !ol || !os || !lists) return e.err_code;
-        hipLaunchKernelGGL(k_row_flags, dim3((m + 255) / 256), dim3(256), 0, st, m, rp, fl, fs);
+        hipLaunchKernelGGL((k_row_flags<RP>), dim3((m + 255) / 256), dim3(256), 0, st, m, rp, fl, fs);
         int rc = dkmc_exclusive_scan_i32(fl, ol, m, ol + m); if (rc) return rc;
         rc = dkmc_exclusive_scan_i32(fs, os, m, os + m); if (rc) return rc;
         int tot[1];
@@ -458,9 +464,9 @@ int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, dou
 
 #define SPMV(MODE, vin, vout, a0, a1, partp)                                                                          \
     do {                                                                                                             \
-        if (gs) hipLaunchKernelGGL((k_spmv<16, MODE>), dim3(gs), dim3(CG_NT), 0, st, n_short, short_rows, rp, ci, a,  \
+        if (gs) hipLaunchKernelGGL((k_spmv<16, MODE, RP>), dim3(gs), dim3(CG_NT), 0, st, n_short, short_rows, rp, ci, a,  \
                                    vin, vout, a0, a1, partp, ctrl);                                                  \
-        if (gl) hipLaunchKernelGGL((k_spmv<64, MODE>), dim3(gl), dim3(CG_NT), 0, st, n_long, long_rows, rp, ci, a,    \
+        if (gl) hipLaunchKernelGGL((k_spmv<64, MODE, RP>), dim3(gl), dim3(CG_NT), 0, st, n_long, long_rows, rp, ci, a,    \
                                    vin, vout, a0, a1, (partp) ? (partp) + gs : nullptr, ctrl);                       \
     } while (0)
 
@@ -476,7 +482,7 @@ int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, dou
         pS = (double *)scratch(S_CG_PS, (size_t)ns * 8);
         if (!runs || !rem || !nruns || !pS) return e.err_code;
         nrem = nruns + n_long;
-        hipLaunchKernelGGL(k_build_runs, dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, ci, srank, runs, nruns, rem, nrem);
+        hipLaunchKernelGGL((k_build_runs<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, ci, srank, runs, nruns, rem, nrem);
         seg_off = (int *)scratch(S_CG_SEGOFF, (size_t)(n_long + 4) * 4);
         if (!seg_off) return e.err_code;
         int rc = dkmc_exclusive_scan_i32(nruns, seg_off, n_long, seg_off + n_long); if (rc) return rc;
@@ -485,7 +491,7 @@ int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, dou
         segs = (RunDesc *)scratch(S_CG_SEGS, (size_t)(nseg + 1) * sizeof(RunDesc));
         seg_part = (double *)scratch(S_CG_SEGPART, (size_t)(nseg + 1) * 8);
         if (!segs || !seg_part) return e.err_code;
-        hipLaunchKernelGGL(k_compact_segs, dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, (const RunDesc *)runs,
+        hipLaunchKernelGGL((k_compact_segs<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, (const RunDesc *)runs,
                            (const int *)nruns, (const int *)seg_off, segs);
     }
     const int nsb = (nseg + SEGK_NT / 64 - 1) / (SEGK_NT / 64);       // segment blocks of k_spmv_segs
@@ -506,10 +512,10 @@ int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, dou
     double prof_short_ms = 0.0, prof_long_ms = 0.0; int prof_short_n = 0, prof_long_n = 0;
     if (prof) {
         if (!evs_ready) { for (auto &ev : evs) HIPCHK(hipEventCreate(&ev)); evs_ready = true; }
-        std::vector<int> hrp((size_t)m + 1);
-        HIPCHK(hipMemcpy(hrp.data(), rp, ((size_t)m + 1) * 4, hipMemcpyDeviceToHost));
+        std::vector<RP> hrp((size_t)m + 1);
+        HIPCHK(hipMemcpy(hrp.data(), rp, ((size_t)m + 1) * sizeof(RP), hipMemcpyDeviceToHost));
         long long nl = 0, nsh = 0;
-        for (int i = 0; i < m; ++i) { const int c = hrp[i + 1] - hrp[i]; if (c > LONG_ROW_NNZ) nl += c; else nsh += c; }
+        for (int i = 0; i < m; ++i) { const long long c = hrp[i + 1] - hrp[i]; if (c > LONG_ROW_NNZ) nl += c; else nsh += c; }
         e.stats.spmv_long_nnz = nl; e.stats.spmv_short_nnz = nsh; e.stats.spmv_long_rows = n_long; e.stats.spmv_short_rows = n_short;
         e.stats.spmv_segments = nseg; e.stats.spmv_segment_entries = 0;
         if (use_runs && nseg > 0) {
@@ -544,19 +550,19 @@ int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, dou
 #define AP_ARGS(vec) n_short, short_rows, hs, n_long, long_rows, rp, ci, (const double *)a, (const double *)p, t, part_pAp, ctrl, \
                 (const RunDesc *)runs, (const int *)nruns, (const int *)rem, (const int *)nrem, (const double *)(vec), (const int *)seg_off
             if (use_runs) {
-                if (spmv_var != 3) hipLaunchKernelGGL((k_spmv_segs<0>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, nseg, (const RunDesc *)segs,
+                if (spmv_var != 3) hipLaunchKernelGGL((k_spmv_segs<0, RP>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, nseg, (const RunDesc *)segs,
                                    (const double *)a, (const double *)pS, seg_part, ctrl, (const int *)rem, ci, (const double *)p,
-                                   nsb, n_short, short_rows, rp, t, part_pAp);
-                else hipLaunchKernelGGL((k_spmv_segs<1>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, nseg, (const RunDesc *)segs,
+                                   nsb, n_short, short_rows, rp, long_rows, t, part_pAp);
+                else hipLaunchKernelGGL((k_spmv_segs<1, RP>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, nseg, (const RunDesc *)segs,
                                    (const double *)a, (const double *)pS, seg_part, ctrl, (const int *)rem, ci, (const double *)p,
-                                   nsb, n_short, short_rows, rp, t, part_pAp);
+                                   nsb, n_short, short_rows, rp, long_rows, t, part_pAp);
                 if (pb) HIPCHK(hipEventRecord(evs[3 * b + 1], st));
-                hipLaunchKernelGGL((k_spmv_ap<0, 1>), dim3(hl2), dim3(SPMV_NT), 0, st, 0, short_rows, 0, n_long, long_rows, rp, ci, (const double *)a,
+                hipLaunchKernelGGL((k_spmv_ap<0, 1, RP>), dim3(hl2), dim3(SPMV_NT), 0, st, 0, short_rows, 0, n_long, long_rows, rp, ci, (const double *)a,
                                    (const double *)p, t, part_pAp + hsA, ctrl, (const RunDesc *)runs, (const int *)nruns, (const int *)rem,
                                    (const int *)nrem, (const double *)seg_part, (const int *)seg_off);
             }
-            else if (spmv_var == 1) hipLaunchKernelGGL((k_spmv_ap<1, 0>), dim3(np_ap), dim3(SPMV_NT), 0, st, AP_ARGS(pS));
-            else hipLaunchKernelGGL((k_spmv_ap<0, 0>), dim3(np_ap), dim3(SPMV_NT), 0, st, AP_ARGS(pS));
+            else if (spmv_var == 1) hipLaunchKernelGGL((k_spmv_ap<1, 0, RP>), dim3(np_ap), dim3(SPMV_NT), 0, st, AP_ARGS(pS));
+            else hipLaunchKernelGGL((k_spmv_ap<0, 0, RP>), dim3(np_ap), dim3(SPMV_NT), 0, st, AP_ARGS(pS));
 #undef AP_ARGS
             if (pb) HIPCHK(hipEventRecord(evs[3 * b + 2], st));
             hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(CG_NT), 0, st, m, it, part_pAp, np_ap, p, t, y, r, part_rr, ctrl);
@@ -579,8 +585,20 @@ int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, dou
     return e.err_code;
 }
 
+int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, double *x, double *y,
+                    int uniform_rows, const int *srank, int ns, int *iters_out, double *rr_out)
+{
+    return cg_solve_jacobi_t<int>(a, rp, ci, nnz, m, x, y, uniform_rows, srank, ns, iters_out, rr_out);
+}
+// 64-bit row pointers: the tunnelling block of X outgrows 2^31 non-zeros beyond ~4e5 sites
+int cg_solve_jacobi64(double *a, const long long *rp, const int *ci, long long nnz, int m, double *x, double *y,
+                      int uniform_rows, const int *srank, int ns, int *iters_out, double *rr_out)
+{
+    return cg_solve_jacobi_t<long long>(a, rp, ci, nnz, m, x, y, uniform_rows, srank, ns, iters_out, rr_out);
+}
+
 extern "C" int dkmc_solve_sparse_CG_Jacobi(double *A, const int *rp, const int *ci, int nnz, int m, double *x, double *y,
                                            int *iters_out, double *rr_out)
 {
-    return cg_solve_jacobi(A, rp, ci, nnz, m, x, y, 0, nullptr, 0, iters_out, rr_out);
+    return cg_solve_jacobi_t<int>(A, rp, ci, nnz, m, x, y, 0, nullptr, 0, iters_out, rr_out);
 }

@@ -137,7 +137,7 @@ enum {
     S_K_DATA, S_K_RHS, S_K_DIAGPOS,
     S_PW_LIST, S_PW_CNT,
     S_EV_PROB, S_EV_ROWSUM, S_EV_G2, S_EV_G3, S_EV_CTRL, S_EV_UNI, S_EV_LOG, S_EV_TYPE,
-    S_SCAN_TMP, S_SCAN_TMP2,
+    S_SCAN_TMP, S_SCAN_TMP2, S_SCAN_OFF64, S_SCAN_INTILE,
     S_AT_FLAG, S_AT_SITE, S_AT_OFSITE, S_AT_NEIGH,
     S_X_ROWPTR, S_X_COL, S_X_DATA, S_X_DATA2, S_X_CNT, S_X_SLIST, S_X_SCB, S_X_SFLAG, S_X_RHS, S_X_WARM, S_X_SRANK,
     S_P_IMACRO, S_HEAT,
@@ -147,3 +147,5 @@ enum {
 // shared primitives (scan.hip)
 // exclusive prefix sum of n ints (in -> out, out may alias in); total written to d_total (device int) if non-null
 int dkmc_exclusive_scan_i32(const int *d_in, int *d_out, int n, int *d_total);
+// same with 64-bit offsets (counts stay 32 bit)
+int dkmc_exclusive_scan_i32_i64(const int *d_in, long long *d_out, int n, long long *d_total);

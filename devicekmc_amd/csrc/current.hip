@@ -13,8 +13,9 @@
 #include <vector>
 #include <stdlib.h>
 
-int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, double *x, double *y,
-                    int uniform_rows, const int *srank, int ns, int *iters_out, double *rr_out);
+int cg_solve_jacobi64(double *a, const long long *rp, const int *ci, long long nnz, int m, double *x, double *y,
+                      int uniform_rows, const int *srank, int ns, int *iters_out, double *rr_out);
+typedef long long xrp_t;      // row pointers of X are 64 bit: its tunnelling block outgrows 2^31 non-zeros beyond ~4e5 sites
 
 enum { AF_V = 1, AF_MP_PAT = 2, AF_MP_VAL = 4, AF_METAL = 8, AF_CVAC = 16 };
 
@@ -101,7 +102,7 @@ __device__ __forceinline__ int tunnel_kind(int fa, int fb, double cba, double cb
 // MODE 0: count, MODE 1: fill
 template <int MODE>
 __global__ void k_xpat_plain(XParams P, const int *__restrict__ inS, const int *__restrict__ aneigh, const int *__restrict__ ancnt,
-                             int *__restrict__ cnt, const int *__restrict__ rp, int *__restrict__ col)
+                             int *__restrict__ cnt, const xrp_t *__restrict__ rp, int *__restrict__ col)
 {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     const int Nsub = P.Na + 1, N_full = P.Na + 2;
@@ -123,7 +124,7 @@ __global__ void k_xpat_plain(XParams P, const int *__restrict__ inS, const int *
     const int pre0 = row > N_full - P.n_gnd, pre1 = row < P.n_src + 2;
     const int nnb = ancnt[a];
     if (MODE == 0) { cnt[row] = pre0 + pre1 + nnb + 1; return; }
-    int p = rp[row];
+    xrp_t p = rp[row];
     if (pre0) col[p++] = 0;
     if (pre1) col[p++] = 1;
     bool self_done = false;
@@ -139,7 +140,7 @@ __global__ void k_xpat_plain(XParams P, const int *__restrict__ inS, const int *
 #define XS_NT 256
 template <int MODE>
 __global__ __launch_bounds__(XS_NT) void k_xpat_S(XParams P, int ns, const SEntry *__restrict__ S, const int *__restrict__ aneigh,
-                                                  const int *__restrict__ ancnt, int *__restrict__ cnt, const int *__restrict__ rp,
+                                                  const int *__restrict__ ancnt, int *__restrict__ cnt, const xrp_t *__restrict__ rp,
                                                   int *__restrict__ col)
 {
     __shared__ int nb[72], hist[72], wtot[XS_NT / 64], s_total;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(XS_NT) void k_xpat_S(XParams P, int ns, const SEntr
     if (tid < 72) hist[tid] = 0;
     __syncthreads();
     const int pre = (row > N_full - P.n_gnd) + (row < P.n_src + 2);
-    const int row_start = (MODE == 1) ? rp[row] : 0;
+    const xrp_t row_start = (MODE == 1) ? rp[row] : 0;
     int total_before = 0;
     for (int base = 0; base < ns; base += XS_NT) {
         const int k = base + tid;
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(XS_NT) void k_xpat_S(XParams P, int ns, const SEntr
         __syncthreads();
     }
     if (MODE == 0) { if (tid == 0) cnt[row] = pre + nN + total_before; return; }
-    if (tid == 0) { int p = row_start; if (row > N_full - P.n_gnd) col[p++] = 0; if (row < P.n_src + 2) col[p++] = 1; }
+    if (tid == 0) { xrp_t p = row_start; if (row > N_full - P.n_gnd) col[p++] = 0; if (row < P.n_src + 2) col[p++] = 1; }
     if (tid < nN) {
         int cum = 0;
         for (int t = 0; t <= tid; ++t) cum += hist[t];
@@ -265,7 +266,7 @@ __device__ __forceinline__ double x_entry(const XParams &P, int i, int c, const 
 // LPR lanes per row over a row list (rows == nullptr: rows 0..nrows-1 are node rows 0..)
 template <int LPR>
 __global__ __launch_bounds__(256) void k_xval(XParams P, int nrows, const SEntry *__restrict__ S, int use_S,
-                                              const int *__restrict__ inS, const int *__restrict__ rp, const int *__restrict__ ci,
+                                              const int *__restrict__ inS, const xrp_t *__restrict__ rp, const int *__restrict__ ci,
                                               const double *__restrict__ ax, const double *__restrict__ ay, const double *__restrict__ az,
                                               const int *__restrict__ aflag, const double *__restrict__ acb, double *__restrict__ data,
                                               TCacheView TC, const int *__restrict__ atom_site)
@@ -277,11 +278,11 @@ __global__ __launch_bounds__(256) void k_xval(XParams P, int nrows, const SEntry
     if (use_S) i = S[ridx].idx + 2;
     else { i = ridx; if (i >= 2 && inS[i - 2]) return; }
     const int N_full = P.Na + 2;
-    const int p0 = rp[i], p1 = rp[i + 1];
+    const xrp_t p0 = rp[i], p1 = rp[i + 1];
     const double prefac = -(sqrt(2 * P.m_e) / DKMC_HBAR) * (2.0 / 3.0);
-    double off = 0.0, dval = 0.0; int dpos = -1;
+    double off = 0.0, dval = 0.0; xrp_t dpos = -1;
     if (i == 0) {                                                  // :1550-1567
-        for (int p = p0 + l; p < p1; p += LPR) {
+        for (xrp_t p = p0 + l; p < p1; p += LPR) {
             const int c = ci[p]; double v = 0.0;
             if (c == 0) v = +P.high_G;
             if (c == 1) v = -P.loop_G;
@@ -289,7 +290,7 @@ __global__ __launch_bounds__(256) void k_xval(XParams P, int nrows, const SEntry
             if (c == 0) { dpos = p; dval = v; } else { data[p] = v; off += v; }
         }
     } else if (i == 1) {                                           // :1570-1582
-        for (int p = p0 + l; p < p1; p += LPR) {
+        for (xrp_t p = p0 + l; p < p1; p += LPR) {
             const int c = ci[p]; double v = 0.0;
             if (c == 0) v = -P.loop_G;
             if (c >= 2 || (c > N_full - P.n_gnd)) v = -P.high_G;
@@ -299,7 +300,7 @@ __global__ __launch_bounds__(256) void k_xval(XParams P, int nrows, const SEntry
         const int a = i - 2;
         const double xa = ax[a], ya = ay[a], za = az[a], cba = acb[a];
         const int fa = aflag[a];
-        for (int p = p0 + l; p < p1; p += LPR) {
+        for (xrp_t p = p0 + l; p < p1; p += LPR) {
             const int c = ci[p];
             const double v = x_entry(P, i, c, ax, ay, az, aflag, acb, xa, ya, za, fa, cba, prefac, TC, atom_site);
             if (c == i) { dpos = p; dval = v; } else { data[p] = v; off += v; }
@@ -465,13 +466,13 @@ __global__ void k_scale(double *v, int n, double s)
     if (i < n) v[i] = v[i] * s;
 }
 // get_imacro_sparse (current_solver_gpu.cu:781-821): single block, fixed-order reduction
-__global__ __launch_bounds__(256) void k_imacro(const double *__restrict__ xv, const int *__restrict__ rp, const int *__restrict__ ci,
+__global__ __launch_bounds__(256) void k_imacro(const double *__restrict__ xv, const xrp_t *__restrict__ rp, const int *__restrict__ ci,
                                                 const double *__restrict__ m, double *imacro)
 {
     __shared__ double red[4];
-    const int row_start = rp[1] + 2, row_end = rp[2];
+    const xrp_t row_start = rp[1] + 2, row_end = rp[2];
     double s = 0.0;
-    for (int p = row_start + threadIdx.x; p < row_end; p += 256) { const int c = ci[p]; if (c >= 2) s += xv[p] * (m[c] - m[1]); }
+    for (xrp_t p = row_start + threadIdx.x; p < row_end; p += 256) { const int c = ci[p]; if (c >= 2) s += xv[p] * (m[c] - m[1]); }
     const double t = block_sum_all<256>(s, red);
     if (threadIdx.x == 0) *imacro = t;
 }
@@ -494,7 +495,7 @@ __global__ void k_shift(double *m, int n, const double *shift)
 // in the sparse system; set_ineg_sparse + reduce_rows_into_diag + SpMV + copy_pdisp fused (see SURVEY B8/B9
 // for the index slips of the CUDA kernels this replaces).
 template <int LPR>
-__global__ __launch_bounds__(256) void k_power(int Na, int nrows, const int *__restrict__ rows, const int *__restrict__ rp,
+__global__ __launch_bounds__(256) void k_power(int Na, int nrows, const int *__restrict__ rows, const xrp_t *__restrict__ rp,
                                                const int *__restrict__ ci, const double *__restrict__ xv, const double *__restrict__ m,
                                                double Vd, const int *__restrict__ aflag, const int *__restrict__ atom_site,
                                                double alpha, double *__restrict__ site_power)
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(256) void k_power(int Na, int nrows, const int *__r
     if (i < 2) return;
     const double mi = m[i];
     double p = 0.0;
-    for (int q = rp[i] + l; q < rp[i + 1]; q += LPR) {
+    for (xrp_t q = rp[i] + l; q < rp[i + 1]; q += LPR) {
         const int c = ci[q];
         if (c < 2 || c == i) continue;
         const double ical = xv[q] * (mi - m[c]);
@@ -586,18 +587,16 @@ extern "C" int dkmc_update_power_gpu_sparse(dkmc_gpubuf *buf, int n_src, int n_g
 
     // ---- 3. sparsity: counts -> row_ptr -> columns ----
     int *cnt = (int *)scratch(S_X_CNT, (size_t)(Nsub + 4) * 4);
-    int *rp = (int *)scratch(S_X_ROWPTR, (size_t)(Nsub + 4) * 4);
+    xrp_t *rp = (xrp_t *)scratch(S_X_ROWPTR, (size_t)(Nsub + 4) * sizeof(xrp_t));
     if (!cnt || !rp) return e.err_code;
     const int nbr = (Nsub + 255) / 256;
-    hipLaunchKernelGGL((k_xpat_plain<0>), dim3(nbr), dim3(256), 0, st, P, inS, aneigh, ancnt, cnt, (const int *)nullptr, (int *)nullptr);
-    if (ns > 0) hipLaunchKernelGGL((k_xpat_S<0>), dim3(ns), dim3(XS_NT), 0, st, P, ns, S, aneigh, ancnt, cnt, (const int *)nullptr, (int *)nullptr);
-    // nnz can exceed int32 for very large tunnelling blocks: sum in 64 bit on the host side of the scan
-    rc = dkmc_exclusive_scan_i32(cnt, rp, Nsub, rp + Nsub); if (rc) return rc;
-    int nnz_i = 0;
-    HIPCHK(hipMemcpyAsync(&nnz_i, rp + Nsub, sizeof(int), hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL((k_xpat_plain<0>), dim3(nbr), dim3(256), 0, st, P, inS, aneigh, ancnt, cnt, (const xrp_t *)nullptr, (int *)nullptr);
+    if (ns > 0) hipLaunchKernelGGL((k_xpat_S<0>), dim3(ns), dim3(XS_NT), 0, st, P, ns, S, aneigh, ancnt, cnt, (const xrp_t *)nullptr, (int *)nullptr);
+    rc = dkmc_exclusive_scan_i32_i64(cnt, rp, Nsub, rp + Nsub); if (rc) return rc;
+    long long nnz = 0;
+    HIPCHK(hipMemcpyAsync(&nnz, rp + Nsub, sizeof(long long), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (nnz_i <= 0) return dkmc_fail(10, "update_power: X has more than 2^31-1 non-zeros (int32 CSR, as in the reference)", __FILE__, __LINE__);
-    const long long nnz = nnz_i;
+    if (nnz <= 0) return dkmc_fail(10, "update_power: empty X", __FILE__, __LINE__);
     e.stats.X_nnz = nnz;
     int *col = (int *)scratch(S_X_COL, (size_t)nnz * 4);
     double *data = (double *)scratch(S_X_DATA, (size_t)nnz * 8), *data2 = (double *)scratch(S_X_DATA2, (size_t)nnz * 8);
@@ -627,7 +626,7 @@ extern "C" int dkmc_update_power_gpu_sparse(dkmc_gpubuf *buf, int n_src, int n_g
     int *node_srank = (int *)scratch(S_X_SCB, (size_t)(Nsub + 4) * 4);
     if (!node_srank) return e.err_code;
     hipLaunchKernelGGL(k_node_srank, dim3(nbr), dim3(256), 0, st, Nsub, srank, node_srank);
-    rc = cg_solve_jacobi(data2, rp, col, (int)nnz, Nsub, rhs, m, 0, node_srank, ns, &e.stats.cg_iters_X, &e.stats.cg_rr_X);
+    rc = cg_solve_jacobi64(data2, rp, col, nnz, Nsub, rhs, m, 0, node_srank, ns, &e.stats.cg_iters_X, &e.stats.cg_rr_X);
     if (rc) return rc;
     if (e.current_warm_start == 1) {
         if (g_warm_n != Nsub) { if (g_warm) (void)hipFree(g_warm); HIPCHK(hipMalloc((void **)&g_warm, (size_t)Nsub * 8)); g_warm_n = Nsub; }
@@ -660,7 +659,12 @@ extern "C" int dkmc_get_last_X(int *rows_out, long long *nnz_out, int *h_rp, int
     if (rows_out) *rows_out = g_last_rows;
     if (nnz_out) *nnz_out = g_last_nnz;
     HIPCHK(hipStreamSynchronize(e.stream));
-    if (h_rp) HIPCHK(hipMemcpy(h_rp, e.buf[S_X_ROWPTR], (size_t)(g_last_rows + 1) * 4, hipMemcpyDeviceToHost));
+    if (h_rp) {
+        if (g_last_nnz > 2147483647LL) return dkmc_fail(12, "get_last_X: more than 2^31-1 non-zeros do not fit the int32 row pointers of this call", __FILE__, __LINE__);
+        std::vector<xrp_t> tmp((size_t)g_last_rows + 1);
+        HIPCHK(hipMemcpy(tmp.data(), e.buf[S_X_ROWPTR], tmp.size() * sizeof(xrp_t), hipMemcpyDeviceToHost));
+        for (int i = 0; i <= g_last_rows; ++i) h_rp[i] = (int)tmp[i];
+    }
     if (h_col) HIPCHK(hipMemcpy(h_col, e.buf[S_X_COL], (size_t)g_last_nnz * 4, hipMemcpyDeviceToHost));
     if (h_data) HIPCHK(hipMemcpy(h_data, e.buf[S_X_DATA], (size_t)g_last_nnz * 8, hipMemcpyDeviceToHost));
     return 0;

@@ -251,7 +251,7 @@ template <typename RP>
 __global__ __launch_bounds__(256) void k_build_runs(int n_long, const int *__restrict__ long_rows, const RP *__restrict__ rp,
                                                     const int *__restrict__ ci, const int *__restrict__ srank,
                                                     RunDesc *__restrict__ runs, int *__restrict__ nruns,
-                                                    int *__restrict__ rem, int *__restrict__ nrem)
+                                                    int *__restrict__ rem, int *__restrict__ nrem, int seg_len)
 {
     const int lane = threadIdx.x & 63;
     const int ridx = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -265,8 +265,8 @@ __global__ __launch_bounds__(256) void k_build_runs(int n_long, const int *__res
         const int len = (int)(eA - sA);
         if (len <= 0) return;
         if (len >= RUN_MIN_LEN && sr0 >= 0) {       // long run: emitted as segments of at most SEG_LEN entries
-            for (int c = 0; c < len; c += SEG_LEN) {
-                if (lane == 0) { RunDesc d; d.pos = (long long)sA + c; d.len = min(SEG_LEN, len - c); d.sr0 = sr0 + c; runs[run_base + nr] = d; }
+            for (int c = 0; c < len; c += seg_len) {
+                if (lane == 0) { RunDesc d; d.pos = (long long)sA + c; d.len = min(seg_len, len - c); d.sr0 = sr0 + c; runs[run_base + nr] = d; }
                 ++nr;
             }
         } else {
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void k_compact_segs(int n_long, const int *__r
 // Default cache policy on the matrix stream (NTL = 0): the same 240 MB are re-read every CG iteration and partly stay in
 // the 256 MiB Infinity Cache -- measured 45 us per launch against 53 us with non-temporal loads (NTL = 1, DKMC_SPMV_VAR=3).
 #define SEGK_NT 256
-template <int NTL, typename RP>
+template <int NTL, typename RP, int UNR>
 __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *__restrict__ segs, const double *__restrict__ a,
                                                        const double *__restrict__ pS, double *__restrict__ seg_part, const CgCtrl *ctrl,
                                                        const int *__restrict__ rem, const int *__restrict__ ci, const double *__restrict__ p,
@@ -382,6 +382,20 @@ __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *
     const int npair = len >> 1;
     const dbl2 *av2 = reinterpret_cast<const dbl2 *>(av);
     int k = lane;
+    if (UNR == 8) {
+        for (; k + 448 < npair; k += 512) {
+            dbl2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = LDM(av2 + k + 64 * u);
+#pragma unroll
+            for (int u = 0; u < 8; u += 4) {
+                s0 += v[u].x * pv[2 * (k + 64 * u)] + v[u].y * pv[2 * (k + 64 * u) + 1];
+                s1 += v[u + 1].x * pv[2 * (k + 64 * (u + 1))] + v[u + 1].y * pv[2 * (k + 64 * (u + 1)) + 1];
+                s2 += v[u + 2].x * pv[2 * (k + 64 * (u + 2))] + v[u + 2].y * pv[2 * (k + 64 * (u + 2)) + 1];
+                s3 += v[u + 3].x * pv[2 * (k + 64 * (u + 3))] + v[u + 3].y * pv[2 * (k + 64 * (u + 3)) + 1];
+            }
+        }
+    }
     for (; k + 192 < npair; k += 256) {
         const dbl2 a0 = LDM(av2 + k), a1 = LDM(av2 + k + 64);
         const dbl2 a2 = LDM(av2 + k + 128), a3 = LDM(av2 + k + 192);
@@ -472,6 +486,7 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
 
     // ---- dense-run view of the long rows ----
     static const int use_runs_env = getenv("DKMC_NO_RUNS") ? 0 : 1;
+    static const int seg_len = getenv("DKMC_SEG_LEN") ? atoi(getenv("DKMC_SEG_LEN")) : SEG_LEN;     // experiments; >= RUN_MIN_LEN
     const bool use_runs = use_runs_env && srank && n_long > 0 && ns > 0;
     RunDesc *runs = nullptr, *segs = nullptr; int *nruns = nullptr, *rem = nullptr, *nrem = nullptr, *seg_off = nullptr; double *pS = nullptr, *seg_part = nullptr;
     int nseg = 0;
@@ -482,7 +497,7 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
         pS = (double *)scratch(S_CG_PS, (size_t)ns * 8);
         if (!runs || !rem || !nruns || !pS) return e.err_code;
         nrem = nruns + n_long;
-        hipLaunchKernelGGL((k_build_runs<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, ci, srank, runs, nruns, rem, nrem);
+        hipLaunchKernelGGL((k_build_runs<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, ci, srank, runs, nruns, rem, nrem, seg_len);
         seg_off = (int *)scratch(S_CG_SEGOFF, (size_t)(n_long + 4) * 4);
         if (!seg_off) return e.err_code;
         int rc = dkmc_exclusive_scan_i32(nruns, seg_off, n_long, seg_off + n_long); if (rc) return rc;
@@ -528,6 +543,10 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
     // ---- iterations, launched in batches; the host polls the control block between batches ----
     int it = 0, batch = 8, launched = 0;
     static const int spmv_var = getenv("DKMC_SPMV_VAR") ? atoi(getenv("DKMC_SPMV_VAR")) : 0;   // experiments only
+    static const int seg_unr = getenv("DKMC_SEG_UNR") ? atoi(getenv("DKMC_SEG_UNR")) : 4;
+    // matrix stream: default cache policy while the values of one sweep fit the 256 MiB Infinity Cache (they are re-read
+    // every iteration), non-temporal beyond that (measured: 45 vs 53 us at 240 MB, 478 vs 456 us at 1.86 GB)
+    const int seg_nt = (spmv_var == 3) ? 1 : (spmv_var == 2) ? 0 : (nnz * 8 > (300ll << 20));
     CgCtrl h{};
     for (;;) {
         HIPCHK(hipMemcpyAsync(&h, ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
@@ -550,12 +569,13 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
 #define AP_ARGS(vec) n_short, short_rows, hs, n_long, long_rows, rp, ci, (const double *)a, (const double *)p, t, part_pAp, ctrl, \
                 (const RunDesc *)runs, (const int *)nruns, (const int *)rem, (const int *)nrem, (const double *)(vec), (const int *)seg_off
             if (use_runs) {
-                if (spmv_var != 3) hipLaunchKernelGGL((k_spmv_segs<0, RP>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, nseg, (const RunDesc *)segs,
-                                   (const double *)a, (const double *)pS, seg_part, ctrl, (const int *)rem, ci, (const double *)p,
-                                   nsb, n_short, short_rows, rp, long_rows, t, part_pAp);
-                else hipLaunchKernelGGL((k_spmv_segs<1, RP>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, nseg, (const RunDesc *)segs,
-                                   (const double *)a, (const double *)pS, seg_part, ctrl, (const int *)rem, ci, (const double *)p,
-                                   nsb, n_short, short_rows, rp, long_rows, t, part_pAp);
+#define SEG_ARGS nseg, (const RunDesc *)segs, (const double *)a, (const double *)pS, seg_part, ctrl, (const int *)rem, ci, (const double *)p, \
+                 nsb, n_short, short_rows, rp, long_rows, t, part_pAp
+                if (seg_nt && seg_unr == 8) hipLaunchKernelGGL((k_spmv_segs<1, RP, 8>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, SEG_ARGS);
+                else if (seg_nt) hipLaunchKernelGGL((k_spmv_segs<1, RP, 4>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, SEG_ARGS);
+                else if (seg_unr == 8) hipLaunchKernelGGL((k_spmv_segs<0, RP, 8>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, SEG_ARGS);
+                else hipLaunchKernelGGL((k_spmv_segs<0, RP, 4>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, SEG_ARGS);
+#undef SEG_ARGS
                 if (pb) HIPCHK(hipEventRecord(evs[3 * b + 1], st));
                 hipLaunchKernelGGL((k_spmv_ap<0, 1, RP>), dim3(hl2), dim3(SPMV_NT), 0, st, 0, short_rows, 0, n_long, long_rows, rp, ci, (const double *)a,
                                    (const double *)p, t, part_pAp + hsA, ctrl, (const RunDesc *)runs, (const int *)nruns, (const int *)rem,

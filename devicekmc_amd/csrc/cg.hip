@@ -170,8 +170,7 @@ __global__ __launch_bounds__(SPMV_NT) void k_spmv_ap(int n_short, const int *__r
                 const int c2 = __builtin_nontemporal_load(ci + q + 128), c3 = __builtin_nontemporal_load(ci + q + 192);
                 const double a0 = __builtin_nontemporal_load(a + q), a1 = __builtin_nontemporal_load(a + q + 64);
                 const double a2 = __builtin_nontemporal_load(a + q + 128), a3 = __builtin_nontemporal_load(a + q + 192);
-                if (VAR == 1) { s0 += a0 * (double)c0; s1 += a1 * (double)c1; s2 += a2 * (double)c2; s3 += a3 * (double)c3; }
-                else { s0 += a0 * p[c0]; s1 += a1 * p[c1]; s2 += a2 * p[c2]; s3 += a3 * p[c3]; }
+                s0 += a0 * p[c0]; s1 += a1 * p[c1]; s2 += a2 * p[c2]; s3 += a3 * p[c3];
             }
             for (; q < p1; q += 64) s0 += __builtin_nontemporal_load(a + q) * p[__builtin_nontemporal_load(ci + q)];
             double s = (s0 + s1) + (s2 + s3);
@@ -581,7 +580,6 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
                                    (const double *)p, t, part_pAp + hsA, ctrl, (const RunDesc *)runs, (const int *)nruns, (const int *)rem,
                                    (const int *)nrem, (const double *)seg_part, (const int *)seg_off);
             }
-            else if (spmv_var == 1) hipLaunchKernelGGL((k_spmv_ap<1, 0, RP>), dim3(np_ap), dim3(SPMV_NT), 0, st, AP_ARGS(pS));
             else hipLaunchKernelGGL((k_spmv_ap<0, 0, RP>), dim3(np_ap), dim3(SPMV_NT), 0, st, AP_ARGS(pS));
 #undef AP_ARGS
             if (pb) HIPCHK(hipEventRecord(evs[3 * b + 2], st));

@@ -98,10 +98,6 @@ __device__ __forceinline__ double block_sum_all(double v, double *red)
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-struct Arena {
-    char *base = nullptr; size_t cap = 0, off = 0;
-};
-
 struct Engine {
     hipStream_t stream = nullptr;
     int device = 0;
@@ -114,8 +110,6 @@ struct Engine {
     // per-layer energies (copytoConstMemory)
     double E_gen[DKMC_MAX_LAYERS] = {0}, E_rec[DKMC_MAX_LAYERS] = {0}, E_Vdiff[DKMC_MAX_LAYERS] = {0}, E_Odiff[DKMC_MAX_LAYERS] = {0};
     int num_layers = 0;
-    // pinned host mailbox for small D2H reads
-    double *h_mail = nullptr;     // 64 doubles
     // named persistent device buffers (grown on demand, never shrunk)
     static const int NBUF = 64;
     void *buf[NBUF] = {nullptr};
@@ -134,12 +128,12 @@ MetalSet load_metals(const int *d_metals, int num_metals);   // small D2H (cache
 // scratch slots
 enum {
     S_CG_S = 0, S_CG_R, S_CG_P, S_CG_T, S_CG_PART, S_CG_CTRL, S_CG_RUNS, S_CG_REM, S_CG_NRUNS, S_CG_PS, S_CG_SEGOFF, S_CG_SEGS, S_CG_SEGPART,
-    S_K_DATA, S_K_RHS, S_K_DIAGPOS,
+    S_K_DATA, S_K_RHS,
     S_PW_LIST, S_PW_CNT,
-    S_EV_PROB, S_EV_ROWSUM, S_EV_G2, S_EV_G3, S_EV_CTRL, S_EV_UNI, S_EV_LOG, S_EV_TYPE,
+    S_EV_PROB, S_EV_ROWSUM, S_EV_G2, S_EV_G3, S_EV_CTRL, S_EV_UNI, S_EV_LOG,
     S_SCAN_TMP, S_SCAN_TMP2, S_SCAN_OFF64, S_SCAN_INTILE,
     S_AT_FLAG, S_AT_SITE, S_AT_OFSITE, S_AT_NEIGH,
-    S_X_ROWPTR, S_X_COL, S_X_DATA, S_X_DATA2, S_X_CNT, S_X_SLIST, S_X_SCB, S_X_SFLAG, S_X_RHS, S_X_WARM, S_X_SRANK,
+    S_X_ROWPTR, S_X_COL, S_X_DATA, S_X_DATA2, S_X_CNT, S_X_SLIST, S_X_SCB, S_X_SFLAG, S_X_RHS, S_X_SRANK,
     S_P_IMACRO, S_HEAT,
     S_MISC0, S_MISC1, S_MISC2, S_MISC3
 };

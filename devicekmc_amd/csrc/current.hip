@@ -526,7 +526,7 @@ __global__ void k_node_srank(int Nsub, const int *__restrict__ srank, int *__res
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < Nsub) node_srank[i] = i < 2 ? -1 : srank[i - 2];
 }
-__global__ void k_iota_rows(int n, int *rows, const int *inS, int want_S)
+__global__ void k_iota_rows(int n, int *rows)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) rows[i] = i;
@@ -644,7 +644,7 @@ extern "C" int dkmc_update_power_gpu_sparse(dkmc_gpubuf *buf, int n_src, int n_g
         hipLaunchKernelGGL(k_shift, dim3((Na + 2 + 255) / 256), dim3(256), 0, st, m, Na + 2, d_im + 1);
         int *rows = (int *)scratch(S_MISC0, (size_t)Nsub * 4);
         if (!rows) return e.err_code;
-        hipLaunchKernelGGL(k_iota_rows, dim3(nbr), dim3(256), 0, st, Nsub, rows, inS, 0);
+        hipLaunchKernelGGL(k_iota_rows, dim3(nbr), dim3(256), 0, st, Nsub, rows);
         hipLaunchKernelGGL((k_power<64>), dim3((Nsub + 3) / 4), dim3(256), 0, st, Na, Nsub, rows, rp, col, data, m, Vd, aflag, atom_site,
                            alpha_disp, buf->site_power);
     }

@@ -47,13 +47,6 @@ MetalSet load_metals(const int *d_metals, int num_metals)
     return ms;
 }
 
-static int ensure_mail()
-{
-    Engine &e = eng();
-    if (!e.h_mail) HIPCHK(hipHostMalloc((void **)&e.h_mail, 64 * sizeof(double)));
-    return 0;
-}
-
 extern "C" {
 
 const char *dkmc_last_error(void) { return eng().err; }
@@ -72,7 +65,7 @@ int dkmc_get_gpu_info(char *gpu_string, int capacity, int dev)
     return 0;
 }
 
-int dkmc_set_gpu(int dev) { HIPCHK(hipSetDevice(dev)); eng().device = dev; return ensure_mail(); }
+int dkmc_set_gpu(int dev) { HIPCHK(hipSetDevice(dev)); eng().device = dev; return 0; }
 int dkmc_set_stream(void *s) { eng().stream = (hipStream_t)s; return 0; }
 int dkmc_synchronize(void) { HIPCHK(hipStreamSynchronize(eng().stream)); return 0; }
 
@@ -115,7 +108,7 @@ int dkmc_gpubuf_create(dkmc_gpubuf *buf, int N, int N_atom, int nn, int nmt,
     HIPCHK(hipMemcpy(buf->freq, &freq, sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(buf->lattice, h_lattice, 3 * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(buf->neigh_idx, h_neigh, (size_t)N * nn * sizeof(int), hipMemcpyHostToDevice));
-    return ensure_mail();
+    return 0;
 }
 #undef ALLOC
 

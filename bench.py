@@ -73,7 +73,7 @@ def main():
     Vd = 5.0
     s, p = make_workload(args.workload)
     p.rnd_seed_kmc = parallel.replica_kmc_seed(p.rnd_seed_kmc, rank)   # replicas follow different event streams
-    dev = host.Device(s, p)
+    dev = host.Device(s, p, gpu_neighbors=devname)       # HIP cell-list neighbour index (setup, outside the timed region)
     sim = host.KMCProcess(dev, p.freq)
     gb = dev.make_gpubuf(devname)
     L.dkmc_set_current_warm_start(args.warm_start)

@@ -111,6 +111,20 @@ class GPUBuffers:
         self.t["T_bg"].fill_(float(T_bg))
 
 
+def build_neighbor_index_gpu(x, y, z, lattice, pbc, nn_dist, device="cuda:0"):
+    """Device.cpp:98-136 + :69-80 on the GPU (cell list, dkmc_build_neighbor_index).  Returns (neigh int32 [N, nn], nn)."""
+    L = _lib.load()
+    dev = torch.device(device)
+    _use_stream(dev)
+    tx, ty, tz = (torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(dev) for a in (x, y, z))
+    lat = np.ascontiguousarray(lattice, dtype=np.float64)
+    nn = C.c_int(0)
+    check(L.dkmc_build_neighbor_index(len(x), _ptr(tx), _ptr(ty), _ptr(tz), _np_ptr(lat), int(pbc), nn_dist, C.byref(nn), None))
+    out = torch.empty(len(x) * nn.value, dtype=torch.int32, device=dev)
+    check(L.dkmc_build_neighbor_index(len(x), _ptr(tx), _ptr(ty), _ptr(tz), _np_ptr(lat), int(pbc), nn_dist, C.byref(nn), _ptr(out)))
+    return out.cpu().numpy().reshape(len(x), nn.value), nn.value
+
+
 def _use_stream(dev):
     check(_lib.load().dkmc_set_stream(C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
 
@@ -118,11 +132,16 @@ def _use_stream(dev):
 class Device:
     """Device.h:61-231 (USE_CUDA build): host copy of the site fields + the thin callers of the GPU path."""
 
-    def __init__(self, structure: Structure, p: KMCParameters):
+    def __init__(self, structure: Structure, p: KMCParameters, gpu_neighbors=None):
+        """gpu_neighbors: device string (e.g. "cuda:0") to build the neighbour index with the HIP cell list instead of
+        the host k-d tree (same result; minutes faster at 1e6 sites)."""
         self.p = p
         self.N = structure.N
         self.site_x, self.site_y, self.site_z = structure.x, structure.y, structure.z
-        self.site_element, self.neigh_idx, self.max_num_neighbors, self.site_layer = prepare_device(structure, p)
+        neigh = None
+        if gpu_neighbors:
+            neigh = build_neighbor_index_gpu(structure.x, structure.y, structure.z, p.lattice, p.pbc, p.nn_dist, gpu_neighbors)
+        self.site_element, self.neigh_idx, self.max_num_neighbors, self.site_layer = prepare_device(structure, p, neigh)
         self.lattice, self.pbc, self.nn_dist, self.sigma, self.k = p.lattice, p.pbc, p.nn_dist, p.sigma, p.k
         self.T_bg = p.background_temp
         self.site_charge = np.zeros(self.N, dtype=np.int32)

@@ -58,6 +58,7 @@ SYMBOLS = {
     "dkmc_copy_charge_to_gpu": (_I, [C.POINTER(dkmc_gpubuf), vp]),
     "dkmc_copy_Tbg_to_gpu": (_I, [C.POINTER(dkmc_gpubuf), _D]),
     "dkmc_copy_to_const_memory": (_I, [vp, vp, vp, vp, _I]),
+    "dkmc_build_neighbor_index": (_I, [_I, vp, vp, vp, vp, _I, _D, c_int_p, vp]),
     "dkmc_initialize_sparsity": (_I, [C.POINTER(dkmc_gpubuf), _I, _D, _I]),
     "dkmc_update_charge_gpu": (_I, [vp, vp, vp, _I, _I, vp, _I]),
     "dkmc_update_CB_edge_gpu_sparse": (_I, [C.POINTER(dkmc_gpubuf), _I, _I, _I, _D, _I, _D, _D, _D, _I]),

@@ -139,12 +139,13 @@ def make_substoichiometric(element: np.ndarray, concentration: float, rng: StdMT
     return added
 
 
-def prepare_device(s: Structure, p: KMCParameters):
-    """Everything GPUBuffers is constructed from (kmc_main.cpp:88-121), as numpy arrays."""
+def prepare_device(s: Structure, p: KMCParameters, neigh_nn=None):
+    """Everything GPUBuffers is constructed from (kmc_main.cpp:88-121), as numpy arrays.
+    neigh_nn: optional precomputed (neigh_idx, nn), e.g. from the HIP cell-list builder."""
     element = s.element.copy()
     if p.pristine:
         rng = StdMT19937(p.rnd_seed)
         make_substoichiometric(element, p.initial_vacancy_concentration, rng)
-    neigh, nn = build_neighbor_index(s, p.lattice, p.pbc, p.nn_dist)
+    neigh, nn = neigh_nn if neigh_nn is not None else build_neighbor_index(s, p.lattice, p.pbc, p.nn_dist)
     layer = site_layers(s.x, p.layers)
     return element, neigh, nn, layer

@@ -112,6 +112,12 @@ int dkmc_copy_Tbg_to_gpu(dkmc_gpubuf *buf, double T_bg);                        
 int dkmc_copy_to_const_memory(const double *h_E_gen, const double *h_E_rec, const double *h_E_Vdiff,
                               const double *h_E_Odiff, int num_layers);
 
+/* ---- neighbour index: Device::constructSiteNeighborList + padding (Device.cpp:98-136, :69-80) ------- */
+/* Row i of d_neigh_out[N * nn] holds every j != i with site_dist(i, j) < nn_dist, ascending, -1 padded; nn = global maximum.
+ * Two calls: d_neigh_out == NULL computes nn into *nn_out; the second call fills d_neigh_out using nn = *nn_out. */
+int dkmc_build_neighbor_index(int N, const double *d_x, const double *d_y, const double *d_z, const double *h_lattice,
+                              int pbc, double nn_dist, int *nn_out, int *d_neigh_out);
+
 /* ---- sparsity of K: initialize_sparsity (iterative_solvers_gpu.cu:96-109) ------------------- */
 /* fills Device_*, contact_left_*, contact_right_* of buf (allocated by the library) */
 int dkmc_initialize_sparsity(dkmc_gpubuf *buf, int pbc, double nn_dist, int num_atoms_contact);

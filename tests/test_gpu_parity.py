@@ -313,3 +313,22 @@ def test_current_7p5_properties(dev_7p5, hip):
     import scipy.sparse as sp
     A = sp.csr_matrix((data, ci, rp))
     assert abs(A - A.T).max() <= 1e-12 * np.abs(data).max()
+
+
+def test_neighbor_index_gpu(cell_2p5, dev_7p5, hip):
+    """the HIP cell-list builder reproduces Device.cpp:98-136 + :69-80 (ascending j, -1 padding, nn = max)."""
+    from devicekmc_amd import params as pm, structure
+    from oracle import oracle as oc
+    host, L = hip
+    p = pm.KMCParameters()
+    for s, lat in ((cell_2p5, p.lattice), (dev_7p5, params_7p5().lattice)):
+        neigh, nn = host.build_neighbor_index_gpu(s.x, s.y, s.z, lat, False, p.nn_dist)
+        on, onn = oc.build_neighbors(s.x, s.y, s.z, np.array(lat), False, p.nn_dist)
+        assert nn == onn and np.array_equal(neigh, on)
+    sub = structure.Structure(cell_2p5.element[:3000], cell_2p5.x[:3000], cell_2p5.y[:3000], cell_2p5.z[:3000], {})
+    neigh, nn = host.build_neighbor_index_gpu(sub.x, sub.y, sub.z, p.lattice, True, p.nn_dist)
+    on, onn = oc.build_neighbors(sub.x, sub.y, sub.z, np.array(p.lattice), True, p.nn_dist)
+    assert nn == onn and np.array_equal(neigh, on)
+    # a Device built on it is identical to the host-built one
+    d1 = host.Device(cell_2p5, p); d2 = host.Device(cell_2p5, p, gpu_neighbors="cuda:0")
+    assert d1.max_num_neighbors == d2.max_num_neighbors and np.array_equal(d1.neigh_idx, d2.neigh_idx)

@@ -1,0 +1,71 @@
+"""Snapshot / log formats of the reference driver, host side.
+
+* Snapshots: ``Device::writeSnapshot`` (Device.cpp:236-252) writes ``N``, a blank line, then per site
+  ``element   x   y   z   potential   power`` with iostream's default 6 significant digits; ``restart = 1`` reloads such a
+  file as the site list through ``read_xyz`` (utils.cpp:72-98, kmc_main.cpp:65-80: only element and xyz are read back).
+  ``write_snapshot(..., full_precision=True)`` keeps 17 digits so that a restart reproduces the coordinates bit for bit.
+* Step log: the ``output.txt`` block per superstep (kmc_main.cpp:177-278): ``KMC step count``, ``V_vcm``, ``KMC time is``,
+  then the result map in key order (std::map), so the reference's timing_boxplot.py / plotting scripts can read it.
+"""
+import numpy as np
+
+from .params import ELEMENT_NAMES
+from .structure import Structure
+
+_NAME_TO_ELEMENT = {n: i for i, n in enumerate(ELEMENT_NAMES)}
+
+
+def _g6(v: float) -> str:
+    """operator<< of a double with the default precision (6 significant digits, %g)."""
+    return "%g" % v
+
+
+def write_snapshot(path, element, x, y, z, potential, power, full_precision=False):
+    fmt = (lambda v: repr(float(v))) if full_precision else _g6
+    with open(path, "w") as f:
+        f.write("%d\n\n" % len(element))
+        for i in range(len(element)):
+            f.write("%s   %s   %s   %s   %s   %s\n" % (ELEMENT_NAMES[int(element[i])], fmt(x[i]), fmt(y[i]), fmt(z[i]),
+                                                    fmt(potential[i]), fmt(power[i])))
+
+
+def read_xyz(path) -> Structure:
+    """utils.cpp:72-98: first line N, second line skipped, then ``element x y z [ignored...]``."""
+    with open(path) as f:
+        n = int(f.readline().split()[0])
+        f.readline()
+        el = np.empty(n, dtype=np.int32); xyz = np.empty((n, 3))
+        for i in range(n):
+            t = f.readline().split()
+            if t[0] not in _NAME_TO_ELEMENT:
+                raise ValueError("Error: Unknown element type in update_element!: " + t[0])
+            el[i] = _NAME_TO_ELEMENT[t[0]]
+            xyz[i] = (float(t[1]), float(t[2]), float(t[3]))
+    return Structure(el, xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), {})
+
+
+class StepLog:
+    """Accumulates the per-superstep block of output.txt (kmc_main.cpp:177-278)."""
+
+    def __init__(self):
+        self.lines = []
+
+    def bias_header(self, Vd, folder):
+        self.lines += ["--------------------------------", "Applied Voltage = %s V" % _g6(Vd),
+                       "--------------------------------", "Created folder: " + folder]
+
+    def step(self, kmc_step_count, V_vcm, kmc_time, result_map, t_fields=None, t_log=None, t_superstep=None):
+        self.lines += ["--------------", "KMC step count: %d" % kmc_step_count, "V_vcm: %s" % _g6(V_vcm),
+                       "KMC time is: %s" % _g6(kmc_time)]
+        for key in sorted(result_map):                       # std::map iterates in key order
+            self.lines.append("%s: %s" % (key, _g6(result_map[key])))
+        if t_fields is not None:
+            self.lines.append("Z - calculation time - all fields [s]: %s" % _g6(t_fields))
+        if t_log is not None:
+            self.lines.append("Z - calculation time - logging results [s]: %s" % _g6(t_log))
+        if t_superstep is not None:
+            self.lines.append("Z - calculation time - KMC superstep [s]: %s" % _g6(t_superstep))
+        self.lines.append("--------------------------------------")
+
+    def text(self):
+        return "\n".join(self.lines) + "\n"

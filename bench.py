@@ -146,8 +146,10 @@ def main():
             # 16 B per segment descriptor and 8 B per segment result.  The CSR formulation of the same product
             #  would move 12 B per entry.
             kname = "k_spmv_segs"
-            bytes_per_launch = 8.0 * st["spmv_segment_entries"] + 24.0 * st["spmv_segments"]
-            csr_equiv = 12.0 * st["spmv_segment_entries"] + 24.0 * st["spmv_long_rows"]
+            # the same launch also carries the short rows of X in CSR form (12 B per non-zero + 24 B per row)
+            bytes_per_launch = (8.0 * st["spmv_segment_entries"] + 24.0 * st["spmv_segments"]
+                                + 12.0 * st["spmv_short_nnz"] + 24.0 * st["spmv_short_rows"])
+            csr_equiv = 12.0 * nnz_all + 24.0 * rows_all
         else:
             kname = "k_spmv_ap"
             bytes_per_launch = 12.0 * nnz_all + 24.0 * rows_all

@@ -332,3 +332,25 @@ def test_neighbor_index_gpu(cell_2p5, dev_7p5, hip):
     # a Device built on it is identical to the host-built one
     d1 = host.Device(cell_2p5, p); d2 = host.Device(cell_2p5, p, gpu_neighbors="cuda:0")
     assert d1.max_num_neighbors == d2.max_num_neighbors and np.array_equal(d1.neigh_idx, d2.neigh_idx)
+
+
+def test_superstep_pbc_and_heating(cell_2p5, hip):
+    """The 2.5 nm cell is periodic in y,z with the period of parameters.txt: run it with pbc = 1 (wrapped distances in the
+    neighbour list, pair sum, event table and X) and global heating on; same events, T_bg and current as the oracle."""
+    from devicekmc_amd import params as pm
+    host, L = hip
+    p = pm.KMCParameters(); p.pbc = True; p.solve_heating_global = True; p.cg_tol = 1e-9
+    dev, sim, gb, o = make_pair(cell_2p5, p, hip)
+    assert dev.max_num_neighbors == o.nn and np.array_equal(dev.neigh_idx, o.neigh)
+    assert (dev.neigh_idx >= 0).sum() > 9399 * 23.3            # periodic images add neighbours at the lateral faces
+    for k in range(3):
+        dev.updateCharge(gb); dev.updatePotential(gb, p, Vd, k)
+        _, dt = sim.executeKMCStep(gb, dev, want_log=True)
+        dev.updatePower(gb, p, Vd); dev.updateTemperature(gb, p, dt)
+        out = o.superstep(Vd)
+        assert np.array_equal(sim.last_event_log, o.last_events["log"]), k
+        assert abs(dt / out["step_time"] - 1) <= 1e-7
+        assert abs(dev.imacro / out["imacro"] - 1) <= 1e-6
+        assert abs(dev.T_bg - out["T_bg"]) <= 1e-9
+    rp, ci, data = host.get_last_X()
+    assert np.array_equal(rp, o.last_X["row_ptr"]) and np.array_equal(ci, o.last_X["col"])

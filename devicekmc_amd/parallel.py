@@ -11,14 +11,18 @@ import torch.distributed as dist
 
 
 def init(backend=None):
-    """Returns (rank, world, local_rank).  Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment."""
+    """Returns (rank, world, local_rank).  Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the environment.
+    On GPUs the rank's device is selected BEFORE the process group is created (RCCL binds to the current device)."""
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+    if backend == "nccl" and torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, world, local_rank
 
 
@@ -29,7 +33,10 @@ def replica_kmc_seed(base_seed: int, rank: int) -> int:
 
 def barrier():
     if dist.is_initialized():
-        dist.barrier()
+        if dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(seconds: float, device="cpu") -> float:

@@ -64,7 +64,12 @@ def main():
     import torch
 
     from devicekmc_amd import parallel
-    rank, world, local_rank = parallel.init("nccl")
+    # rehearsal on a one-GPU box: DKMC_BENCH_BACKEND=gloo DKMC_BENCH_SINGLE_DEVICE=1 lets several ranks share cuda:0
+    backend = os.environ.get("DKMC_BENCH_BACKEND", "nccl")
+    if os.environ.get("DKMC_BENCH_SINGLE_DEVICE"):
+        os.environ["LOCAL_RANK_REAL"] = os.environ.get("LOCAL_RANK", "0")
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local_rank = parallel.init(backend)
     torch.cuda.set_device(local_rank)
     devname = "cuda:%d" % local_rank
 
@@ -129,7 +134,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t_start
     L.dkmc_set_profiling(0)
-    elapsed = parallel.max_over_ranks(elapsed, devname)
+    elapsed = parallel.max_over_ranks(elapsed, devname if backend == "nccl" else "cpu")
 
     st = host.get_stats()
     # ---- roofline of the dominant kernel: k_spmv_ap (CSR SpMV t = X p of the current solve's CG, fused p.t) ----

@@ -292,6 +292,11 @@ def test_kmc_time_vs_reference_cuda_log_7p5(dev_7p5, hip, ref_logs):
         assert abs(t / gold[k]["KMC time"] - 1) < 3e-4, (k, t, gold[k])
         pb = get(gb, "site_potential_boundary")
         assert np.abs(pb - o.pot_boundary).max() <= 1e-6 * Vd
+    # the remaining 16 logged supersteps, HIP path alone against the reference's log
+    for k in range(3, len(gold)):
+        dev.updateCharge(gb); dev.updatePotential(gb, p, Vd, k)
+        _, dt = sim.executeKMCStep(gb, dev); t += dt
+        assert abs(t / gold[k]["KMC time"] - 1) < 3e-4, (k, t, gold[k])
 
 
 def test_current_7p5_properties(dev_7p5, hip):

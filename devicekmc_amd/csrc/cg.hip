@@ -9,10 +9,13 @@
 //   * dot products are fused into the SpMV / axpy kernels; block partials are written to memory and
 //     re-reduced in a fixed order by every block of the consuming kernel (no atomics, run-to-run
 //     deterministic);
-//   * rows are binned by length: sub-wave groups of 16 lanes for short rows (K: ~26 nnz/row), one
-//     wave64 per long row (tunnelling rows of X have thousands of entries), so that each row is
-//     read as contiguous 64/128-byte segments.
-// HBM traffic per iteration (algorithmic): 12*nnz + 4*(m+1) + 96*m bytes.
+//   * rows are binned by length.  Short rows (K: ~26 nnz/row; the neighbour rows of X) take 16 lanes each.  The long rows
+//     of X (tunnelling rows, thousands of entries) are not multiplied in CSR form at all inside the iteration loop: their
+//     entries are viewed as index-free dense runs cut into <= 2048-entry segments, one wave64 per segment, 8 B per entry
+//     (k_build_runs / k_spmv_segs below); a tiny second kernel adds a row's segment partials in a fixed order;
+//   * row pointers are a template parameter (int for K, 64-bit for X whose non-zeros outgrow 2^31 at ~4e5 sites).
+// HBM traffic per iteration in the CSR formulation: 12*nnz + 4*(m+1) + 96*m bytes; with the segments the
+// matrix part of X drops to 8 B per entry.
 #include "common.h"
 #include <vector>
 #include <stdlib.h>

@@ -14,17 +14,16 @@ enum { EV_GEN = 0, EV_REC = 1, EV_VDIFF = 2, EV_IDIFF = 3, EV_NULL = 4 };
 #define DKMC_KB 8.617333262e-5       // kmc_events.cu:4
 #define DKMC_Q 1.60217663e-19        // gpu_solvers.h:261
 #define DKMC_HBAR 1.054571817e-34    // iterative_solvers_gpu.cu:8
-#define DKMC_MAX_METALS 8
 #define DKMC_MAX_LAYERS 5            // kmc_events.cu:7
 #define WAVE 64
 
-struct MetalSet { int n; int e[DKMC_MAX_METALS]; };
+// the list of metallic elements stays in device memory, as in the reference (is_in_array_gpu, gpu_solvers.h:211-220)
+struct MetalSet { int n; const int *e; };
 
 __device__ __forceinline__ bool is_metal(int el, const MetalSet &ms)
 {
     bool r = false;
-#pragma unroll
-    for (int t = 0; t < DKMC_MAX_METALS; ++t) r |= (t < ms.n) && (ms.e[t] == el);
+    for (int t = 0; t < ms.n; ++t) r |= (ms.e[t] == el);
     return r;
 }
 
@@ -120,7 +119,7 @@ Engine &eng();
 int dkmc_fail(int code, const char *what, const char *file, int line);
 // persistent scratch: returns a device buffer of at least `bytes`, identified by slot
 void *scratch(int slot, size_t bytes);
-MetalSet load_metals(const int *d_metals, int num_metals);   // small D2H (cached by pointer)
+inline MetalSet load_metals(const int *d_metals, int num_metals) { MetalSet ms; ms.n = num_metals; ms.e = d_metals; return ms; }
 
 #define HIPCHK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) return dkmc_fail((int)e__, hipGetErrorString(e__), __FILE__, __LINE__); } while (0)
 #define KCHK() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return dkmc_fail((int)e__, hipGetErrorString(e__), __FILE__, __LINE__); } while (0)

@@ -33,20 +33,6 @@ void *scratch(int slot, size_t bytes)
     return e.buf[slot];
 }
 
-static const int *g_metal_ptr = nullptr; static int g_metal_n = -1; static MetalSet g_metal_cache;
-MetalSet load_metals(const int *d_metals, int num_metals)
-{
-    if (d_metals == g_metal_ptr && num_metals == g_metal_n) return g_metal_cache;
-    MetalSet ms; ms.n = num_metals > DKMC_MAX_METALS ? DKMC_MAX_METALS : num_metals;
-    for (int i = 0; i < DKMC_MAX_METALS; ++i) ms.e[i] = -1;
-    if (ms.n > 0) {
-        (void)hipStreamSynchronize(eng().stream);
-        (void)hipMemcpy(ms.e, d_metals, ms.n * sizeof(int), hipMemcpyDeviceToHost);
-    }
-    g_metal_ptr = d_metals; g_metal_n = num_metals; g_metal_cache = ms;
-    return ms;
-}
-
 extern "C" {
 
 const char *dkmc_last_error(void) { return eng().err; }

@@ -61,7 +61,7 @@ __global__ void k_kpat_count(int m, int N_left, int nn, const int *__restrict__ 
 }
 
 __global__ void k_kpat_fill(int m, int N_left, int nn, const int *__restrict__ neigh,
-                            const int *rpd, const int *rpl, const int *rpr, int *cold, int *coll, int *colr, int *diagpos)
+                            const int *rpd, const int *rpl, const int *rpr, int *cold, int *coll, int *colr)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= m) return;
@@ -75,16 +75,30 @@ __global__ void k_kpat_fill(int m, int N_left, int nn, const int *__restrict__ n
         if (j < N_left) coll[pl++] = j;
         else if (j >= N_left + m) colr[pr++] = j - (N_left + m);
         else {
-            if (!diag_done && j > i) { diagpos[r] = pd; cold[pd++] = r; diag_done = true; }
+            if (!diag_done && j > i) { cold[pd++] = r; diag_done = true; }
             cold[pd++] = j - N_left;
         }
     }
-    if (!diag_done) { diagpos[r] = pd; cold[pd++] = r; }
+    if (!diag_done) cold[pd++] = r;
+}
+
+// shape of every K pattern built by initialize_sparsity, keyed by its row-pointer array: a solve with other contact sizes
+// than the pattern was built for would index out of bounds
+struct KPatInfo { const int *rp; int m, N_left; };
+static KPatInfo g_kpat[16]; static int g_kpat_n = 0;
+static void kpat_register(const int *rp, int m, int N_left)
+{
+    for (int i = 0; i < g_kpat_n; ++i) if (g_kpat[i].rp == rp) { g_kpat[i].m = m; g_kpat[i].N_left = N_left; return; }
+    g_kpat[g_kpat_n % 16] = KPatInfo{rp, m, N_left}; ++g_kpat_n; if (g_kpat_n > 16) g_kpat_n = 16;
+}
+static bool kpat_matches(const int *rp, int m, int N_left)
+{
+    for (int i = 0; i < g_kpat_n; ++i) if (g_kpat[i].rp == rp) return g_kpat[i].m == m && g_kpat[i].N_left == N_left;
+    return false;
 }
 
 __global__ void k_set_last(int *rp, int m, const int *total) { if (threadIdx.x == 0 && blockIdx.x == 0) rp[m] = *total; }
 
-static int *g_diagpos = nullptr; static int g_diagpos_m = 0; static int g_kpat_N_left = -1;
 
 extern "C" int dkmc_initialize_sparsity(dkmc_gpubuf *buf, int pbc, double nn_dist, int num_atoms_contact)
 {
@@ -114,14 +128,12 @@ extern "C" int dkmc_initialize_sparsity(dkmc_gpubuf *buf, int pbc, double nn_dis
     HIPCHK(hipStreamSynchronize(st));
     buf->Device_nnz = h_tot[0]; buf->contact_left_nnz = h_tot[1]; buf->contact_right_nnz = h_tot[2];
     for (int b = 0; b < 3; ++b) HIPCHK(hipMalloc((void **)cis[b], (size_t)(h_tot[b] > 0 ? h_tot[b] : 1) * sizeof(int)));
-    if (g_diagpos) (void)hipFree(g_diagpos);
-    HIPCHK(hipMalloc((void **)&g_diagpos, (size_t)m * sizeof(int)));
-    g_diagpos_m = m; g_kpat_N_left = N_left;
     hipLaunchKernelGGL(k_kpat_fill, dim3(blocks), dim3(256), 0, st, m, N_left, nn, buf->neigh_idx,
                        buf->Device_row_ptr_d, buf->contact_left_row_ptr, buf->contact_right_row_ptr,
-                       buf->Device_col_indices_d, buf->contact_left_col_indices, buf->contact_right_col_indices, g_diagpos);
+                       buf->Device_col_indices_d, buf->contact_left_col_indices, buf->contact_right_col_indices);
     KCHK();
     HIPCHK(hipStreamSynchronize(st));
+    kpat_register(buf->Device_row_ptr_d, m, N_left);
     return 0;
 }
 
@@ -145,7 +157,7 @@ __global__ __launch_bounds__(256) void k_assemble_K(int m, int N_left, const int
                                                     const int *__restrict__ rp, const int *__restrict__ ci,
                                                     const int *__restrict__ lrp, const int *__restrict__ lci,
                                                     const int *__restrict__ rrp, const int *__restrict__ rci,
-                                                    const int *__restrict__ diagpos, double VL, double VR,
+                                                    double VL, double VR,
                                                     double *__restrict__ data, double *__restrict__ rhs)
 {
     const int LPR = 16;
@@ -155,9 +167,10 @@ __global__ __launch_bounds__(256) void k_assemble_K(int m, int N_left, const int
     const int i = N_left + r;
     const int ei = element[i], qi = charge[i];
     double off = 0.0, kl = 0.0, kr = 0.0;
+    int dpos = -1;                                   // position of the diagonal entry (exactly one lane meets it)
     for (int p = rp[r] + l; p < rp[r + 1]; p += LPR) {
         const int c = ci[p];
-        if (c == r) continue;
+        if (c == r) { dpos = p; continue; }
         const int j = N_left + c;
         const double gg = k_cond<CB>(ei, element[j], qi, charge[j], ms, high_G, low_G);
         data[p] = -gg;
@@ -167,13 +180,11 @@ __global__ __launch_bounds__(256) void k_assemble_K(int m, int N_left, const int
     for (int p = rrp[r] + l; p < rrp[r + 1]; p += LPR) { const int j = N_left + m + rci[p]; kr += k_cond<CB>(ei, element[j], qi, charge[j], ms, high_G, low_G); }
 #pragma unroll
     for (int o = LPR / 2; o > 0; o >>= 1) { off += __shfl_xor(off, o, LPR); kl += __shfl_xor(kl, o, LPR); kr += __shfl_xor(kr, o, LPR); }
-    if (l == 0) {
-        double d = off;      // reduce_rows_into_diag: -(sum of off-diagonals)
-        d += kl;             // add_vector_to_diagonal (left)
-        d += kr;             // add_vector_to_diagonal (right)
-        data[diagpos[r]] = d;
-        rhs[r] = kl * VL + kr * VR;
-    }
+    double d = off;          // reduce_rows_into_diag: -(sum of off-diagonals)
+    d += kl;                 // add_vector_to_diagonal (left)
+    d += kr;                 // add_vector_to_diagonal (right)
+    if (dpos >= 0) data[dpos] = d;
+    if (l == 0) rhs[r] = kl * VL + kr * VR;
 }
 
 __global__ void k_fill_contacts(double *field, int N, int N_left, int N_right, double vl, double vr, double scale_all)
@@ -190,8 +201,10 @@ static int solve_K(dkmc_gpubuf *buf, int N, int N_left, int N_right, double VL, 
 {
     Engine &e = eng(); hipStream_t st = e.stream;
     const int m = N - N_left - N_right;
-    if (!buf->Device_row_ptr_d || g_diagpos_m != m || g_kpat_N_left != N_left)
-        return dkmc_fail(6, "K sparsity not initialised for this contact size (call initialize_sparsity)", __FILE__, __LINE__);
+    if (!buf->Device_row_ptr_d || !buf->Device_col_indices_d || !buf->contact_left_row_ptr || !buf->contact_right_row_ptr)
+        return dkmc_fail(6, "K sparsity not initialised (call initialize_sparsity)", __FILE__, __LINE__);
+    if (N_left != N_right || !kpat_matches(buf->Device_row_ptr_d, m, N_left))
+        return dkmc_fail(6, "K sparsity was built for other contact sizes than this solve asks for", __FILE__, __LINE__);
     double *data = (double *)scratch(S_K_DATA, (size_t)buf->Device_nnz * 8);
     double *rhs = (double *)scratch(S_K_RHS, (size_t)m * 8);
     if (!data || !rhs) return e.err_code;
@@ -200,11 +213,11 @@ static int solve_K(dkmc_gpubuf *buf, int N, int N_left, int N_right, double VL, 
     if (cb) hipLaunchKernelGGL((k_assemble_K<1>), dim3(blocks), dim3(256), 0, st, m, N_left, buf->site_element, buf->site_charge, ms,
                                high_G, low_G, buf->Device_row_ptr_d, buf->Device_col_indices_d, buf->contact_left_row_ptr,
                                buf->contact_left_col_indices, buf->contact_right_row_ptr, buf->contact_right_col_indices,
-                               g_diagpos, VL, VR, data, rhs);
+                               VL, VR, data, rhs);
     else hipLaunchKernelGGL((k_assemble_K<0>), dim3(blocks), dim3(256), 0, st, m, N_left, buf->site_element, buf->site_charge, ms,
                             high_G, low_G, buf->Device_row_ptr_d, buf->Device_col_indices_d, buf->contact_left_row_ptr,
                             buf->contact_left_col_indices, buf->contact_right_row_ptr, buf->contact_right_col_indices,
-                            g_diagpos, VL, VR, data, rhs);
+                            VL, VR, data, rhs);
     KCHK();
     return cg_solve_jacobi(data, buf->Device_row_ptr_d, buf->Device_col_indices_d, buf->Device_nnz, m, rhs, field + N_left, 1, nullptr, 0, iters, rr);
 }

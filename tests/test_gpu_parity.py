@@ -359,3 +359,58 @@ def test_superstep_pbc_and_heating(cell_2p5, hip):
         assert abs(dev.T_bg - out["T_bg"]) <= 1e-9
     rp, ci, data = host.get_last_X()
     assert np.array_equal(rp, o.last_X["row_ptr"]) and np.array_equal(ci, o.last_X["col"])
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_randomised_event_engine(cell_2p5, hip, seed):
+    """All four event classes (generation, recombination, vacancy and ion diffusion) on randomised site states and
+    potentials: event table exact, long event sequences identical to the oracle, charges exact."""
+    from devicekmc_amd import params as pm
+    from devicekmc_amd.host import _ptr
+    from devicekmc_amd.lib import check
+    host, L = hip
+    torch = _torch()
+    rng = np.random.default_rng(seed)
+    p = pm.KMCParameters(); p.rnd_seed_kmc = seed
+    dev, sim, gb, o = make_pair(cell_2p5, p, hip, tol=1e-6)
+    el = o.element.copy()
+    ox = np.nonzero(el == pm.O_EL)[0]; dd = np.nonzero(el == pm.DEFECT)[0]
+    el[rng.choice(ox, 300, replace=False)] = pm.VACANCY                    # many vacancies, some clustered
+    el[rng.choice(dd, 200, replace=False)] = pm.OXYGEN_DEFECT              # oxygen ions on interstitial sites
+    o.element[:] = el; put(gb, "site_element", el)
+    dev.updateCharge(gb); o.update_charge()
+    assert np.array_equal(get(gb, "site_charge"), o.charge)
+    # rough potentials so that every class gets appreciable rates (|dphi| up to ~2 V between neighbours)
+    pb = np.linspace(-2.5, 2.5, dev.N)[np.argsort(np.argsort(o.x))] + 0.3 * rng.standard_normal(dev.N)
+    pc = 0.2 * rng.standard_normal(dev.N)
+    o.pot_boundary[:] = pb; o.pot_charge[:] = pc
+    put(gb, "site_potential_boundary", pb); put(gb, "site_potential_charge", pc)
+    N, nn = dev.N, dev.max_num_neighbors
+    ev_type = torch.zeros(N * nn, dtype=torch.int32, device="cuda:0"); ev_prob = torch.zeros(N * nn, dtype=torch.float64, device="cuda:0")
+    check(L.dkmc_build_event_list(N, nn, _ptr(gb.neigh_idx), _ptr(gb.site_layer), _ptr(gb.lattice), int(p.pbc), _ptr(gb.T_bg), _ptr(gb.freq),
+                                  _ptr(gb.sigma), _ptr(gb.k), _ptr(gb.site_x), _ptr(gb.site_y), _ptr(gb.site_z),
+                                  _ptr(gb.site_potential_boundary), _ptr(gb.site_potential_charge), _ptr(gb.site_element),
+                                  _ptr(gb.site_charge), _ptr(ev_type), _ptr(ev_prob)))
+    torch.cuda.synchronize()
+    ot, op = o.build_event_list()
+    gt = ev_type.cpu().numpy()
+    assert np.array_equal(gt, ot)
+    for cls in range(4):
+        assert (ot == cls).sum() > 0, cls                                 # every class is present
+    gp = ev_prob.cpu().numpy(); nz = op > 0
+    fin = nz & np.isfinite(op)
+    assert np.array_equal(np.isfinite(gp), np.isfinite(op))
+    assert np.abs(gp[fin] / op[fin] - 1).max() <= 1e-10
+    if np.isfinite(op).all():
+        # event loop: with rates this large hundreds of events run before a waiting time exceeds 1/freq
+        sim.batch = 64
+        _, dt = sim.executeKMCStep(gb, dev, want_log=True)
+        odt = o.execute_kmc_step(ev=(ot, op))
+        n = o.last_events["n"]
+        assert n >= 100 and (np.bincount(o.last_events["log"][:, 3], minlength=4)[:4] > 0).all()   # all four classes EXECUTED
+        safe = o.last_events["margin"] > 1e-9                              # draws within rounding distance of a bucket edge are exempt
+        k = n if safe.all() else int(np.argmin(safe))
+        assert np.array_equal(sim.last_event_log[:k], o.last_events["log"][:k])
+        if safe.all():
+            assert len(sim.last_event_log) == n and abs(dt / odt - 1) <= 1e-9
+            assert np.array_equal(get(gb, "site_element"), o.element) and np.array_equal(get(gb, "site_charge"), o.charge)

@@ -414,3 +414,39 @@ def test_randomised_event_engine(cell_2p5, hip, seed):
         if safe.all():
             assert len(sim.last_event_log) == n and abs(dt / odt - 1) <= 1e-9
             assert np.array_equal(get(gb, "site_element"), o.element) and np.array_equal(get(gb, "site_charge"), o.charge)
+
+
+def test_current_solve_randomised_negative_bias(cell_2p5, hip):
+    """X assembly / solve / power on a state with 300 vacancies (clusters of neutral vacancies -> high_G links) at a
+    NEGATIVE bias (the `ical > 0 && Vd < 0` branch of the power formula): pattern exact, values, I_macro, power."""
+    from devicekmc_amd import params as pm
+    from oracle import oracle as oc
+    host, L = hip
+    V = -3.0
+    p = pm.KMCParameters(); p.cg_tol = 1e-10; p.solve_heating_global = True
+    dev = host.Device(cell_2p5, p); sim = host.KMCProcess(dev, p.freq)
+    gb = dev.make_gpubuf("cuda:0")
+    L.dkmc_set_current_warm_start(0)
+    rng = np.random.default_rng(5)
+    el = dev.site_element.copy()
+    ox = np.nonzero(el == pm.O_EL)[0]
+    el[rng.choice(ox, 300, replace=False)] = pm.VACANCY
+    dev.site_element = el
+    dev.setLaplacePotential(gb, p, V)
+    gb.sync_HostToGPU(dev)
+    o = oc.OracleKMC(cell_2p5.element, cell_2p5.x, cell_2p5.y, cell_2p5.z, p)
+    o.element[:] = el
+    o.set_laplace_potential(V)
+    dev.updateCharge(gb); o.update_charge()
+    assert np.array_equal(get(gb, "site_charge"), o.charge)
+    assert ((o.element == pm.VACANCY) & (o.charge == 0)).sum() > 20          # neutral (clustered / contact-adjacent) vacancies exist
+    dev.updatePower(gb, p, V)
+    oi = o.update_power(V, heating=True)
+    rp, ci, data = host.get_last_X()
+    X = o.last_X
+    assert np.array_equal(rp, X["row_ptr"]) and np.array_equal(ci, X["col"])
+    big = np.abs(X["data"]) > 1e-300
+    assert np.abs(data[big] / X["data"][big] - 1).max() <= 1e-10
+    assert oi < 0 and abs(dev.imacro / oi - 1) <= 1e-6
+    pw = get(gb, "site_power")
+    assert np.abs(o.power).max() > 0 and np.abs(pw - o.power).max() <= 1e-6 * np.abs(o.power).max()

@@ -221,7 +221,8 @@ def main():
                        "current_warm_start": args.warm_start, "cg_tol": p.cg_tol},
             "split_ms": {k: round(v / n * 1e3, 3) for k, v in phases.items()},
             "per_step": {"events": counters["events"] / n, "cg_iters_K": counters["cg_iters_K"] / n,
-                         "cg_iters_X": counters["cg_iters_X"] / n, "X_nnz": int(st["X_nnz"])},
+                         "cg_iters_X": counters["cg_iters_X"] / n, "X_nnz": int(st["X_nnz"]), "n_charged": int(st["n_charged"]),
+                         "K_rows": int(s.N - 2 * p.num_atoms_first_layer), "K_nnz": int(gb.c.Device_nnz)},
             "roofline": roof, "cpu_baseline": cpu, "alt_warm_start": alt,
         }
         print(json.dumps(out))

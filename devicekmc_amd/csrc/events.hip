@@ -19,7 +19,7 @@ __constant__ LayerEnergies c_layerE;
 
 struct EvOut {                 // device -> host mailbox
     double event_time, psum_last;
-    int n_events, exhausted, bad, pad;
+    int n_events, exhausted, bad, n_charged;
 };
 
 // rate of slot (i, j): kmc_events.cu:52-122.  Returns the event type, P through *prob.
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(EVL_NT) void k_ev_loop(int N, int nn, const int *__
                                                     int ng2, int ng3, int *__restrict__ element, int *__restrict__ charge,
                                                     const double *__restrict__ uniform, int n_uniform,
                                                     const double *__restrict__ freq_p, EvOut *__restrict__ out,
-                                                    int *__restrict__ evlog, int max_log)
+                                                    int *__restrict__ evlog, int max_log, const int *__restrict__ ncharged_p)
 {
     __shared__ int sh_i, sh_j, sh_stop;
     __shared__ double sh_psum;
@@ -244,7 +244,8 @@ __global__ __launch_bounds__(EVL_NT) void k_ev_loop(int N, int nn, const int *__
         ++n_events;
         if (!(event_time < inv_freq)) break;
     }
-    if (tid == 0) { out->event_time = event_time; out->psum_last = psum_last; out->n_events = n_events; out->exhausted = exhausted; out->bad = bad; }
+    if (tid == 0) { out->event_time = event_time; out->psum_last = psum_last; out->n_events = n_events; out->exhausted = exhausted; out->bad = bad;
+                    out->n_charged = ncharged_p ? *ncharged_p : -1; }     // charged-site count of the last pair sum rides along in the mailbox
 }
 
 // called by dkmc_copy_to_const_memory (engine.hip)
@@ -294,13 +295,14 @@ extern "C" int dkmc_execute_kmc_step_gpu(int N, int nn, const int *neigh, const 
         hipLaunchKernelGGL(k_ev_level, dim3((ng3 + 3) / 4), dim3(256), 0, st, ng2, g2, ng3, g3);
     }
     hipLaunchKernelGGL(k_ev_loop, dim3(1), dim3(EVL_NT), 0, st, N, nn, neigh, ev_prob, rowsum, g2, g3, ng2, ng3, element, charge,
-                       uni, n_uniform, freq, out, h_event_log ? evlog : (int *)nullptr, max_log);
+                       uni, n_uniform, freq, out, h_event_log ? evlog : (int *)nullptr, max_log, (const int *)e.buf[S_PW_CNT]);
     KCHK();
     EvOut h;
     HIPCHK(hipMemcpyAsync(&h, out, sizeof(EvOut), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (h_event_log && h.n_events > 0) HIPCHK(hipMemcpy(h_event_log, evlog, (size_t)h.n_events * 16, hipMemcpyDeviceToHost));
     e.stats.n_events = h.n_events; e.stats.psum_last = h.psum_last;
+    if (h.n_charged >= 0) e.stats.n_charged = h.n_charged;
     if (n_events_out) *n_events_out = h.n_events;
     if (exhausted_out) *exhausted_out = h.exhausted;
     if (event_time_out) *event_time_out = h.event_time;

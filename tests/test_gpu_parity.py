@@ -450,3 +450,30 @@ def test_current_solve_randomised_negative_bias(cell_2p5, hip):
     assert oi < 0 and abs(dev.imacro / oi - 1) <= 1e-6
     pw = get(gb, "site_power")
     assert np.abs(o.power).max() > 0 and np.abs(pw - o.power).max() <= 1e-6 * np.abs(o.power).max()
+
+
+def test_crossbar_log(hip, ref_logs, golden_dir):
+    """structures/crossbars/timing_10nm_5pitch (110 813 sites, V = 1, solve_current = 0): a second geometry.  Same events as
+    the oracle; KMC time of the first logged supersteps of the reference's CUDA run within 5e-3 (its CG stops at 1e-6 and the
+    rates at V = 1 amplify that; beyond step 10 the logged trajectory and a converged one part at a single event)."""
+    from devicekmc_amd import params as pm, structure
+    from oracle import oracle as oc
+    host, L = hip
+    gold = ref_logs["crossbars/timing_10nm_5pitch/output_initial.txt"]["steps"]
+    s = structure.load_structure(os.path.join(golden_dir, "crossbar_10nm_5pitch.npz"))
+    p = pm.KMCParameters(rnd_seed=5, lattice=tuple(s.meta["lattice"]), num_atoms_first_layer=144, num_atoms_contact=11520)
+    p.cg_tol = 1e-9; p.solve_current = False
+    V = 1.0
+    dev = host.Device(s, p, gpu_neighbors="cuda:0"); sim = host.KMCProcess(dev, p.freq)
+    gb = dev.make_gpubuf("cuda:0")
+    o = oc.OracleKMC(s.element, s.x, s.y, s.z, p)
+    assert dev.N == 110813 and np.array_equal(dev.neigh_idx, o.neigh) and np.array_equal(dev.site_element, o.element)
+    t = 0.0
+    for k in range(8):
+        dev.updateCharge(gb); dev.updatePotential(gb, p, V, k)
+        _, dt = sim.executeKMCStep(gb, dev, want_log=True); t += dt
+        if k < 3:
+            o.superstep(V)
+            assert np.array_equal(sim.last_event_log, o.last_events["log"]), k
+            assert np.array_equal(get(gb, "site_charge"), o.charge)
+        assert abs(t / gold[k]["KMC time"] - 1) < 5e-3, (k, t, gold[k])

@@ -477,3 +477,27 @@ def test_crossbar_log(hip, ref_logs, golden_dir):
             assert np.array_equal(sim.last_event_log, o.last_events["log"]), k
             assert np.array_equal(get(gb, "site_charge"), o.charge)
         assert abs(t / gold[k]["KMC time"] - 1) < 5e-3, (k, t, gold[k])
+
+
+def test_error_paths(cell_2p5, hip):
+    """Errors are reported through return codes + dkmc_last_error (the shim prints and carries on like the reference)."""
+    from devicekmc_amd import params as pm
+    from devicekmc_amd.lib import DeviceKMCError, check
+    host, L = hip
+    p = pm.KMCParameters()
+    dev = host.Device(cell_2p5, p)
+    gb = host.GPUBuffers(p.layers, dev.site_layer, p.freq, dev.N, dev.N_atom, dev.site_x, dev.site_y, dev.site_z, dev.max_num_neighbors,
+                         dev.sigma, dev.k, dev.lattice, dev.neigh_idx, list(p.metals), "cuda:0")
+    gb.sync_HostToGPU(dev)
+    with pytest.raises(DeviceKMCError, match="sparsity"):            # solve before initialize_sparsity
+        dev.updatePotential(gb, p, Vd, 0)
+    check(L.dkmc_initialize_sparsity(C.byref(gb.c), 0, p.nn_dist, p.num_atoms_first_layer))
+    with pytest.raises(DeviceKMCError, match="contact sizes"):      # solve with other contact sizes than the pattern
+        check(L.dkmc_background_potential_gpu_sparse(C.byref(gb.c), dev.N, 100, 100, Vd, 0, p.high_G, p.low_G, p.nn_dist, 2, 0))
+    dev.updatePotential(gb, p, Vd, 0)
+    # a device without any possible event: every rate is zero -> reported, not a hang
+    put(gb, "site_element", np.full(dev.N, pm.Hf_EL, dtype=np.int32))
+    sim = host.KMCProcess(dev, p.freq)
+    with pytest.raises(DeviceKMCError, match="positive rate"):
+        sim.executeKMCStep(gb, dev)
+    assert L.dkmc_last_error() == b""                                 # cleared by the raising wrapper

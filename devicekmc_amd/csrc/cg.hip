@@ -488,7 +488,8 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
 
     // ---- dense-run view of the long rows ----
     static const int use_runs_env = getenv("DKMC_NO_RUNS") ? 0 : 1;
-    static const int seg_len = getenv("DKMC_SEG_LEN") ? atoi(getenv("DKMC_SEG_LEN")) : SEG_LEN;     // experiments; >= RUN_MIN_LEN
+    // experiments only; the descriptor capacity per row (nnz/RUN_MIN_LEN + 1) needs segments of at least 2 * RUN_MIN_LEN entries
+    static const int seg_len = getenv("DKMC_SEG_LEN") ? (atoi(getenv("DKMC_SEG_LEN")) < 2 * RUN_MIN_LEN ? 2 * RUN_MIN_LEN : atoi(getenv("DKMC_SEG_LEN"))) : SEG_LEN;
     const bool use_runs = use_runs_env && srank && n_long > 0 && ns > 0;
     RunDesc *runs = nullptr, *segs = nullptr; int *nruns = nullptr, *rem = nullptr, *nrem = nullptr, *seg_off = nullptr; double *pS = nullptr, *seg_part = nullptr;
     int nseg = 0;

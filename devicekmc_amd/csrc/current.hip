@@ -143,7 +143,7 @@ __global__ __launch_bounds__(XS_NT) void k_xpat_S(XParams P, int ns, const SEntr
                                                   const int *__restrict__ ancnt, int *__restrict__ cnt, const xrp_t *__restrict__ rp,
                                                   int *__restrict__ col)
 {
-    __shared__ int nb[72], hist[72], wtot[XS_NT / 64], s_total;
+    __shared__ int nb[72], hist[72], wtot[XS_NT / 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const SEntry me = S[blockIdx.x];
     const int a = me.idx, row = a + 2, N_full = P.Na + 2;
@@ -152,7 +152,6 @@ __global__ __launch_bounds__(XS_NT) void k_xpat_S(XParams P, int ns, const SEntr
         int n = 0; bool self_done = false;
         for (int s = 0; s < nnb; ++s) { const int b = aneigh[(size_t)a * P.nn + s]; if (!self_done && b > a) { nb[n++] = a; self_done = true; } nb[n++] = b; }
         if (!self_done) nb[n++] = a;
-        s_total = 0;
     }
     if (tid < 72) hist[tid] = 0;
     __syncthreads();

@@ -438,7 +438,7 @@ static inline int grid_for(int work_items, int per_block)
 // the system: rank in the tunnelling set or -1) enables the dense-run view of the long rows.
 template <typename RP>
 static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long nnz, int m, double *x, double *y,
-                             int uniform_rows, const int *srank, int ns, int *iters_out, double *rr_out)
+                             int uniform_rows, const int *srank, int ns, int *iters_out, double *rr_out, int *iter_hint = nullptr)
 {
     Engine &e = eng(); hipStream_t st = e.stream;
     if (m <= 0) { if (iters_out) *iters_out = 0; if (rr_out) *rr_out = 0; return 0; }
@@ -544,7 +544,11 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
         }
     }
     // ---- iterations, launched in batches; the host polls the control block between batches ----
-    int it = 0, batch = 8, launched = 0;
+    // Batch plan: the iteration count of consecutive solves of the same system changes slowly (X: 666 +- 10 at 85 k sites), so
+    // the first batch is sized just below the previous count; after it, short batches keep the no-op tail small.
+    int it = 0, launched = 0;
+    int batch = 8;
+    if (iter_hint && *iter_hint > 24) batch = *iter_hint - 8;
     static const int spmv_var = getenv("DKMC_SPMV_VAR") ? atoi(getenv("DKMC_SPMV_VAR")) : 0;   // experiments only
     static const int seg_unr = getenv("DKMC_SEG_UNR") ? atoi(getenv("DKMC_SEG_UNR")) : 4;
     // matrix stream: default cache policy while the values of one sweep fit the 256 MiB Infinity Cache (they are re-read
@@ -555,7 +559,7 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
         HIPCHK(hipMemcpyAsync(&h, ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (prof && launched) {       // only launches that did work (iteration index below the final count) are counted
-            for (int b = 0; b < launched; b += PROF_STRIDE) {
+            for (int b = 0; b < launched && b < 64; b += PROF_STRIDE) {
                 if (it - launched + b >= h.iters) break;
                 float ms = 0.f;
                 if (use_runs) {
@@ -567,7 +571,7 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
         if (h.done) break;
         if (it >= 200000) { dkmc_fail(4, "CG: no convergence after 200000 iterations", __FILE__, __LINE__); break; }
         for (int b = 0; b < batch; ++b, ++it) {
-            const bool pb = prof && (b % PROF_STRIDE == 0);      // events perturb the stream: sample 1 launch in 8
+            const bool pb = prof && b < 64 && (b % PROF_STRIDE == 0);      // events perturb the stream: sample 1 launch in 8 (first 64 of a batch)
             if (pb) HIPCHK(hipEventRecord(evs[3 * b], st));
 #define AP_ARGS(vec) n_short, short_rows, hs, n_long, long_rows, rp, ci, (const double *)a, (const double *)p, t, part_pAp, ctrl, \
                 (const RunDesc *)runs, (const int *)nruns, (const int *)rem, (const int *)nrem, (const double *)(vec), (const int *)seg_off
@@ -592,7 +596,8 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
         }
         launched = batch;
         KCHK();
-        if (batch < 64) batch *= 2;
+        if (iter_hint && *iter_hint > 24) batch = 8;           // after the sized first batch: short ones
+        else if (batch < 64) batch *= 2;
     }
 #undef SPMV
     if (prof) {
@@ -603,6 +608,7 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
     hipLaunchKernelGGL(k_vec_mul, dim3(gv), dim3(CG_NT), 0, st, m, y, s);
     KCHK();
     if (iters_out) *iters_out = h.iters;
+    if (iter_hint) *iter_hint = h.iters;
     if (rr_out) *rr_out = h.rr[h.iters & 1];
     return e.err_code;
 }
@@ -616,7 +622,8 @@ int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, dou
 int cg_solve_jacobi64(double *a, const long long *rp, const int *ci, long long nnz, int m, double *x, double *y,
                       int uniform_rows, const int *srank, int ns, int *iters_out, double *rr_out)
 {
-    return cg_solve_jacobi_t<long long>(a, rp, ci, nnz, m, x, y, uniform_rows, srank, ns, iters_out, rr_out);
+    static int hint = 0;          // iteration count of the previous solve of X (batch sizing only)
+    return cg_solve_jacobi_t<long long>(a, rp, ci, nnz, m, x, y, uniform_rows, srank, ns, iters_out, rr_out, &hint);
 }
 
 extern "C" int dkmc_solve_sparse_CG_Jacobi(double *A, const int *rp, const int *ci, int nnz, int m, double *x, double *y,

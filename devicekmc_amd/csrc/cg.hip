@@ -57,6 +57,18 @@ __device__ __forceinline__ double reduce_partials(const double *part, int n, dou
     return block_sum_all<CG_NT>(s, red);
 }
 
+// same, fetching the stop flag in the same barrier round (saves one dependent global load + barrier per kernel)
+__device__ __forceinline__ double reduce_partials_and_flag(const double *part, int n, double *red, const CgCtrl *ctrl, bool *done)
+{
+    __shared__ int sdone;
+    if (threadIdx.x == 0) sdone = ctrl->done;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += CG_NT) s += part[i];
+    s = block_sum_all<CG_NT>(s, red);          // its barriers also publish sdone
+    *done = sdone != 0;
+    return s;
+}
+
 // One group of LPR lanes per row.  rows == nullptr: identity row list.
 template <int LPR, int MODE, typename RP>
 __global__ __launch_bounds__(CG_NT) void k_spmv(int nrows, const int *__restrict__ rows, const RP *__restrict__ rp,
@@ -200,8 +212,9 @@ __global__ __launch_bounds__(CG_NT) void k_cg_update(int m, int it, const double
                                                      double *__restrict__ part_rr, const CgCtrl *ctrl)
 {
     __shared__ double red[CG_NT / 64];
-    if (cg_done(ctrl)) return;
-    const double pAp = reduce_partials(part_pAp, npart, red);
+    bool done;
+    const double pAp = reduce_partials_and_flag(part_pAp, npart, red, ctrl, &done);
+    if (done) return;
     const double alpha = ctrl->rr[it & 1] / pAp;
     double acc = 0.0;
     for (int i = blockIdx.x * CG_NT + threadIdx.x; i < m; i += gridDim.x * CG_NT) {
@@ -220,8 +233,9 @@ __global__ __launch_bounds__(CG_NT) void k_cg_direction(int m, int it, const dou
                                                         CgCtrl *ctrl, double tol2, const int *__restrict__ srank, double *__restrict__ pS)
 {
     __shared__ double red[CG_NT / 64];
-    if (cg_done(ctrl)) return;
-    const double rr_new = reduce_partials(part_rr, npart, red);
+    bool done;
+    const double rr_new = reduce_partials_and_flag(part_rr, npart, red, ctrl, &done);
+    if (done) return;
     const double beta = rr_new / ctrl->rr[it & 1];
     for (int i = blockIdx.x * CG_NT + threadIdx.x; i < m; i += gridDim.x * CG_NT) {
         const double pn = p[i] * beta - r[i];

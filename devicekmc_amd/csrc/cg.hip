@@ -506,7 +506,7 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
     static const int seg_len = getenv("DKMC_SEG_LEN") ? (atoi(getenv("DKMC_SEG_LEN")) < 2 * RUN_MIN_LEN ? 2 * RUN_MIN_LEN : atoi(getenv("DKMC_SEG_LEN"))) : SEG_LEN;
     const bool use_runs = use_runs_env && srank && n_long > 0 && ns > 0;
     RunDesc *runs = nullptr, *segs = nullptr; int *nruns = nullptr, *rem = nullptr, *nrem = nullptr, *seg_off = nullptr; double *pS = nullptr, *seg_part = nullptr;
-    int nseg = 0;
+    int nseg = 0, nseg_loc = 0, seg_lo = 0; size_t seg_chunk = 0; bool sharded = false;
     if (use_runs) {
         runs = (RunDesc *)scratch(S_CG_RUNS, ((size_t)nnz / RUN_MIN_LEN + n_long + 2) * sizeof(RunDesc));
         rem = (int *)scratch(S_CG_REM, (size_t)nnz * 4);
@@ -520,13 +520,25 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
         int rc = dkmc_exclusive_scan_i32(nruns, seg_off, n_long, seg_off + n_long); if (rc) return rc;
         HIPCHK(hipMemcpyAsync(&nseg, seg_off + n_long, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        // sharded solve (comm.hip): the segments are dealt to the ranks in equal contiguous chunks (whole 4-segment
+        // workgroups); rank r multiplies [r*chunk, (r+1)*chunk) and an in-place all-gather completes seg_part
+        if (comm_attached()) {
+            sharded = true;
+            const int nr = comm_nranks();
+            seg_chunk = (size_t)(((nseg + nr - 1) / nr + 3) & ~3);
+            const long long lo = (long long)comm_rank() * (long long)seg_chunk;
+            seg_lo = (int)(lo < nseg ? lo : nseg);
+            nseg_loc = (int)((long long)nseg - seg_lo < (long long)seg_chunk ? nseg - seg_lo : seg_chunk);
+            e.stats.comm_ranks = nr; e.stats.comm_local_segments = nseg_loc; e.stats.comm_count_per_rank = (long long)seg_chunk;
+        } else { nseg_loc = nseg; e.stats.comm_ranks = 0; }
+        e.stats.spmv_segments = nseg;
         segs = (RunDesc *)scratch(S_CG_SEGS, (size_t)(nseg + 1) * sizeof(RunDesc));
-        seg_part = (double *)scratch(S_CG_SEGPART, (size_t)(nseg + 1) * 8);
+        seg_part = (double *)scratch(S_CG_SEGPART, (sharded ? (size_t)comm_nranks() * seg_chunk : (size_t)nseg) * 8 + 8);
         if (!segs || !seg_part) return e.err_code;
         hipLaunchKernelGGL((k_compact_segs<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, (const RunDesc *)runs,
                            (const int *)nruns, (const int *)seg_off, segs);
     }
-    const int nsb = (nseg + SEGK_NT / 64 - 1) / (SEGK_NT / 64);       // segment blocks of k_spmv_segs
+    const int nsb = (nseg_loc + SEGK_NT / 64 - 1) / (SEGK_NT / 64);   // segment blocks of k_spmv_segs (this rank's share)
     const int hsA = (use_runs && n_short > 0) ? grid_for(n_short, SEGK_NT / 16) : 0;   // its short-row blocks
     if (use_runs) np_ap = hsA + hl2;
     // ---- Jacobi scaling ----
@@ -540,10 +552,10 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
 
     // ---- optional kernel profile: HIP events around every A*p launch (bench.py roofline) ----
     const bool prof = e.profiling && !uniform_rows;
-    static hipEvent_t evs[3 * 64]; static bool evs_ready = false;
-    double prof_short_ms = 0.0, prof_long_ms = 0.0; int prof_short_n = 0, prof_long_n = 0;
+    static hipEvent_t evs[3 * 64], evc[64 / PROF_STRIDE]; static bool evs_ready = false;
+    double prof_short_ms = 0.0, prof_long_ms = 0.0, prof_comm_ms = 0.0; int prof_short_n = 0, prof_long_n = 0, prof_comm_n = 0;
     if (prof) {
-        if (!evs_ready) { for (auto &ev : evs) HIPCHK(hipEventCreate(&ev)); evs_ready = true; }
+        if (!evs_ready) { for (auto &ev : evs) HIPCHK(hipEventCreate(&ev)); for (auto &ev : evc) HIPCHK(hipEventCreate(&ev)); evs_ready = true; }
         std::vector<RP> hrp((size_t)m + 1);
         HIPCHK(hipMemcpy(hrp.data(), rp, ((size_t)m + 1) * sizeof(RP), hipMemcpyDeviceToHost));
         long long nl = 0, nsh = 0;
@@ -566,8 +578,9 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
     static const int spmv_var = getenv("DKMC_SPMV_VAR") ? atoi(getenv("DKMC_SPMV_VAR")) : 0;   // experiments only
     static const int seg_unr = getenv("DKMC_SEG_UNR") ? atoi(getenv("DKMC_SEG_UNR")) : 4;
     // matrix stream: default cache policy while the values of one sweep fit the 256 MiB Infinity Cache (they are re-read
-    // every iteration), non-temporal beyond that (measured: 45 vs 53 us at 240 MB, 478 vs 456 us at 1.86 GB)
-    const int seg_nt = (spmv_var == 3) ? 1 : (spmv_var == 2) ? 0 : (nnz * 8 > (300ll << 20));
+    // every iteration), non-temporal beyond that (measured: 45 vs 53 us at 240 MB, 478 vs 456 us at 1.86 GB); a rank of a
+    // sharded solve streams only its share
+    const int seg_nt = (spmv_var == 3) ? 1 : (spmv_var == 2) ? 0 : (nnz * 8 / (sharded ? comm_nranks() : 1) > (300ll << 20));
     CgCtrl h{};
     for (;;) {
         HIPCHK(hipMemcpyAsync(&h, ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
@@ -578,7 +591,8 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
                 float ms = 0.f;
                 if (use_runs) {
                     HIPCHK(hipEventElapsedTime(&ms, evs[3 * b], evs[3 * b + 1])); prof_long_ms += ms; ++prof_long_n;
-                    HIPCHK(hipEventElapsedTime(&ms, evs[3 * b + 1], evs[3 * b + 2])); prof_short_ms += ms; ++prof_short_n;
+                    if (sharded) { HIPCHK(hipEventElapsedTime(&ms, evs[3 * b + 1], evc[b / PROF_STRIDE])); prof_comm_ms += ms; ++prof_comm_n; }
+                    HIPCHK(hipEventElapsedTime(&ms, sharded ? evc[b / PROF_STRIDE] : evs[3 * b + 1], evs[3 * b + 2])); prof_short_ms += ms; ++prof_short_n;
                 } else { HIPCHK(hipEventElapsedTime(&ms, evs[3 * b], evs[3 * b + 2])); prof_long_ms += ms; ++prof_long_n; }
             }
         }
@@ -590,14 +604,20 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
 #define AP_ARGS(vec) n_short, short_rows, hs, n_long, long_rows, rp, ci, (const double *)a, (const double *)p, t, part_pAp, ctrl, \
                 (const RunDesc *)runs, (const int *)nruns, (const int *)rem, (const int *)nrem, (const double *)(vec), (const int *)seg_off
             if (use_runs) {
-#define SEG_ARGS nseg, (const RunDesc *)segs, (const double *)a, (const double *)pS, seg_part, ctrl, (const int *)rem, ci, (const double *)p, \
-                 nsb, n_short, short_rows, rp, long_rows, t, part_pAp
+#define SEG_ARGS nseg_loc, (const RunDesc *)segs + seg_lo, (const double *)a, (const double *)pS, seg_part + seg_lo, ctrl, (const int *)rem, ci, \
+                 (const double *)p, nsb, n_short, short_rows, rp, long_rows, t, part_pAp
                 if (seg_nt && seg_unr == 8) hipLaunchKernelGGL((k_spmv_segs<1, RP, 8>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, SEG_ARGS);
                 else if (seg_nt) hipLaunchKernelGGL((k_spmv_segs<1, RP, 4>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, SEG_ARGS);
                 else if (seg_unr == 8) hipLaunchKernelGGL((k_spmv_segs<0, RP, 8>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, SEG_ARGS);
                 else hipLaunchKernelGGL((k_spmv_segs<0, RP, 4>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, SEG_ARGS);
 #undef SEG_ARGS
                 if (pb) HIPCHK(hipEventRecord(evs[3 * b + 1], st));
+                if (sharded) {
+                    // the exchange step: every rank enqueues exactly the same sequence of collectives (the batch plan and
+                    // the stop decisions depend only on values that are identical on all ranks)
+                    if (int rc = comm_allgather_f64(seg_part, seg_chunk)) return rc;
+                    if (pb) HIPCHK(hipEventRecord(evc[b / PROF_STRIDE], st));
+                }
                 hipLaunchKernelGGL((k_spmv_ap<0, 1, RP>), dim3(hl2), dim3(SPMV_NT), 0, st, 0, short_rows, 0, n_long, long_rows, rp, ci, (const double *)a,
                                    (const double *)p, t, part_pAp + hsA, ctrl, (const RunDesc *)runs, (const int *)nruns, (const int *)rem,
                                    (const int *)nrem, (const double *)seg_part, (const int *)seg_off);
@@ -617,6 +637,7 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
     if (prof) {
         e.stats.spmv_long_ms = prof_long_ms; e.stats.spmv_short_ms = prof_short_ms;
         e.stats.spmv_long_launches = prof_long_n; e.stats.spmv_short_launches = prof_short_n;
+        e.stats.comm_ms = prof_comm_ms; e.stats.comm_launches = prof_comm_n;
     }
     // ---- un-scale the solution (:459) ----
     hipLaunchKernelGGL(k_vec_mul, dim3(gv), dim3(CG_NT), 0, st, m, y, s);
@@ -636,8 +657,9 @@ int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, dou
 int cg_solve_jacobi64(double *a, const long long *rp, const int *ci, long long nnz, int m, double *x, double *y,
                       int uniform_rows, const int *srank, int ns, int *iters_out, double *rr_out)
 {
-    static int hint = 0;          // iteration count of the previous solve of X (batch sizing only)
-    return cg_solve_jacobi_t<long long>(a, rp, ci, nnz, m, x, y, uniform_rows, srank, ns, iters_out, rr_out, &hint);
+    // batch sizing from the iteration count of the previous solve of X; the hint lives in the engine because attaching a
+    // communicator resets it (the batch plan must be identical on all ranks of a sharded solve)
+    return cg_solve_jacobi_t<long long>(a, rp, ci, nnz, m, x, y, uniform_rows, srank, ns, iters_out, rr_out, &eng().x_iter_hint);
 }
 
 extern "C" int dkmc_solve_sparse_CG_Jacobi(double *A, const int *rp, const int *ci, int nnz, int m, double *x, double *y,

@@ -103,6 +103,7 @@ struct Engine {
     double cg_tol = 1e-6;
     int current_warm_start = 0;
     int profiling = 0;
+    int x_iter_hint = 0;           // iteration count of the previous CG solve of X (sizes the first launch batch)
     dkmc_stats stats{};
     char err[512] = {0};
     int err_code = 0;
@@ -136,6 +137,12 @@ enum {
     S_P_IMACRO, S_HEAT,
     S_MISC0, S_MISC1, S_MISC2, S_MISC3
 };
+
+// exchange step of the sharded current solve (comm.hip)
+int comm_attached();
+int comm_nranks();
+int comm_rank();
+int comm_allgather_f64(double *buf, size_t count);     // in place on the engine's stream; rank r owns buf[r*count, (r+1)*count)
 
 // shared primitives (scan.hip)
 // exclusive prefix sum of n ints (in -> out, out may alias in); total written to d_total (device int) if non-null

@@ -34,7 +34,12 @@ class dkmc_stats(C.Structure):
                 ("spmv_long_launches", C.c_int), ("spmv_short_launches", C.c_int),
                 ("spmv_long_nnz", C.c_longlong), ("spmv_short_nnz", C.c_longlong),
                 ("spmv_long_rows", C.c_int), ("spmv_short_rows", C.c_int),
-                ("spmv_segments", C.c_int), ("spmv_pad", C.c_int), ("spmv_segment_entries", C.c_longlong)]
+                ("spmv_segments", C.c_int), ("spmv_pad", C.c_int), ("spmv_segment_entries", C.c_longlong),
+                ("comm_ranks", C.c_int), ("comm_local_segments", C.c_int), ("comm_count_per_rank", C.c_longlong),
+                ("comm_ms", C.c_double), ("comm_launches", C.c_int), ("comm_pad", C.c_int)]
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
 
 
 # every symbol include/devicekmc_hip.h declares: name -> (restype, argtypes)
@@ -73,6 +78,12 @@ SYMBOLS = {
     "dkmc_get_last_X": (_I, [c_int_p, C.POINTER(C.c_longlong), vp, vp, vp]),
     "dkmc_update_temperatureglobal_gpu": (_I, [vp, vp, _I, _D, _D, _D, _D, _D]),
     "dkmc_update_temperature_global_analytic": (_I, [vp, vp, _I, _D, _D, _D, _D, _D, c_dbl_p]),
+    "dkmc_comm_unique_id": (_I, [C.c_char_p]),
+    "dkmc_comm_init_rccl": (_I, [_I, _I, C.c_char_p]),
+    "dkmc_comm_init_host": (_I, [_I, _I, ALLGATHER_FN, vp]),
+    "dkmc_comm_allgather_host": (_I, [vp, C.c_size_t]),
+    "dkmc_comm_info": (_I, [C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "dkmc_comm_destroy": (_I, []),
 }
 
 _lib = None

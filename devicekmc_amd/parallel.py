@@ -1,8 +1,13 @@
 """Multi-GPU layout of the benchmark: one process per GPU, launched by torch.distributed.run.
 
-The reference is single-GPU and this round shards nothing inside a superstep ("replicas only",
-DESIGN.md section 7): every rank advances an independent replica of the workload that differs only in its KMC
-random stream.  The only collective is the max-over-ranks of the timed region (RCCL on GPUs, gloo in the CPU tests).
+The reference is single-GPU.  Two ways to use N GPUs:
+
+* replicas (weak scaling, the default of bench.py): every rank advances an independent replica of the workload that
+  differs only in its KMC random stream; the only collective is the max-over-ranks of the timed region.
+* sharded solve (strong scaling): all ranks advance the SAME simulation in lockstep and the segment stage of the
+  current solve's A*p is dealt to the ranks, completed by one all-gather per CG iteration inside the library
+  (csrc/comm.hip).  `attach_solver_comm` creates that communicator: RCCL over xGMI when the process group is nccl,
+  the host-callback transport over gloo otherwise (rehearsal with several ranks on one GPU, CPU tests).
 """
 import os
 
@@ -50,6 +55,68 @@ def max_over_ranks(seconds: float, device="cpu") -> float:
 def aggregate_rate(steps_per_rank: int, world: int, elapsed_max: float) -> float:
     """Whole-job throughput: every replica completed steps_per_rank steps within the slowest rank's time."""
     return world * steps_per_rank / elapsed_max
+
+
+_solver_cb = None      # keeps the ctypes callback object alive while the library holds its address
+
+
+def _gloo_allgather_cb(group):
+    """dkmc_allgather_fn over a torch.distributed group with CPU tensors: all-gathers the pinned host buffer in place."""
+    import ctypes
+    import numpy as np
+    from . import lib
+
+    def cb(host_buf, bytes_per_rank, rank, nranks, _user):
+        try:
+            n = bytes_per_rank // 8
+            arr = np.ctypeslib.as_array(ctypes.cast(host_buf, ctypes.POINTER(ctypes.c_double)), shape=(nranks * n,))
+            full = torch.from_numpy(arr)
+            chunks = [full[r * n:(r + 1) * n] for r in range(nranks)]
+            dist.all_gather(chunks, chunks[rank].clone(), group=group)
+            return 0
+        except Exception as exc:              # an exception must not unwind through the C caller
+            print("devicekmc_amd.parallel: all-gather callback failed: %r" % (exc,), flush=True)
+            return 1
+    return lib.ALLGATHER_FN(cb)
+
+
+def attach_solver_comm(transport=None, group=None):
+    """Attach the current-solve communicator of this rank (call after the device has been selected, on every rank).
+    transport: "rccl", "host", or None = rccl if the default process group is nccl, host otherwise.
+    A world of one attaches nothing unless a transport is named explicitly (tests of the 1-rank RCCL path)."""
+    global _solver_cb
+    from . import lib
+    L = lib.load()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if transport is None:
+        if world == 1:
+            return "none"
+        transport = "rccl" if dist.get_backend(group) == "nccl" else "host"
+    if transport == "rccl":
+        import ctypes
+        idbuf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            lib.check(L.dkmc_comm_unique_id(idbuf))
+        if world > 1:
+            dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+            t = torch.frombuffer(bytearray(idbuf.raw), dtype=torch.uint8).to(dev)
+            dist.broadcast(t, src=0, group=group)
+            idbuf = ctypes.create_string_buffer(bytes(t.cpu().numpy().tobytes()), 128)
+        lib.check(L.dkmc_comm_init_rccl(world, rank, idbuf))
+    elif transport == "host":
+        _solver_cb = _gloo_allgather_cb(group) if world > 1 else lib.ALLGATHER_FN(lambda *a: 0)
+        lib.check(L.dkmc_comm_init_host(world, rank, _solver_cb, None))
+    else:
+        raise ValueError("unknown transport %r" % (transport,))
+    return transport
+
+
+def detach_solver_comm():
+    global _solver_cb
+    from . import lib
+    lib.check(lib.load().dkmc_comm_destroy())
+    _solver_cb = None
 
 
 def finalize():

@@ -66,6 +66,12 @@ typedef struct dkmc_stats {
      * spmv_short_ms the row kernel that follows it) */
     int spmv_segments, spmv_pad;
     long long spmv_segment_entries;
+    /* sharded current solve (dkmc_comm_*): ranks, the segments this rank multiplied in the last solve, doubles exchanged per
+     * all-gather, and (profiling on) the HIP-event time of the sampled all-gathers */
+    int comm_ranks, comm_local_segments;
+    long long comm_count_per_rank;
+    double comm_ms;
+    int comm_launches, comm_pad;
 } dkmc_stats;
 
 const char *dkmc_last_error(void);
@@ -186,6 +192,23 @@ int dkmc_update_temperatureglobal_gpu(const double *d_site_power, double *d_T_bg
 int dkmc_update_temperature_global_analytic(const double *d_site_power, double *d_T_bg, int N, double event_time,
                                             double dissipation_constant, double t_ox, double A, double c_p,
                                             double *h_P_tot);
+
+/* ---- multi-GPU: one simulation advanced in lockstep by N processes, one GPU each (no reference counterpart) ----
+ * While a communicator is attached, update_power_gpu_sparse deals the segment stage of A*p of its CG solve to the ranks
+ * and completes the per-segment partial sums with ONE in-place all-gather per iteration; every other phase is computed
+ * redundantly and identically on every rank, so all ranks hold the same state after every call and the result is
+ * bit-identical to the single-GPU one.  Every rank must make the same sequence of calls with the same inputs.
+ * Transports: RCCL over xGMI (unique id from rank 0, distributed by the caller), or a host callback that all-gathers a
+ * pinned host buffer in place (rehearsal on machines where the ranks share a GPU, which RCCL refuses). */
+enum { DKMC_COMM_NONE = 0, DKMC_COMM_RCCL = 1, DKMC_COMM_HOST = 2 };
+/* host_buf holds nranks chunks of bytes_per_rank bytes, the caller's own chunk (index rank) filled in; on return all are */
+typedef int (*dkmc_allgather_fn)(void *host_buf, size_t bytes_per_rank, int rank, int nranks, void *user);
+int dkmc_comm_unique_id(char *id128);                                   /* ncclGetUniqueId; 128 bytes out */
+int dkmc_comm_init_rccl(int nranks, int rank, const char *id128);       /* after dkmc_set_gpu / dkmc_set_stream */
+int dkmc_comm_init_host(int nranks, int rank, dkmc_allgather_fn fn, void *user);
+int dkmc_comm_allgather_host(double *host_buf, size_t count_per_rank);  /* the callback transport's host half (no GPU needed) */
+int dkmc_comm_info(int *nranks, int *rank, int *transport);
+int dkmc_comm_destroy(void);
 
 #ifdef __cplusplus
 }

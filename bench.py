@@ -13,9 +13,13 @@ Workloads (config.workload):
   tile:K  the 2.5 nm cell tiled K x K laterally, e.g. tile:3 = 84 591 sites
 
 Contract: python bench.py --gpus N --steps K --warmup W ; prints ONE JSON line on rank 0.
-N > 1 (launched with torch.distributed.run): the reference has no multi-GPU path and this round shards nothing:
-every rank runs an independent replica of the workload on its own GPU ("replicas only"); value is the
-aggregate steps/s over all replicas.
+N > 1 (launched with torch.distributed.run; the reference has no multi-GPU path): `value` is measured in replica mode --
+every rank runs an independent replica of the workload (own KMC random stream) on its own GPU, value = aggregate
+steps/s, "scaling": "weak".  The same run then measures the sharded current solve (csrc/comm.hip: all ranks advance ONE
+simulation in lockstep, the segment stage of A*p is dealt to the ranks, one RCCL all-gather per CG iteration) on the
+default workload and on a larger one, against the single-GPU time of the same steps, and checks bit-identity; that goes
+into the extra "sharded_solve" block (strong scaling, never `value`).  A watchdog prints the line without that block if
+the sharded part does not finish in time.
 """
 import argparse
 import json
@@ -58,6 +62,10 @@ def main():
     ap.add_argument("--workload", default="7.5nm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--warm-start", type=int, default=0, help="dkmc_set_current_warm_start mode (0 = reference)")
+    ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the sharded-solve block")
+    ap.add_argument("--sharded-workloads", default=None, help="comma list; default: the main workload and tile:5")
+    ap.add_argument("--sharded-steps", type=int, default=2)
+    ap.add_argument("--sharded-timeout", type=float, default=420.0, help="watchdog for the sharded-solve block [s]")
     args = ap.parse_args()
 
     import numpy as np
@@ -210,6 +218,7 @@ def main():
                "ms_per_step": round(tc * 1e3, 1),
                "split_ms": {k: round(v * 1e3, 2) for k, v in o.timing.items()}}
 
+    out = None
     if rank == 0:
         n = args.steps
         out = {
@@ -225,8 +234,114 @@ def main():
                          "K_rows": int(s.N - 2 * p.num_atoms_first_layer), "K_nnz": int(gb.c.Device_nnz)},
             "roofline": roof, "cpu_baseline": cpu, "alt_warm_start": alt,
         }
-        print(json.dumps(out))
+
+    # ---- the one JSON line; printed exactly once, by the normal path or by the watchdog of the sharded block ----
+    import threading
+    emit_lock = threading.Lock()
+    emitted = []
+
+    def emit(extra):
+        with emit_lock:
+            if emitted:
+                return
+            emitted.append(1)
+            if rank == 0:
+                if extra is not None:
+                    out["sharded_solve"] = extra
+                print(json.dumps(out), flush=True)
+
+    if world > 1 and not args.no_sharded:
+        def on_timeout():
+            emit({"error": "sharded-solve block did not finish within %.0f s" % args.sharded_timeout})
+            os._exit(0)             # a rank stuck in a collective cannot be unwound
+        wd = threading.Timer(args.sharded_timeout, on_timeout); wd.daemon = True; wd.start()
+        try:
+            del gb, sim, dev
+            torch.cuda.empty_cache()
+            names = args.sharded_workloads.split(",") if args.sharded_workloads else [args.workload, "tile:5"]
+            extra = sharded_block(names, args.sharded_steps, devname, backend, rank, world)
+        except Exception as exc:         # the replica measurement above stays valid
+            extra = {"error": repr(exc)[:300]}
+        wd.cancel()
+        emit(extra)
+    else:
+        emit(None)
     parallel.finalize()
+
+
+def lockstep_run(name, nsteps, devname, Vd=5.0):
+    """nsteps supersteps of workload `name` from a fresh state with the reference seeds (identical on every rank);
+    returns (seconds for the steps after the first, trace, stats of the last step).  The first step is untimed: it fills the
+    tunnelling-coefficient cache and sizes the scratch buffers."""
+    import torch
+    from devicekmc_amd import host, lib
+    L = lib.load()
+    s, p = make_workload(name)
+    dev = host.Device(s, p, gpu_neighbors=devname)
+    sim = host.KMCProcess(dev, p.freq)
+    gb = dev.make_gpubuf(devname)
+    L.dkmc_set_current_warm_start(0)
+    dev.setLaplacePotential(gb, p, Vd)
+    gb.sync_HostToGPU(dev)
+    trace, iters = [], 0
+    t0 = None
+    L.dkmc_set_profiling(1)
+    for k in range(nsteps + 1):
+        if k == 1:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+        dev.updateCharge(gb); dev.updatePotential(gb, p, Vd, k)
+        _, dt = sim.executeKMCStep(gb, dev)
+        dev.updatePower(gb, p, Vd); dev.updateTemperature(gb, p, dt)
+        trace.append((dt, dev.imacro, dev.T_bg))
+        if k >= 1:
+            iters += host.get_stats()["cg_iters_X"]
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    L.dkmc_set_profiling(0)
+    st = dict(host.get_stats())
+    st["cg_iters_X_per_step"] = iters / nsteps
+    st["sites"] = int(s.N)
+    del gb, sim, dev
+    torch.cuda.empty_cache()
+    return el, trace, st
+
+
+def sharded_block(names, nsteps, devname, backend, rank, world):
+    """Strong scaling of one simulation over the ranks: single-GPU time (every rank runs it, slowest counts) against the
+    lockstep run with the sharded current solve, same steps, same seeds; bit-identity of (dt, I_macro, T_bg) checked."""
+    import torch
+    import torch.distributed as dist
+    from devicekmc_amd import parallel
+    red_dev = devname if backend == "nccl" else "cpu"
+    res = {"ranks": world, "steps": nsteps, "workloads": {}}
+    for name in names:
+        parallel.barrier()
+        t_single, trace_single, st1 = lockstep_run(name, nsteps, devname)
+        t_single = parallel.max_over_ranks(t_single, red_dev)
+        parallel.barrier()
+        res["transport"] = parallel.attach_solver_comm()
+        try:
+            parallel.barrier()
+            t_shard, trace_shard, st2 = lockstep_run(name, nsteps, devname)
+        finally:
+            parallel.detach_solver_comm()
+        t_shard = parallel.max_over_ranks(t_shard, red_dev)
+        same_here = 1.0 if trace_shard == trace_single else 0.0
+        flag = torch.tensor([same_here], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        traces = [None] * world
+        dist.all_gather_object(traces, trace_shard)
+        res["workloads"][name] = {
+            "sites": st1["sites"], "X_nnz": int(st1["X_nnz"]), "cg_iters_X": st1["cg_iters_X_per_step"],
+            "single_gpu_ms_per_step": round(t_single / nsteps * 1e3, 3), "sharded_ms_per_step": round(t_shard / nsteps * 1e3, 3),
+            "speedup": round(t_single / t_shard, 3),
+            "bit_identical_to_single_gpu": bool(flag.item() == 1.0), "ranks_agree": all(t == traces[0] for t in traces),
+            "segments": int(st2["spmv_segments"]), "allgather_doubles_per_rank": int(st2["comm_count_per_rank"]),
+            "allgather_us": round(st2["comm_ms"] / max(st2["comm_launches"], 1) * 1e3, 2),
+            "segment_kernel_us": round(st2["spmv_long_ms"] / max(st2["spmv_long_launches"], 1) * 1e3, 2),
+            "single_gpu_segment_kernel_us": round(st1["spmv_long_ms"] / max(st1["spmv_long_launches"], 1) * 1e3, 2),
+        }
+    return res
 
 
 if __name__ == "__main__":

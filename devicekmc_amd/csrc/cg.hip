@@ -18,6 +18,7 @@
 // matrix part of X drops to 8 B per entry.
 #include "common.h"
 #include <vector>
+#include <algorithm>
 #include <stdlib.h>
 
 #define CG_NT 256
@@ -191,6 +192,55 @@ __global__ __launch_bounds__(SPMV_NT) void k_spmv_ap(int n_short, const int *__r
             double s = (s0 + s1) + (s2 + s3);
             s = wave_sum(s);
             if (lane == 0) { t[row] = s; acc += p[row] * s; }
+        }
+    }
+    const double tot = block_sum_all<SPMV_NT>(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// ---- sharded solve (comm.hip): stage 2 of the long-row product split around the exchange step ---------------------------
+// The long rows are dealt to the ranks at row boundaries (balanced by segment count).  k_rowsum_owner adds the segment
+// partials of the rows this rank owns -- the same 16-lane arithmetic as the fused stage 2 above -- into its chunk of the
+// exchange buffer; after the all-gather k_rowsum_apply, with the fused kernel's launch shape and thread-to-row mapping,
+// stores t and forms the p.t partials.  Values and summation order are those of the single-GPU kernel: bit-identical.
+#define MAX_RANKS 64
+struct RowParts { int n; int chunk; int lo[MAX_RANKS + 1]; };      // rank r owns long rows [lo[r], lo[r+1]); chunk = slots per rank
+
+__global__ __launch_bounds__(SPMV_NT) void k_rowsum_owner(int row_lo, int row_hi, const int *__restrict__ nruns, const int *__restrict__ seg_off,
+                                                          const double *__restrict__ seg_part, double *__restrict__ mine, const CgCtrl *ctrl)
+{
+    if (ctrl->done) return;
+    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+    for (int ridx = row_lo + blockIdx.x * (SPMV_NT / 16) + g; ridx < row_hi; ridx += gridDim.x * (SPMV_NT / 16)) {
+        double s = 0.0;
+        const int nsg = nruns[ridx];
+        const double *sp = seg_part + seg_off[ridx];
+        for (int j = l; j < nsg; j += 16) s += sp[j];
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+        if (l == 0) mine[ridx - row_lo] = s;
+    }
+}
+
+__global__ __launch_bounds__(SPMV_NT) void k_rowsum_apply(int n_long, const int *__restrict__ long_rows, const RowParts *__restrict__ rp_, const double *__restrict__ gathered,
+                                                          const double *__restrict__ p, double *__restrict__ t, double *__restrict__ part,
+                                                          const CgCtrl *ctrl)
+{
+    __shared__ double red[SPMV_NT / 64];
+    __shared__ int sdone;
+    if (threadIdx.x == 0) sdone = ctrl->done;
+    __syncthreads();
+    if (sdone) return;
+    double acc = 0.0;
+    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+    for (int ridx = blockIdx.x * (SPMV_NT / 16) + g; ridx < n_long; ridx += gridDim.x * (SPMV_NT / 16)) {
+        if (l == 0) {
+            int r = 0;
+            const int nr = rp_->n;
+            while (r + 1 < nr && ridx >= rp_->lo[r + 1]) ++r;
+            const double s = gathered[(size_t)r * rp_->chunk + (ridx - rp_->lo[r])];
+            const int row = long_rows[ridx];
+            t[row] = s; acc += p[row] * s;
         }
     }
     const double tot = block_sum_all<SPMV_NT>(acc, red);
@@ -506,7 +556,7 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
     static const int seg_len = getenv("DKMC_SEG_LEN") ? (atoi(getenv("DKMC_SEG_LEN")) < 2 * RUN_MIN_LEN ? 2 * RUN_MIN_LEN : atoi(getenv("DKMC_SEG_LEN"))) : SEG_LEN;
     const bool use_runs = use_runs_env && srank && n_long > 0 && ns > 0;
     RunDesc *runs = nullptr, *segs = nullptr; int *nruns = nullptr, *rem = nullptr, *nrem = nullptr, *seg_off = nullptr; double *pS = nullptr, *seg_part = nullptr;
-    int nseg = 0, nseg_loc = 0, seg_lo = 0; size_t seg_chunk = 0; bool sharded = false;
+    int nseg = 0, nseg_loc = 0, seg_lo = 0; bool sharded = false; RowParts parts{}, *dparts = nullptr; double *xbuf = nullptr;
     if (use_runs) {
         runs = (RunDesc *)scratch(S_CG_RUNS, ((size_t)nnz / RUN_MIN_LEN + n_long + 2) * sizeof(RunDesc));
         rem = (int *)scratch(S_CG_REM, (size_t)nnz * 4);
@@ -520,20 +570,33 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
         int rc = dkmc_exclusive_scan_i32(nruns, seg_off, n_long, seg_off + n_long); if (rc) return rc;
         HIPCHK(hipMemcpyAsync(&nseg, seg_off + n_long, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        // sharded solve (comm.hip): the segments are dealt to the ranks in equal contiguous chunks (whole 4-segment
-        // workgroups); rank r multiplies [r*chunk, (r+1)*chunk) and an in-place all-gather completes seg_part
+        // sharded solve (comm.hip): the long rows are dealt to the ranks at row boundaries, balanced by segment count; a
+        // rank multiplies the segments of its rows and sums them per row; the row sums are what is exchanged
         if (comm_attached()) {
             sharded = true;
-            const int nr = comm_nranks();
-            seg_chunk = (size_t)(((nseg + nr - 1) / nr + 3) & ~3);
-            const long long lo = (long long)comm_rank() * (long long)seg_chunk;
-            seg_lo = (int)(lo < nseg ? lo : nseg);
-            nseg_loc = (int)((long long)nseg - seg_lo < (long long)seg_chunk ? nseg - seg_lo : seg_chunk);
-            e.stats.comm_ranks = nr; e.stats.comm_local_segments = nseg_loc; e.stats.comm_count_per_rank = (long long)seg_chunk;
+            const int nr = comm_nranks(), me = comm_rank();
+            if (nr > MAX_RANKS) return dkmc_fail(46, "CG: more ranks than MAX_RANKS", __FILE__, __LINE__);
+            std::vector<int> hoff((size_t)n_long + 1);
+            HIPCHK(hipMemcpy(hoff.data(), seg_off, ((size_t)n_long + 1) * 4, hipMemcpyDeviceToHost));
+            parts.n = nr; parts.lo[0] = 0;
+            for (int r = 1; r < nr; ++r) {           // first row whose segments start at or beyond r/nr of the total
+                const long long want = (long long)nseg * r / nr;
+                parts.lo[r] = (int)(std::lower_bound(hoff.begin(), hoff.begin() + n_long, (int)want) - hoff.begin());
+            }
+            parts.lo[nr] = n_long;
+            int mx = 0; for (int r = 0; r < nr; ++r) mx = std::max(mx, parts.lo[r + 1] - parts.lo[r]);
+            parts.chunk = (mx + 1) & ~1;
+            if (parts.chunk == 0) parts.chunk = 2;
+            seg_lo = hoff[parts.lo[me]]; nseg_loc = hoff[parts.lo[me + 1]] - seg_lo;
+            xbuf = (double *)scratch(S_CG_XCHG, (size_t)nr * parts.chunk * 8);
+            dparts = (RowParts *)scratch(S_CG_PARTS, sizeof(RowParts));
+            if (!xbuf || !dparts) return e.err_code;
+            HIPCHK(hipMemcpy(dparts, &parts, sizeof(RowParts), hipMemcpyHostToDevice));
+            e.stats.comm_ranks = nr; e.stats.comm_local_segments = nseg_loc; e.stats.comm_count_per_rank = parts.chunk;
         } else { nseg_loc = nseg; e.stats.comm_ranks = 0; }
         e.stats.spmv_segments = nseg;
         segs = (RunDesc *)scratch(S_CG_SEGS, (size_t)(nseg + 1) * sizeof(RunDesc));
-        seg_part = (double *)scratch(S_CG_SEGPART, (sharded ? (size_t)comm_nranks() * seg_chunk : (size_t)nseg) * 8 + 8);
+        seg_part = (double *)scratch(S_CG_SEGPART, (size_t)(nseg + 1) * 8);
         if (!segs || !seg_part) return e.err_code;
         hipLaunchKernelGGL((k_compact_segs<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, (const RunDesc *)runs,
                            (const int *)nruns, (const int *)seg_off, segs);
@@ -613,11 +676,17 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
 #undef SEG_ARGS
                 if (pb) HIPCHK(hipEventRecord(evs[3 * b + 1], st));
                 if (sharded) {
-                    // the exchange step: every rank enqueues exactly the same sequence of collectives (the batch plan and
-                    // the stop decisions depend only on values that are identical on all ranks)
-                    if (int rc = comm_allgather_f64(seg_part, seg_chunk)) return rc;
+                    // row sums of the owned rows -> exchange step -> t and the p.t partials on every rank.  Every rank enqueues
+                    // exactly the same sequence of collectives (the batch plan and the stop decisions depend only on values
+                    // that are identical on all ranks).
+                    const int me = comm_rank(), r0 = parts.lo[me], r1 = parts.lo[me + 1];
+                    if (r1 > r0) hipLaunchKernelGGL(k_rowsum_owner, dim3(grid_for(r1 - r0, SPMV_NT / 16)), dim3(SPMV_NT), 0, st, r0, r1, (const int *)nruns,
+                                                    (const int *)seg_off, (const double *)seg_part, xbuf + (size_t)me * parts.chunk, ctrl);
+                    if (int rc = comm_allgather_f64(xbuf, (size_t)parts.chunk)) return rc;
                     if (pb) HIPCHK(hipEventRecord(evc[b / PROF_STRIDE], st));
-                }
+                    hipLaunchKernelGGL(k_rowsum_apply, dim3(hl2), dim3(SPMV_NT), 0, st, n_long, long_rows, (const RowParts *)dparts, (const double *)xbuf, (const double *)p, t,
+                                       part_pAp + hsA, ctrl);
+                } else
                 hipLaunchKernelGGL((k_spmv_ap<0, 1, RP>), dim3(hl2), dim3(SPMV_NT), 0, st, 0, short_rows, 0, n_long, long_rows, rp, ci, (const double *)a,
                                    (const double *)p, t, part_pAp + hsA, ctrl, (const RunDesc *)runs, (const int *)nruns, (const int *)rem,
                                    (const int *)nrem, (const double *)seg_part, (const int *)seg_off);

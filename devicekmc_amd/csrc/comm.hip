@@ -2,10 +2,10 @@
 //
 // The reference is single-GPU.  Here N processes (one per GPU) advance the SAME simulation in lockstep; every phase is
 // computed redundantly and identically on every rank except the dominant one, the segment stage of A*p in the CG solve of
-// X (cg.hip, k_spmv_segs), whose work items are dealt to the ranks in equal contiguous chunks.  After that stage each rank
-// holds its chunk of the per-segment partial sums; one in-place all-gather per CG iteration completes the array on every
-// rank, and everything downstream (row sums, dot products, vector updates, stop test) is again computed identically
-// everywhere.  Consequences: the result is bit-identical to the single-GPU result, all ranks take the same control
+// X (cg.hip, k_spmv_segs): the long (tunnelling) rows are dealt to the ranks at row boundaries, balanced by segment count.
+// A rank multiplies the segments of its rows and adds them per row; one in-place all-gather per CG iteration hands every
+// rank every row sum (8 B per long row), and everything downstream (dot products, vector updates, stop test) is again
+// computed identically everywhere.  Consequences: the result is bit-identical to the single-GPU result, all ranks take the same control
 // decisions (no rank can leave the iteration loop while another waits in the collective), and no dot-product all-reduce
 // is needed.
 //

@@ -66,8 +66,9 @@ typedef struct dkmc_stats {
      * spmv_short_ms the row kernel that follows it) */
     int spmv_segments, spmv_pad;
     long long spmv_segment_entries;
-    /* sharded current solve (dkmc_comm_*): ranks, the segments this rank multiplied in the last solve, doubles exchanged per
-     * all-gather, and (profiling on) the HIP-event time of the sampled all-gathers */
+    /* sharded current solve (dkmc_comm_*): ranks, the segments this rank multiplied in the last solve, doubles per rank in
+     * the all-gather (row sums of the owned long rows, padded to the largest share), and (profiling on) the HIP-event time
+     * of the sampled exchange steps (row-sum kernel + all-gather) */
     int comm_ranks, comm_local_segments;
     long long comm_count_per_rank;
     double comm_ms;
@@ -194,8 +195,8 @@ int dkmc_update_temperature_global_analytic(const double *d_site_power, double *
                                             double *h_P_tot);
 
 /* ---- multi-GPU: one simulation advanced in lockstep by N processes, one GPU each (no reference counterpart) ----
- * While a communicator is attached, update_power_gpu_sparse deals the segment stage of A*p of its CG solve to the ranks
- * and completes the per-segment partial sums with ONE in-place all-gather per iteration; every other phase is computed
+ * While a communicator is attached, update_power_gpu_sparse deals the long rows of A*p of its CG solve to the ranks
+ * and hands every rank every row sum with ONE in-place all-gather per iteration; every other phase is computed
  * redundantly and identically on every rank, so all ranks hold the same state after every call and the result is
  * bit-identical to the single-GPU one.  Every rank must make the same sequence of calls with the same inputs.
  * Transports: RCCL over xGMI (unique id from rank 0, distributed by the caller), or a host callback that all-gathers a

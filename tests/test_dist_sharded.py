@@ -80,10 +80,10 @@ def test_two_ranks_lockstep_bit_identical():
         assert iters == riters                                        # same CG iteration counts
         for n in rfields:
             assert np.array_equal(fields[n], rfields[n]), (rank, n)   # every field a caller can read back: bit-identical
-        assert st["comm_ranks"] == 2 and st["comm_count_per_rank"] % 4 == 0
+        assert st["comm_ranks"] == 2 and st["comm_count_per_rank"] % 2 == 0
     nseg = got0[3]["spmv_segments"]
     assert got0[3]["comm_local_segments"] + got1[3]["comm_local_segments"] == nseg > 0      # the ranks split the segments
-    assert abs(got0[3]["comm_local_segments"] - got1[3]["comm_local_segments"]) <= 8
+    assert abs(got0[3]["comm_local_segments"] - got1[3]["comm_local_segments"]) <= 64      # balanced up to one row
 
 
 def test_rccl_transport_one_rank():

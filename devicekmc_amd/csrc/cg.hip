@@ -17,6 +17,7 @@
 // HBM traffic per iteration in the CSR formulation: 12*nnz + 4*(m+1) + 96*m bytes; with the segments the
 // matrix part of X drops to 8 B per entry.
 #include "common.h"
+#include <hip/hip_ext.h>
 #include <vector>
 #include <algorithm>
 #include <stdlib.h>
@@ -615,7 +616,7 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
 
     // ---- optional kernel profile: HIP events around every A*p launch (bench.py roofline) ----
     const bool prof = e.profiling && !uniform_rows;
-    static hipEvent_t evs[3 * 64], evc[64 / PROF_STRIDE]; static bool evs_ready = false;
+    static hipEvent_t evs[4 * 64], evc[64 / PROF_STRIDE]; static bool evs_ready = false;
     double prof_short_ms = 0.0, prof_long_ms = 0.0, prof_comm_ms = 0.0; int prof_short_n = 0, prof_long_n = 0, prof_comm_n = 0;
     if (prof) {
         if (!evs_ready) { for (auto &ev : evs) HIPCHK(hipEventCreate(&ev)); for (auto &ev : evc) HIPCHK(hipEventCreate(&ev)); evs_ready = true; }
@@ -653,28 +654,27 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
                 if (it - launched + b >= h.iters) break;
                 float ms = 0.f;
                 if (use_runs) {
-                    HIPCHK(hipEventElapsedTime(&ms, evs[3 * b], evs[3 * b + 1])); prof_long_ms += ms; ++prof_long_n;
-                    if (sharded) { HIPCHK(hipEventElapsedTime(&ms, evs[3 * b + 1], evc[b / PROF_STRIDE])); prof_comm_ms += ms; ++prof_comm_n; }
-                    HIPCHK(hipEventElapsedTime(&ms, sharded ? evc[b / PROF_STRIDE] : evs[3 * b + 1], evs[3 * b + 2])); prof_short_ms += ms; ++prof_short_n;
-                } else { HIPCHK(hipEventElapsedTime(&ms, evs[3 * b], evs[3 * b + 2])); prof_long_ms += ms; ++prof_long_n; }
+                    HIPCHK(hipEventElapsedTime(&ms, evs[4 * b], evs[4 * b + 1])); prof_long_ms += ms; ++prof_long_n;
+                    if (sharded) { HIPCHK(hipEventElapsedTime(&ms, evs[4 * b + 1], evc[b / PROF_STRIDE])); prof_comm_ms += ms; ++prof_comm_n; }
+                    HIPCHK(hipEventElapsedTime(&ms, evs[4 * b + 2], evs[4 * b + 3])); prof_short_ms += ms; ++prof_short_n;
+                } else { HIPCHK(hipEventElapsedTime(&ms, evs[4 * b], evs[4 * b + 1])); prof_long_ms += ms; ++prof_long_n; }
             }
         }
         if (h.done) break;
         if (it >= 200000) { dkmc_fail(4, "CG: no convergence after 200000 iterations", __FILE__, __LINE__); break; }
         for (int b = 0; b < batch; ++b, ++it) {
-            const bool pb = prof && b < 64 && (b % PROF_STRIDE == 0);      // events perturb the stream: sample 1 launch in 8 (first 64 of a batch)
-            if (pb) HIPCHK(hipEventRecord(evs[3 * b], st));
-#define AP_ARGS(vec) n_short, short_rows, hs, n_long, long_rows, rp, ci, (const double *)a, (const double *)p, t, part_pAp, ctrl, \
-                (const RunDesc *)runs, (const int *)nruns, (const int *)rem, (const int *)nrem, (const double *)(vec), (const int *)seg_off
+            // sampled launches (1 in 8 of the first 64 of a batch) carry start/stop events of the dispatch itself
+            // (hipExtLaunchKernelGGL): the kernel's own begin/end timestamps, no extra marker packets in the stream
+            const bool pb = prof && b < 64 && (b % PROF_STRIDE == 0);
+            hipEvent_t e0 = pb ? evs[4 * b] : nullptr, e1 = pb ? evs[4 * b + 1] : nullptr, e2 = pb ? evs[4 * b + 2] : nullptr, e3 = pb ? evs[4 * b + 3] : nullptr;
             if (use_runs) {
-#define SEG_ARGS nseg_loc, (const RunDesc *)segs + seg_lo, (const double *)a, (const double *)pS, seg_part + seg_lo, ctrl, (const int *)rem, ci, \
+#define SEG_ARGS nseg_loc, (const RunDesc *)segs + seg_lo, (const double *)a, (const double *)pS, seg_part + seg_lo, (const CgCtrl *)ctrl, (const int *)rem, ci, \
                  (const double *)p, nsb, n_short, short_rows, rp, long_rows, t, part_pAp
-                if (seg_nt && seg_unr == 8) hipLaunchKernelGGL((k_spmv_segs<1, RP, 8>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, SEG_ARGS);
-                else if (seg_nt) hipLaunchKernelGGL((k_spmv_segs<1, RP, 4>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, SEG_ARGS);
-                else if (seg_unr == 8) hipLaunchKernelGGL((k_spmv_segs<0, RP, 8>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, SEG_ARGS);
-                else hipLaunchKernelGGL((k_spmv_segs<0, RP, 4>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, SEG_ARGS);
+                if (seg_nt && seg_unr == 8) hipExtLaunchKernelGGL((k_spmv_segs<1, RP, 8>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
+                else if (seg_nt) hipExtLaunchKernelGGL((k_spmv_segs<1, RP, 4>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
+                else if (seg_unr == 8) hipExtLaunchKernelGGL((k_spmv_segs<0, RP, 8>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
+                else hipExtLaunchKernelGGL((k_spmv_segs<0, RP, 4>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
 #undef SEG_ARGS
-                if (pb) HIPCHK(hipEventRecord(evs[3 * b + 1], st));
                 if (sharded) {
                     // row sums of the owned rows -> exchange step -> t and the p.t partials on every rank.  Every rank enqueues
                     // exactly the same sequence of collectives (the batch plan and the stop decisions depend only on values
@@ -684,16 +684,16 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
                                                     (const int *)seg_off, (const double *)seg_part, xbuf + (size_t)me * parts.chunk, ctrl);
                     if (int rc = comm_allgather_f64(xbuf, (size_t)parts.chunk)) return rc;
                     if (pb) HIPCHK(hipEventRecord(evc[b / PROF_STRIDE], st));
-                    hipLaunchKernelGGL(k_rowsum_apply, dim3(hl2), dim3(SPMV_NT), 0, st, n_long, long_rows, (const RowParts *)dparts, (const double *)xbuf, (const double *)p, t,
-                                       part_pAp + hsA, ctrl);
+                    hipExtLaunchKernelGGL(k_rowsum_apply, dim3(hl2), dim3(SPMV_NT), 0, st, e2, e3, 0, n_long, long_rows, (const RowParts *)dparts, (const double *)xbuf,
+                                          (const double *)p, t, part_pAp + hsA, (const CgCtrl *)ctrl);
                 } else
-                hipLaunchKernelGGL((k_spmv_ap<0, 1, RP>), dim3(hl2), dim3(SPMV_NT), 0, st, 0, short_rows, 0, n_long, long_rows, rp, ci, (const double *)a,
-                                   (const double *)p, t, part_pAp + hsA, ctrl, (const RunDesc *)runs, (const int *)nruns, (const int *)rem,
-                                   (const int *)nrem, (const double *)seg_part, (const int *)seg_off);
+                hipExtLaunchKernelGGL((k_spmv_ap<0, 1, RP>), dim3(hl2), dim3(SPMV_NT), 0, st, e2, e3, 0, 0, short_rows, 0, n_long, long_rows, rp, ci, (const double *)a,
+                                      (const double *)p, t, part_pAp + hsA, (const CgCtrl *)ctrl, (const RunDesc *)runs, (const int *)nruns, (const int *)rem,
+                                      (const int *)nrem, (const double *)seg_part, (const int *)seg_off);
             }
-            else hipLaunchKernelGGL((k_spmv_ap<0, 0, RP>), dim3(np_ap), dim3(SPMV_NT), 0, st, AP_ARGS(pS));
-#undef AP_ARGS
-            if (pb) HIPCHK(hipEventRecord(evs[3 * b + 2], st));
+            else hipExtLaunchKernelGGL((k_spmv_ap<0, 0, RP>), dim3(np_ap), dim3(SPMV_NT), 0, st, e0, e1, 0, n_short, short_rows, hs, n_long, long_rows, rp, ci,
+                                       (const double *)a, (const double *)p, t, part_pAp, (const CgCtrl *)ctrl, (const RunDesc *)runs, (const int *)nruns,
+                                       (const int *)rem, (const int *)nrem, (const double *)pS, (const int *)seg_off);
             hipLaunchKernelGGL(k_cg_update, dim3(gv), dim3(CG_NT), 0, st, m, it, part_pAp, np_ap, p, t, y, r, part_rr, ctrl);
             hipLaunchKernelGGL(k_cg_direction, dim3(gv), dim3(CG_NT), 0, st, m, it, part_rr, gv, r, p, ctrl, tol2, use_runs ? srank : (const int *)nullptr, pS);
         }

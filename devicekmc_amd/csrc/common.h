@@ -134,7 +134,7 @@ enum {
     S_SCAN_TMP, S_SCAN_TMP2, S_SCAN_OFF64, S_SCAN_INTILE,
     S_AT_FLAG, S_AT_SITE, S_AT_OFSITE, S_AT_NEIGH,
     S_X_ROWPTR, S_X_COL, S_X_DATA, S_X_DATA2, S_X_CNT, S_X_SLIST, S_X_SCB, S_X_SFLAG, S_X_RHS, S_X_SRANK,
-    S_P_IMACRO, S_HEAT,
+    S_P_IMACRO, S_HEAT, S_HEAT_A, S_HEAT_B, S_HEAT_Y,
     S_MISC0, S_MISC1, S_MISC2, S_MISC3
 };
 

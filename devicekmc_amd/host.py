@@ -226,8 +226,34 @@ class Device:
             result["Global temperature [K]"] = self.T_bg
             result["Total dissipated power [mW]"] = P.value * 1e3
         elif p.solve_heating_local:
-            raise NotImplementedError("local heating has no GPU implementation in the reference either (SURVEY 3.5)")
+            # heat_solver.cpp:286-308; the dense host inverses of the reference are replaced by sparse solves on the device
+            _use_stream(gpubuf.dev)
+            ns, steady, iters, T = C.c_int(0), C.c_int(0), C.c_int(0), C.c_double(0.0)
+            check(_lib.load().dkmc_update_temperature_local(C.byref(gpubuf.c), step_time, p.delta_t, p.tau, p.background_temp,
+                                                            p.k_th_interface, p.k_th_vacancies, self.nn_dist, p.num_atoms_contact,
+                                                            C.byref(ns), C.byref(steady), C.byref(iters), C.byref(T)))
+            self.T_bg = T.value
+            self.last_heat_solves, self.last_heat_steady, self.last_heat_cg_iters = ns.value, bool(steady.value), iters.value
+            result["Global temperature [K]"] = self.T_bg
         return result
+
+    # heat_solver.cpp:5-37
+    def get_num_in_contacts(self, num_atoms_contact: int, contact_name: str) -> int:
+        el, N = self.site_element, self.N
+        nondef = np.flatnonzero(el != 0)                      # positions of the non-DEFECT sites
+        if contact_name == "left":
+            return 0 if num_atoms_contact <= 0 else int(nondef[num_atoms_contact - 1]) + 1
+        return 0 if num_atoms_contact <= 0 else N - int(nondef[len(nondef) - num_atoms_contact])
+
+    # heat_solver.cpp:40-246 (kmc_main.cpp:90-94: once, when solve_heating_local is set)
+    def constructLaplacian(self, gpubuf: GPUBuffers, p: KMCParameters):
+        _use_stream(gpubuf.dev)
+        N_metals = int(np.isin(self.site_element, list(p.metals)).sum())                      # Device.cpp:45-50
+        self.N_left_tot = self.get_num_in_contacts(p.num_atoms_contact, "left")
+        self.N_right_tot = self.get_num_in_contacts(N_metals - p.num_atoms_contact, "right")
+        self.N_interface = self.N - self.N_left_tot - self.N_right_tot
+        gamma = 1.0 / (p.delta * ((p.k_th_interface / p.k_th_metal) + 1.0))
+        check(_lib.load().dkmc_construct_laplacian(C.byref(gpubuf.c), self.N_left_tot, self.N_right_tot, gamma))
 
 
 class KMCProcess:

@@ -78,6 +78,10 @@ SYMBOLS = {
     "dkmc_get_last_X": (_I, [c_int_p, C.POINTER(C.c_longlong), vp, vp, vp]),
     "dkmc_update_temperatureglobal_gpu": (_I, [vp, vp, _I, _D, _D, _D, _D, _D]),
     "dkmc_update_temperature_global_analytic": (_I, [vp, vp, _I, _D, _D, _D, _D, _D, c_dbl_p]),
+    "dkmc_set_heat_cg_tolerance": (None, [_D]),
+    "dkmc_construct_laplacian": (_I, [C.POINTER(dkmc_gpubuf), _I, _I, _D]),
+    "dkmc_update_temperature_local": (_I, [C.POINTER(dkmc_gpubuf), _D, _D, _D, _D, _D, _D, _D, _I,
+                                           C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), c_dbl_p]),
     "dkmc_comm_unique_id": (_I, [C.c_char_p]),
     "dkmc_comm_init_rccl": (_I, [_I, _I, C.c_char_p]),
     "dkmc_comm_init_host": (_I, [_I, _I, ALLGATHER_FN, vp]),

@@ -73,6 +73,14 @@ class KMCParameters:
     m_0: float = 9.11e-31
     layers: List[Layer] = field(default_factory=default_layers)
     cg_tol: float = 1e-6                    # iterative_solvers_gpu.cu:322
+    # local temperature model (parameters.txt:76-91)
+    k_th_metal: float = 29.0
+    k_th_non_vacancy: float = 0.5
+    k_th_vacancies: float = 5.0
+    delta_t: float = 1e-13
+    delta: float = 1.0
+    power_adjustment_term: float = 1.0
+    L_char: float = 3.5e-10
 
     # input_parser.cpp:391-398
     @property
@@ -90,6 +98,14 @@ class KMCParameters:
     @property
     def m_e(self) -> float:
         return self.m_r * self.m_0
+
+    @property
+    def k_th_interface(self) -> float:       # input_parser.cpp:395
+        return self.k_th_non_vacancy + (self.k_th_vacancies - self.k_th_non_vacancy) * self.initial_vacancy_concentration
+
+    @property
+    def tau(self) -> float:                  # input_parser.cpp:396
+        return self.k_th_interface / (self.L_char * self.L_char * self.c_p * 1e6)
 
     # current_solver.cpp:8-17
     @property

@@ -194,6 +194,20 @@ int dkmc_update_temperature_global_analytic(const double *d_site_power, double *
                                             double dissipation_constant, double t_ox, double A, double c_p,
                                             double *h_P_tot);
 
+/* ---- local temperature model (host-only dense code in the reference: heat_solver.cpp:40-246, 286-308, 354-513) ----
+ * Sparse form of the same linear systems, solved with the Jacobi-CG.
+ * dkmc_construct_laplacian = Device::constructLaplacian: N_left_tot / N_right_tot are get_num_in_contacts (:5-37) evaluated
+ * by the caller on the host copy of site_element, gamma = 1/(delta*(k_th_interface/k_th_metal + 1)) (:86).
+ * dkmc_update_temperature_local = the local branch of Device::updateTemperature (:286-308): one steady-state solve when
+ * step_time > 1e3*delta_t, else int(step_time/delta_t)+1 transient solves; reads gpubuf.site_power, updates
+ * gpubuf.site_temperature and gpubuf.T_bg.  Tolerance of these solves: dkmc_set_heat_cg_tolerance (default 1e-10; the
+ * reference applies an explicit inverse). */
+void dkmc_set_heat_cg_tolerance(double tol);
+int dkmc_construct_laplacian(const dkmc_gpubuf *buf, int N_left_tot, int N_right_tot, double gamma);
+int dkmc_update_temperature_local(dkmc_gpubuf *buf, double step_time, double delta_t, double tau, double background_temp,
+                                  double k_th_interface, double k_th_vacancies, double nn_dist, int num_atoms_contact,
+                                  int *n_solves_out, int *steady_out, int *cg_iters_out, double *T_bg_out);
+
 /* ---- multi-GPU: one simulation advanced in lockstep by N processes, one GPU each (no reference counterpart) ----
  * While a communicator is attached, update_power_gpu_sparse deals the long rows of A*p of its CG solve to the ranks
  * and hands every rank every row sum with ONE in-place all-gather per iteration; every other phase is computed

@@ -501,3 +501,60 @@ def test_error_paths(cell_2p5, hip):
     with pytest.raises(DeviceKMCError, match="positive rate"):
         sim.executeKMCStep(gb, dev)
     assert L.dkmc_last_error() == b""                                 # cleared by the raising wrapper
+
+
+def test_local_temperature_model(cell_2p5, hip):
+    """Local heating (heat_solver.cpp:40-246, 286-308, 354-513; host-only and dense in the reference): the sparse device
+    solves against the dense numpy restatement (explicit inverses), transient sub-steps and steady state.  The oracle for
+    this model is unpinned (no reference fixture exists); tolerance 1e-7 K on temperatures of 300..1e3 K (CG stops at a
+    scaled residual of 1e-10, the dense inverse carries ~1e-12 relative error itself)."""
+    from devicekmc_amd import params as pm
+    from oracle import heat_local as hl
+    host, L = hip
+    p = pm.KMCParameters(); p.solve_heating_local = True
+    dev, sim, gb, o = make_pair(cell_2p5, p, hip, tol=1e-10)
+    dev.updateCharge(gb); dev.updatePotential(gb, p, Vd, 0)
+    sim.executeKMCStep(gb, dev)
+    dev.updatePower(gb, p, Vd)                                    # site_power of a real step
+    power = get(gb, "site_power").copy()
+    assert power.max() > 0
+    element = get(gb, "site_element").copy()
+    dev.site_element = element                                    # host copy after the step's events (contact counting)
+    dev.constructLaplacian(gb, p)
+    orc = hl.LocalHeatOracle(element, dev.neigh_idx, p.metals, p.num_atoms_contact, p.nn_dist, p.delta, p.delta_t, p.tau,
+                             p.k_th_interface, p.k_th_metal)
+    assert (dev.N_left_tot, dev.N_right_tot, dev.N_interface) == (orc.N_left_tot, orc.N_right_tot, orc.N_interface)
+    assert 0 < orc.N_interface < dev.N
+    # the power of one step heats by micro-kelvins; the model is linear in the power: scale it so that one transient update
+    # raises the hottest site by 30 K and the comparison resolves kelvins
+    trial = np.full(dev.N, p.background_temp)
+    orc.update_local_temperature(trial, power, element, p.background_temp, p.delta_t, p.tau, p.k_th_interface, p.k_th_vacancies,
+                                 p.num_atoms_contact)
+    power *= 30.0 / np.abs(trial - p.background_temp).max()
+    put(gb, "site_power", power)
+    T_ref = np.full(dev.N, p.background_temp)
+    put(gb, "site_temperature", T_ref)
+    # (a) transient: 2.5 delta_t -> 3 solves, then again from the heated state (warm history)
+    for step_time in (2.5 * p.delta_t, 0.3 * p.delta_t):
+        want_Tbg, want_n, want_ss = orc.update_temperature_local(T_ref, power, element, step_time, p.background_temp, p.delta_t, p.tau,
+                                                                 p.k_th_interface, p.k_th_vacancies, p.num_atoms_contact)
+        res = dev.updateTemperature(gb, p, step_time)
+        T = get(gb, "site_temperature")
+        assert (dev.last_heat_solves, dev.last_heat_steady) == (want_n, bool(want_ss))
+        assert np.abs(T - T_ref).max() <= 1e-7, np.abs(T - T_ref).max()
+        assert abs(res["Global temperature [K]"] - want_Tbg) <= 1e-9
+        assert abs(float(gb.T_bg.item()) - want_Tbg) <= 1e-9
+    assert np.abs(T_ref - p.background_temp).max() > 1.0          # the comparison is not vacuous
+    # (b) steady state: step_time > 1e3 delta_t
+    want_Tbg, want_n, want_ss = orc.update_temperature_local(T_ref, power, element, 2e3 * p.delta_t, p.background_temp, p.delta_t, p.tau,
+                                                             p.k_th_interface, p.k_th_vacancies, p.num_atoms_contact)
+    res = dev.updateTemperature(gb, p, 2e3 * p.delta_t)
+    T = get(gb, "site_temperature")
+    assert dev.last_heat_steady and want_ss == 1
+    rel = np.abs(T - T_ref).max() / max(1.0, np.abs(T_ref - p.background_temp).max())
+    assert rel <= 1e-8, rel                                       # steady-state temperatures can be large: relative to the rise
+    assert abs(res["Global temperature [K]"] - want_Tbg) <= 1e-8 * max(1.0, abs(want_Tbg))
+    # sites outside the interface keep their temperature
+    out = np.r_[0:orc.N_left_tot, dev.N - orc.N_right_tot:dev.N]
+    assert np.all(T[out] == p.background_temp)
+    put(gb, "site_temperature", np.full(dev.N, p.background_temp))

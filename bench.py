@@ -269,7 +269,7 @@ def main():
     parallel.finalize()
 
 
-def lockstep_run(name, nsteps, devname, Vd=5.0):
+def lockstep_run(name, nsteps, devname, Vd=5.0, tiles=1):
     """nsteps supersteps of workload `name` from a fresh state with the reference seeds (identical on every rank);
     returns (seconds for the steps after the first, trace, stats of the last step).  The first step is untimed: it fills the
     tunnelling-coefficient cache and sizes the scratch buffers."""
@@ -281,6 +281,7 @@ def lockstep_run(name, nsteps, devname, Vd=5.0):
     sim = host.KMCProcess(dev, p.freq)
     gb = dev.make_gpubuf(devname)
     L.dkmc_set_current_warm_start(0)
+    L.dkmc_set_symmetric_tiles(tiles)
     dev.setLaplacePotential(gb, p, Vd)
     gb.sync_HostToGPU(dev)
     trace, iters = [], 0
@@ -298,6 +299,7 @@ def lockstep_run(name, nsteps, devname, Vd=5.0):
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     L.dkmc_set_profiling(0)
+    L.dkmc_set_symmetric_tiles(1)
     st = dict(host.get_stats())
     st["cg_iters_X_per_step"] = iters / nsteps
     st["sites"] = int(s.N)
@@ -326,7 +328,13 @@ def sharded_block(names, nsteps, devname, backend, rank, world):
         finally:
             parallel.detach_solver_comm()
         t_shard = parallel.max_over_ranks(t_shard, red_dev)
-        same_here = 1.0 if trace_shard == trace_single else 0.0
+        # bit-identity is against the single-GPU solve that reads every stored entry (the sharded solve's arithmetic); the timing
+        # baseline above is the default single-GPU solve, which may use symmetric tiles (equal to rounding)
+        trace_exact = trace_single
+        if trace_shard != trace_single and st1["spmv_tiles"] > 0:
+            _, trace_exact, _ = lockstep_run(name, nsteps, devname, tiles=0)
+        same_here = 1.0 if trace_shard == trace_exact else 0.0
+        close = all(abs(a - b) <= 1e-9 * abs(b) for ta, tb in zip(trace_shard, trace_single) for a, b in zip(ta, tb))
         flag = torch.tensor([same_here], dtype=torch.float64, device=red_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         traces = [None] * world
@@ -335,7 +343,8 @@ def sharded_block(names, nsteps, devname, backend, rank, world):
             "sites": st1["sites"], "X_nnz": int(st1["X_nnz"]), "cg_iters_X": st1["cg_iters_X_per_step"],
             "single_gpu_ms_per_step": round(t_single / nsteps * 1e3, 3), "sharded_ms_per_step": round(t_shard / nsteps * 1e3, 3),
             "speedup": round(t_single / t_shard, 3),
-            "bit_identical_to_single_gpu": bool(flag.item() == 1.0), "ranks_agree": all(t == traces[0] for t in traces),
+            "bit_identical_to_single_gpu_segment_path": bool(flag.item() == 1.0), "equal_to_default_single_gpu_within_1e-9": bool(close),
+            "single_gpu_symmetric_tiles": int(st1["spmv_tiles"]), "ranks_agree": all(t == traces[0] for t in traces),
             "segments": int(st2["spmv_segments"]), "allgather_doubles_per_rank": int(st2["comm_count_per_rank"]),
             "allgather_us": round(st2["comm_ms"] / max(st2["comm_launches"], 1) * 1e3, 2),
             "segment_kernel_us": round(st2["spmv_long_ms"] / max(st2["spmv_long_launches"], 1) * 1e3, 2),

@@ -23,7 +23,7 @@
 #include <stdlib.h>
 
 #define CG_NT 256
-#define CG_MAX_PART 2048        // max blocks writing partials per kernel family
+#define CG_MAX_PART 8192        // max blocks writing partials per kernel family
 #define PROF_STRIDE 8
 #define LONG_ROW_NNZ 192        // rows with more entries go to the wave-per-row bin
 
@@ -41,6 +41,14 @@ enum { M_SCALE = 0, M_INIT = 1, M_AP = 2, M_DIAG = 3 };
 #define REM_SEG_LEN 256
 #define SEG_LEN 2048           // entries per segment = work item of one wave in k_spmv_segs
 struct __attribute__((aligned(16))) RunDesc { long long pos; int len, sr0; };   // sr0 < 0: gather segment of long row -1-sr0
+// per long row, everything stage 2 needs in one 16-byte load (tile mode)
+struct __attribute__((aligned(16))) LRowMeta { int sr, nseg, segoff, row, wbeg, wend, kend, pad; };   // [wbeg, wend): windows of the row block's tiles; kend: 1 + last row block with a tile in the row's window
+// symmetric tiles of the tunnelling block (see k_tile_flags)
+#define SEGK_NT 256            // workgroup of k_spmv_segs / k_spmv_tiles: 4 waves, one work item each
+#define TILE_SEG_LEN 256       // tile mode: what the tiles leave behind is cut into pieces of at most this many entries (16 lanes each)
+#define TILE_R 32
+#define TILE_C 256
+struct TileDesc { int k, w, ncols, pad; long long pos[TILE_R]; };     // S-rows [32k, 32k+32) x S-cols [256w, 256w+ncols)
 
 // block-uniform read of the stop flag (only the last kernel of an iteration ever sets it)
 __device__ __forceinline__ bool cg_done(const CgCtrl *ctrl)
@@ -248,6 +256,53 @@ __global__ __launch_bounds__(SPMV_NT) void k_rowsum_apply(int n_long, const int 
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
 }
 
+// stage 2 in symmetric-tile mode: t[row] = the row's segment partials + the row partials of the tiles of its row block
+// (ascending window) + the column partials of the tiles of its window (ascending row block), lane-strided over 16 lanes and
+// combined in a fixed order; launch shape of the fused stage 2.  The partial arrays are indexed by the tile GRID position
+// (k * nW + w; cells without a tile stay zero from the memset at the start of the solve), so that after the row's 32-byte
+// descriptor every load address is known: two dependent loads per row instead of three.
+__global__ __launch_bounds__(SPMV_NT) void k_rowsum_tiles(int n_long, const LRowMeta *__restrict__ meta, const double *__restrict__ seg_part,
+                                                          int nW, const double *__restrict__ rowpart, const double *__restrict__ colpart,
+                                                          const double *__restrict__ p, double *__restrict__ t, double *__restrict__ part,
+                                                          const CgCtrl *ctrl)
+{
+    __shared__ double red[SPMV_NT / 64];
+    __shared__ int sdone;
+    if (threadIdx.x == 0) sdone = ctrl->done;
+    __syncthreads();
+    if (sdone) return;
+    double acc = 0.0;
+    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+    for (int ridx = blockIdx.x * (SPMV_NT / 16) + g; ridx < n_long; ridx += gridDim.x * (SPMV_NT / 16)) {
+        const LRowMeta mt = meta[ridx];
+        double s = 0.0;
+        const double *sp = seg_part + mt.segoff;
+        for (int j = l; j < mt.nseg; j += 16) s += sp[j];
+        if (mt.sr >= 0) {
+            const int k = mt.sr / TILE_R, w2 = mt.sr / TILE_C;
+            const double *rpp = rowpart + ((size_t)k * nW) * TILE_R + (mt.sr % TILE_R);
+            for (int base = mt.wbeg + l; base < mt.wend; base += 64) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int w = base + 16 * u; v[u] = w < mt.wend ? rpp[(size_t)w * TILE_R] : 0.0; }
+                s += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+            const double *cpp = colpart + (size_t)w2 * TILE_C + (mt.sr % TILE_C);
+            for (int base = l; base < mt.kend; base += 64) {
+                double v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int k2 = base + 16 * u; v[u] = k2 < mt.kend ? cpp[((size_t)k2 * nW) * TILE_C] : 0.0; }
+                s += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+        if (l == 0) { t[mt.row] = s; acc += p[mt.row] * s; }
+    }
+    const double tot = block_sum_all<SPMV_NT>(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
 // after M_INIT: rr0 and the first stop test on the 2-norm (cublasDnrm2, :418)
 __global__ __launch_bounds__(CG_NT) void k_cg_check0(const double *part, int npart, CgCtrl *ctrl, double tol2)
 {
@@ -318,12 +373,14 @@ template <typename RP>
 __global__ __launch_bounds__(256) void k_build_runs(int n_long, const int *__restrict__ long_rows, const RP *__restrict__ rp,
                                                     const int *__restrict__ ci, const int *__restrict__ srank,
                                                     RunDesc *__restrict__ runs, int *__restrict__ nruns,
-                                                    int *__restrict__ rem, int *__restrict__ nrem, int seg_len)
+                                                    int *__restrict__ rem, int *__restrict__ nrem, int seg_len, int diag_break)
 {
     const int lane = threadIdx.x & 63;
     const int ridx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ridx >= n_long) return;
     const int row = long_rows[ridx];
+    // symmetric-tile mode: a run never crosses the row's own S-rank, so that every run is wholly in one triangle
+    const int self_sr = diag_break ? srank[row] : -1;
     const RP p0 = rp[row], p1 = rp[row + 1];
     const long long run_base = (long long)(p0 / RUN_MIN_LEN) + ridx;
     int nr = 0, nrm = 0;
@@ -332,8 +389,8 @@ __global__ __launch_bounds__(256) void k_build_runs(int n_long, const int *__res
         const int len = (int)(eA - sA);
         if (len <= 0) return;
         if (len >= RUN_MIN_LEN && sr0 >= 0) {       // long run: emitted as segments of at most SEG_LEN entries
-            for (int c = 0; c < len; c += seg_len) {
-                if (lane == 0) { RunDesc d; d.pos = (long long)sA + c; d.len = min(seg_len, len - c); d.sr0 = sr0 + c; runs[run_base + nr] = d; }
+            for (long long c = 0; c < len; c += seg_len) {
+                if (lane == 0) { RunDesc d; d.pos = (long long)sA + c; d.len = (int)min((long long)seg_len, (long long)len - c); d.sr0 = sr0 + (int)c; runs[run_base + nr] = d; }
                 ++nr;
             }
         } else {
@@ -347,7 +404,7 @@ __global__ __launch_bounds__(256) void k_build_runs(int n_long, const int *__res
         const int sr = valid ? srank[ci[q]] : -1;
         int prev = __shfl_up(sr, 1, WAVE);
         if (lane == 0) prev = carry;
-        const bool brk = valid && (q == p0 || sr < 0 || prev < 0 || sr != prev + 1);
+        const bool brk = valid && (q == p0 || sr < 0 || prev < 0 || sr != prev + 1 || (self_sr >= 0 && (sr == self_sr || prev == self_sr)));
         unsigned long long mask = __ballot(brk);
         while (mask) {
             const int b = __ffsll((long long)mask) - 1;
@@ -388,59 +445,370 @@ __global__ __launch_bounds__(256) void k_compact_segs(int n_long, const int *__r
     for (int j = lane; j < nruns[ridx]; j += WAVE) dst[j] = src[j];
 }
 
+// ---- symmetric tiles of the tunnelling block --------------------------------------------------------------------------------
+// X is symmetric and its tunnelling block is dense by classes (contact x contact, vacancy x contact: every pair present), so
+// nearly every long-run entry a_ij has its mirror a_ji stored in row j.  A *tile* is TILE_R (32) consecutive S-rows x one TILE_C (256) wide
+// window of S-columns strictly above the diagonal that is completely dense AND whose mirror (the window's rows x the 32
+// columns) is completely dense: the tile's values are read ONCE per iteration and yield both the row products (t_i += a_ij p_j)
+// and the column products (t_j += a_ij p_i); the mirror entries are cut out of their rows' segment lists and never read in
+// the loop.  Everything that is not in such a tile (sparse parts near the diagonal, ragged edges, rows 0/1) stays in the
+// segment path, both triangles.  The values stay where they are (CSR order): a tile is 32 strips of 256 contiguous values
+// (64 KiB per wave); its partial results are 32 row sums and 256 column sums (3.5 % of the bytes read), combined in stage 2.
+
+// per row block: range of windows that hold a tile; per window: 1 + the last row block that holds a tile (0 = none)
+__global__ void k_tile_ranges(int nK, int nW, const int *__restrict__ dense, int *__restrict__ wbeg, int *__restrict__ wend, int *__restrict__ kend)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nK) {
+        int b = nW, e = 0;
+        for (int w = 0; w < nW; ++w) if (dense[(long long)i * nW + w]) { b = min(b, w); e = w + 1; }
+        wbeg[i] = b; wend[i] = e;
+    }
+    if (i < nW) {
+        int e = 0;
+        for (int k = 0; k < nK; ++k) if (dense[(long long)k * nW + i]) e = k + 1;
+        kend[i] = e;
+    }
+}
+__global__ void k_lrow_meta(int n_long, const int *__restrict__ long_rows, const int *__restrict__ lsr, const int *__restrict__ nsegs,
+                            const int *__restrict__ seg_off, const int *__restrict__ wbeg, const int *__restrict__ wend, const int *__restrict__ kend,
+                            LRowMeta *__restrict__ meta)
+{
+    const int ridx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ridx >= n_long) return;
+    LRowMeta m; m.sr = lsr[ridx]; m.nseg = nsegs[ridx]; m.segoff = seg_off[ridx]; m.row = long_rows[ridx]; m.wbeg = 0; m.wend = 0; m.kend = 0; m.pad = 0;
+    if (m.sr >= 0) { m.wbeg = wbeg[m.sr / TILE_R]; m.wend = wend[m.sr / TILE_R]; m.kend = kend[m.sr / TILE_C]; }
+    meta[ridx] = m;
+}
+// s2r: S-rank -> long-row index (or -1, preset); lsr: long-row index -> S-rank (or -1)
+__global__ void k_s2r(int n_long, const int *__restrict__ long_rows, const int *__restrict__ srank, int *__restrict__ s2r, int *__restrict__ lsr)
+{
+    const int ridx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ridx < n_long) { const int sr = srank[long_rows[ridx]]; lsr[ridx] = sr; if (sr >= 0) s2r[sr] = ridx; }
+}
+
+template <typename RP>
+__device__ __forceinline__ const RunDesc *row_runs(int ridx, const int *long_rows, const RP *rp, const RunDesc *runs)
+{
+    return runs + ((long long)(rp[long_rows[ridx]] / RUN_MIN_LEN) + ridx);
+}
+// position (index into a) of S-column `lo` in long row ridx if one of its raw runs covers [lo, hi); -1 otherwise
+template <typename RP>
+__device__ __forceinline__ long long run_covering(int ridx, int lo, int hi, const int *long_rows, const RP *rp, const RunDesc *runs, const int *nruns)
+{
+    const RunDesc *rr = row_runs(ridx, long_rows, rp, runs);
+    const int n = nruns[ridx];
+    for (int q = 0; q < n; ++q) {
+        const RunDesc d = rr[q];
+        if (d.sr0 >= 0 && d.sr0 <= lo && d.sr0 + d.len >= hi) return d.pos + (lo - d.sr0);
+    }
+    return -1;
+}
+
+// one wave per candidate tile (k, w): dense[k * nW + w] = 1 iff the tile and its mirror are completely present
+template <typename RP>
+__global__ __launch_bounds__(256) void k_tile_flags(int ns, int nK, int nW, const int *__restrict__ s2r, const int *__restrict__ long_rows,
+                                                    const RP *__restrict__ rp, const RunDesc *__restrict__ runs, const int *__restrict__ nruns,
+                                                    int *__restrict__ dense)
+{
+    const int lane = threadIdx.x & 63;
+    const long long tid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tid >= (long long)nK * nW) return;
+    const int k = (int)(tid / nW), w = (int)(tid % nW);
+    const int r0 = k * TILE_R, c0 = w * TILE_C;
+    bool ok = (r0 + TILE_R <= ns) && (c0 >= r0 + TILE_R);          // whole row block, strictly above the diagonal
+    if (ok) {
+        const int ncols = min(TILE_C, ns - c0);
+        if (lane < TILE_R) { const int ridx = s2r[r0 + lane]; ok = ridx >= 0 && run_covering(ridx, c0, c0 + ncols, long_rows, rp, runs, nruns) >= 0; }
+        for (int c = lane; c < ncols && ok; c += 64) { const int ridx = s2r[c0 + c]; ok = ridx >= 0 && run_covering(ridx, r0, r0 + TILE_R, long_rows, rp, runs, nruns) >= 0; }
+    }
+    const bool all_ok = __ballot(!ok) == 0ull;
+    if (lane == 0) dense[tid] = all_ok ? 1 : 0;
+}
+
+template <typename RP>
+__global__ __launch_bounds__(256) void k_tile_desc(int ns, int nK, int nW, const int *__restrict__ dense, const int *__restrict__ toff, const int *__restrict__ s2r,
+                                                   const int *__restrict__ long_rows, const RP *__restrict__ rp, const RunDesc *__restrict__ runs,
+                                                   const int *__restrict__ nruns, TileDesc *__restrict__ tiles)
+{
+    const int lane = threadIdx.x & 63;
+    const long long tid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tid >= (long long)nK * nW || !dense[tid]) return;
+    const int k = (int)(tid / nW), w = (int)(tid % nW);
+    TileDesc *d = tiles + toff[tid];
+    const int c0 = w * TILE_C, ncols = min(TILE_C, ns - c0);
+    if (lane == 0) { d->k = k; d->w = w; d->ncols = ncols; d->pad = 0; }
+    if (lane < TILE_R) d->pos[lane] = run_covering(s2r[k * TILE_R + lane], c0, c0 + ncols, long_rows, rp, runs, nruns);
+}
+
+// Segment list of one long row = its raw runs minus everything the tiles cover, cut into <= seg_len pieces, followed by its
+// gather segments.  One thread per row; FILL = 0 counts, FILL = 1 writes at seg_off[ridx].
+template <int FILL, typename RP>
+__global__ __launch_bounds__(256) void k_emit_segs(int n_long, const int *__restrict__ long_rows, const RP *__restrict__ rp, const int *__restrict__ srank,
+                                                   const RunDesc *__restrict__ runs, const int *__restrict__ nruns, int ns, int nW,
+                                                   const int *__restrict__ dense, int seg_len, int *__restrict__ nsegs, const int *__restrict__ seg_off,
+                                                   RunDesc *__restrict__ segs, const int *__restrict__ goff)
+{
+    const int ridx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ridx >= n_long) return;
+    const int s = srank[long_rows[ridx]];
+    const RunDesc *rr = row_runs(ridx, long_rows, rp, runs);
+    const int n = nruns[ridx];
+    int cnt = 0;
+    RunDesc *out = FILL ? segs + seg_off[ridx] : nullptr;
+    auto emit = [&](long long pos, int sr0, int len) {              // one untiled stretch, cut into segments
+        for (int c = 0; c < len; c += seg_len) {
+            if (FILL) { RunDesc d; d.pos = pos + c; d.len = min(seg_len, len - c); d.sr0 = sr0 + c; out[cnt] = d; }
+            ++cnt;
+        }
+    };
+    for (int q = 0; q < n; ++q) {
+        const RunDesc d = rr[q];
+        if (d.sr0 < 0) {                                                          // gather segment
+            if (goff == nullptr) { if (FILL) out[cnt] = d; ++cnt; continue; }    // (legacy layout: unchanged)
+            // packed layout: position in the compact (value, column) arrays of the remainder entries, 64 entries per wave
+            const long long base = (long long)goff[ridx] + (d.pos - (long long)rp[long_rows[ridx]]);
+            for (int c = 0; c < d.len; c += 64) {
+                if (FILL) { RunDesc g; g.pos = base + c; g.len = min(64, d.len - c); g.sr0 = d.sr0; out[cnt] = g; }
+                ++cnt;
+            }
+            continue;
+        }
+        const int lo = d.sr0, hi = d.sr0 + d.len;
+        if (s < 0 || dense == nullptr) { emit(d.pos, lo, d.len); continue; }
+        int start = lo;                                                         // start of the current untiled stretch
+        if (lo > s) {
+            // upper run: a window is skipped when tile (s/TILE_R, w) exists; dense tiles are whole windows inside this run
+            const int k = s / TILE_R;
+            for (int w = lo / TILE_C; w * TILE_C < hi; ++w) {
+                const int c0 = w * TILE_C, c1 = min(c0 + TILE_C, ns);
+                if (c0 >= lo && c1 <= hi && c0 >= k * TILE_R + TILE_R && dense[(long long)k * nW + w]) {
+                    if (c0 > start) emit(d.pos + (start - lo), start, c0 - start);
+                    start = c1;
+                }
+            }
+        } else {
+            // lower run: the TILE_R columns of row block k' are skipped when tile (k', s/TILE_C) exists (this row is one of its columns)
+            const int w = s / TILE_C;
+            for (int k = lo / TILE_R; k * TILE_R < hi; ++k) {
+                const int c0 = k * TILE_R, c1 = c0 + TILE_R;
+                if (c0 >= lo && c1 <= hi && w * TILE_C >= c1 && dense[(long long)k * nW + w]) {
+                    if (c0 > start) emit(d.pos + (start - lo), start, c0 - start);
+                    start = c1;
+                }
+            }
+        }
+        if (hi > start) emit(d.pos + (start - lo), start, hi - start);
+    }
+    if (!FILL) nsegs[ridx] = cnt;
+}
+
+// Packed copies for the latency-bound roles of the tile-mode launch (fewer dependent loads per wave: descriptor -> packed
+// (value, column) -> p): the remainder entries of the long rows and the short rows, copied after the Jacobi scaling.
+template <typename RP>
+__global__ __launch_bounds__(256) void k_pack_rem(int n_long, const int *__restrict__ long_rows, const RP *__restrict__ rp, const int *__restrict__ ci,
+                                                  const double *__restrict__ a, const int *__restrict__ rem, const int *__restrict__ nrem,
+                                                  const int *__restrict__ goff, double *__restrict__ gval, int *__restrict__ gcol)
+{
+    const int lane = threadIdx.x & 63;
+    const int ridx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ridx >= n_long) return;
+    const RP p0 = rp[long_rows[ridx]];
+    const int n = nrem[ridx], o = goff[ridx];
+    for (int k = lane; k < n; k += 64) { const RP q = p0 + rem[p0 + k]; gval[o + k] = a[q]; gcol[o + k] = ci[q]; }
+}
+template <typename RP>
+__global__ void k_short_len(int n_short, const int *__restrict__ short_rows, const RP *__restrict__ rp, int *__restrict__ len)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_short) { const int row = short_rows[i]; len[i] = (int)(rp[row + 1] - rp[row]); }
+}
+template <typename RP>
+__global__ __launch_bounds__(256) void k_pack_short(int n_short, const int *__restrict__ short_rows, const RP *__restrict__ rp, const int *__restrict__ ci,
+                                                    const double *__restrict__ a, const int *__restrict__ srp, double *__restrict__ sval, int *__restrict__ scol)
+{
+    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
+    const int ridx = blockIdx.x * 16 + g;
+    if (ridx >= n_short) return;
+    const int row = short_rows[ridx];
+    const RP p0 = rp[row]; const int n = (int)(rp[row + 1] - p0), o = srp[ridx];
+    for (int k = l; k < n; k += 16) { sval[o + k] = a[p0 + k]; scol[o + k] = ci[p0 + k]; }
+}
+
 // stage 1 of the long-row product: one wave64 per segment, seg_part[seg] = sum a[pos+k] * pS[sr0+k].
 // Streams 8 B per entry, 4 independent 1-KiB strips in flight per wave; every wave has the same amount of work.
 // Default cache policy on the matrix stream (NTL = 0): the same 240 MB are re-read every CG iteration and partly stay in
 // the 256 MiB Infinity Cache -- measured 45 us per launch against 53 us with non-temporal loads (NTL = 1, DKMC_SPMV_VAR=3).
-#define SEGK_NT 256
-template <int NTL, typename RP, int UNR>
+template <int NTL, typename RP, int UNR, int TILES>
 __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *__restrict__ segs, const double *__restrict__ a,
                                                        const double *__restrict__ pS, double *__restrict__ seg_part, const CgCtrl *ctrl,
                                                        const int *__restrict__ rem, const int *__restrict__ ci, const double *__restrict__ p,
                                                        int nsb, int n_short, const int *__restrict__ short_rows, const RP *__restrict__ rp,
                                                        const int *__restrict__ long_rows,
-                                                       double *__restrict__ t, double *__restrict__ part)
+                                                       double *__restrict__ t, double *__restrict__ part,
+                                                       int ntb, int ntiles, int nW_t, const TileDesc *__restrict__ tiles,
+                                                       double *__restrict__ rowpart, double *__restrict__ colpart,
+                                                       const double *__restrict__ gval, const int *__restrict__ gcol,
+                                                       const int *__restrict__ srp, const double *__restrict__ sval, const int *__restrict__ scol)
 {
     __shared__ double red[SEGK_NT / 64];
     __shared__ int sdone;
-    if ((int)blockIdx.x >= nsb) {
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+#define LDM(ptr) (NTL ? __builtin_nontemporal_load(ptr) : *(ptr))
+    if (TILES && (int)blockIdx.x < ntb) {
+        // symmetric tiles (FIRST ntb blocks, so that the bandwidth-bound part of the launch starts at once and the latency-bound
+        // segment / short-row blocks fill in behind it; one wave per tile; see k_tile_flags): TILE_R strips of <= TILE_C contiguous values,
+        // read once, give the row products (one wave reduction per strip) and the column products (four columns per lane,
+        // accumulated in registers over the strips).  Only instantiated (TILES = 1) when tiles exist: the extra registers
+        // cost the segment waves occupancy, which does not matter once the tiles carry most of the matrix.
+        if (ctrl->done) return;
+        const int lane = threadIdx.x & 63;
+        // the tile index is wave-uniform: say so, and the descriptor (strip positions) is fetched with scalar loads
+        const int tile = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (SEGK_NT / 64) + (int)(threadIdx.x >> 6));
+        if (tile >= ntiles) return;
+        const TileDesc *d = tiles + tile;
+        const int ncols = d->ncols;
+        const size_t cell = (size_t)d->k * nW_t + d->w;                    // position in the tile grid: where the partial sums go
+        const double *pc = pS + (size_t)d->w * TILE_C, *pr = pS + (size_t)d->k * TILE_R;
+        double pcx[2], pcy[2], cax[2], cay[2];
+        int ix[2], iy[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int col = 2 * lane + 128 * u;
+            pcx[u] = col < ncols ? pc[col] : 0.0; pcy[u] = col + 1 < ncols ? pc[col + 1] : 0.0;
+            ix[u] = min(col, ncols - 1); iy[u] = min(col + 1, ncols - 1);      // clamped: out-of-window lanes re-read the last column,
+            cax[u] = 0.0; cay[u] = 0.0;                                          // multiply it by 0 and never store their column sums
+        }
+        // Strips in 4 phases of 8 (a real loop, so that the register budget stays at one phase): the 32 loads of a phase (8-byte
+        // loads -- a strip starts at any element of its row, so its 16-byte alignment varies -- with clamped indices, no branches)
+        // are issued together, 16 KiB in flight per wave.  Row sums: 32 sums over 64 lanes with 32 shuffles instead of 32 x 6.  In
+        // every butterfly step a lane keeps the half of its values whose index bit matches its lane bit and adds the partner's:
+        // xor 32, 16, 8 fold the 8 strips of a phase into one value per lane, xor 4, 2 fold the 4 phases, xor 1 completes the sum.
+        // Fixed order: deterministic.
+        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+#pragma unroll 1
+        for (int ph = 0; ph < TILE_R / 8; ++ph) {
+            double x0[8], y0[8], x1[8], y1[8], ra[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double *strip = a + d->pos[8 * ph + q];
+                x0[q] = LDM(strip + ix[0]); y0[q] = LDM(strip + iy[0]); x1[q] = LDM(strip + ix[1]); y1[q] = LDM(strip + iy[1]);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const double prow = pr[8 * ph + q];
+                ra[q] = (x0[q] * pcx[0] + y0[q] * pcy[0]) + (x1[q] * pcx[1] + y1[q] * pcy[1]);
+                cax[0] += x0[q] * prow; cay[0] += y0[q] * prow; cax[1] += x1[q] * prow; cay[1] += y1[q] * prow;
+            }
+#pragma unroll
+            for (int half = 4, bit = 32; half >= 1; half >>= 1, bit >>= 1) {
+                const bool up = (lane & bit) != 0;
+#pragma unroll
+                for (int j = 0; j < half; ++j) {
+                    const double keep = up ? ra[j + half] : ra[j];
+                    const double send = up ? ra[j] : ra[j + half];
+                    ra[j] = keep + __shfl_xor(send, bit, WAVE);
+                }
+            }
+            acc0 = ph == 0 ? ra[0] : acc0; acc1 = ph == 1 ? ra[0] : acc1; acc2 = ph == 2 ? ra[0] : acc2; acc3 = ph == 3 ? ra[0] : acc3;
+        }
+        {
+            const bool up4 = (lane & 4) != 0, up2 = (lane & 2) != 0;
+            const double b0 = (up4 ? acc2 : acc0) + __shfl_xor(up4 ? acc0 : acc2, 4, WAVE);      // phases 0|2 by lane bit 2
+            const double b1 = (up4 ? acc3 : acc1) + __shfl_xor(up4 ? acc1 : acc3, 4, WAVE);      // phases 1|3
+            const double c0 = (up2 ? b1 : b0) + __shfl_xor(up2 ? b0 : b1, 2, WAVE);              // +1 by lane bit 1
+            const double rsum = c0 + __shfl_xor(c0, 1, WAVE);
+            // strip of this lane: phase = 2*bit2 + bit1, index in the phase = 4*bit5 + 2*bit4 + bit3
+            const int rr = 8 * (((lane >> 2) & 1) * 2 + ((lane >> 1) & 1)) + ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+            if ((lane & 1) == 0) rowpart[cell * TILE_R + rr] = rsum;
+        }
+        double *cp = colpart + cell * TILE_C;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int col = 2 * lane + 128 * u;
+            if (col + 1 < ncols) { dbl2 v; v.x = cax[u]; v.y = cay[u]; *reinterpret_cast<dbl2 *>(cp + col) = v; }
+            else if (col < ncols) cp[col] = cax[u];
+        }
+        return;
+    }
+    const int bid = (int)blockIdx.x - (TILES ? ntb : 0);          // block index among the segment + short-row blocks
+    if (bid >= nsb) {
         // the short rows ride along in the same launch (independent of the segments): 16 lanes per row, p.t partial per block
         if (threadIdx.x == 0) sdone = ctrl->done;
         __syncthreads();
         if (sdone) return;
+        if (TILES) {
+            // tile mode: this work is no longer hidden behind a long matrix stream, and what it costs is dependent loads per wave
+            // times the number of wave rounds: 8 lanes per row (the rows average 17 entries) from the packed copy, one row per
+            // group and launch, so that half as many waves go through the descriptor -> (value, column) -> p chain once
+            const int g8 = threadIdx.x >> 3, l8 = threadIdx.x & 7;
+            const int ridx = (bid - nsb) * (SEGK_NT / 8) + g8;
+            double acc = 0.0;
+            if (ridx < n_short) {
+                const int q0 = srp[ridx], q1 = srp[ridx + 1];
+                double s = 0.0;
+                for (int q = q0 + l8; q < q1; q += 8) s += sval[q] * p[scol[q]];
+                s += __shfl_xor(s, 4, 8); s += __shfl_xor(s, 2, 8); s += __shfl_xor(s, 1, 8);
+                if (l8 == 0) { const int row = short_rows[ridx]; t[row] = s; acc = p[row] * s; }
+            }
+            const double tot = block_sum_all<SEGK_NT>(acc, red);
+            if (threadIdx.x == 0) part[bid - nsb] = tot;
+            return;
+        }
         const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
-        const int nb = gridDim.x - nsb;
+        const int nb = gridDim.x - nsb - (TILES ? ntb : 0);
         double acc = 0.0;
-        for (int ridx = (blockIdx.x - nsb) * (SEGK_NT / 16) + g; ridx < n_short; ridx += nb * (SEGK_NT / 16)) {
+        for (int ridx = (bid - nsb) * (SEGK_NT / 16) + g; ridx < n_short; ridx += nb * (SEGK_NT / 16)) {
             const int row = short_rows[ridx];
-            const RP p0 = rp[row], p1 = rp[row + 1];
             double s = 0.0;
-            for (RP q = p0 + l; q < p1; q += 16) s += a[q] * p[ci[q]];
+            if (TILES) {          // packed copy of the short rows: row pointer by ridx, contiguous (value, column)
+                const int q0 = srp[ridx], q1 = srp[ridx + 1];
+                for (int q = q0 + l; q < q1; q += 16) s += sval[q] * p[scol[q]];
+            } else {
+                const RP p0 = rp[row], p1 = rp[row + 1];
+                for (RP q = p0 + l; q < p1; q += 16) s += a[q] * p[ci[q]];
+            }
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
             if (l == 0) { t[row] = s; acc += p[row] * s; }
         }
         const double tot = block_sum_all<SEGK_NT>(acc, red);
-        if (threadIdx.x == 0) part[blockIdx.x - nsb] = tot;
+        if (threadIdx.x == 0) part[bid - nsb] = tot;
         return;
     }
     if (ctrl->done) return;                  // no barrier on this path: a per-wave read is fine
+    if (TILES) {
+        // tile mode: what the tiles leave behind are short pieces (63 entries on average at 85 k sites): 16 lanes per segment,
+        // 16 segments per workgroup, for the same reason as above
+        const int l16 = threadIdx.x & 15;
+        const int seg = bid * (SEGK_NT / 16) + (threadIdx.x >> 4);
+        if (seg >= nseg) return;
+        const RunDesc d = segs[seg];
+        double g = 0.0;
+        if (d.sr0 < 0) { for (int k = l16; k < d.len; k += 16) g += gval[d.pos + k] * p[gcol[d.pos + k]]; }      // packed remainder entries
+        else { const double *av = a + d.pos, *pv = pS + d.sr0; for (int k = l16; k < d.len; k += 16) g += LDM(av + k) * pv[k]; }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) g += __shfl_xor(g, off, 16);
+        if (l16 == 0) seg_part[seg] = g;
+        return;
+    }
     const int lane = threadIdx.x & 63;
-    const int seg = blockIdx.x * (SEGK_NT / 64) + (threadIdx.x >> 6);
+    const int seg = bid * (SEGK_NT / 64) + (threadIdx.x >> 6);
     if (seg >= nseg) return;
     const RunDesc d = segs[seg];
     if (d.sr0 < 0) {                         // gather segment: entries outside long runs (<1 % of the matrix)
         double g = 0.0;
-        const RP rowp0 = rp[long_rows[-1 - d.sr0]];
-        for (int k = lane; k < d.len; k += 64) { const RP q = rowp0 + rem[d.pos + k]; g += a[q] * p[ci[q]]; }
+        if (TILES) { for (int k = lane; k < d.len; k += 64) g += gval[d.pos + k] * p[gcol[d.pos + k]]; }      // packed remainder entries
+        else {
+            const RP rowp0 = rp[long_rows[-1 - d.sr0]];
+            for (int k = lane; k < d.len; k += 64) { const RP q = rowp0 + rem[d.pos + k]; g += a[q] * p[ci[q]]; }
+        }
         g = wave_sum(g);
         if (lane == 0) seg_part[seg] = g;
         return;
     }
     // 16-byte loads of the matrix stream: peel one entry if the segment starts on an odd element, then every lane
     // reads pairs (1 KiB per wave-instruction, 4 instructions in flight)
-    typedef double dbl2 __attribute__((ext_vector_type(2)));
-#define LDM(ptr) (NTL ? __builtin_nontemporal_load(ptr) : *(ptr))
     const int head = (int)(d.pos & 1);
     const double *av = a + d.pos + head, *pv = pS + d.sr0 + head;
     const int len = d.len - head;
@@ -557,6 +925,10 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
     static const int seg_len = getenv("DKMC_SEG_LEN") ? (atoi(getenv("DKMC_SEG_LEN")) < 2 * RUN_MIN_LEN ? 2 * RUN_MIN_LEN : atoi(getenv("DKMC_SEG_LEN"))) : SEG_LEN;
     const bool use_runs = use_runs_env && srank && n_long > 0 && ns > 0;
     RunDesc *runs = nullptr, *segs = nullptr; int *nruns = nullptr, *rem = nullptr, *nrem = nullptr, *seg_off = nullptr; double *pS = nullptr, *seg_part = nullptr;
+    static const double tile_min_cover = getenv("DKMC_TILE_COVER") ? atof(getenv("DKMC_TILE_COVER")) : 0.8;   // fraction of X that must sit in tiles
+    bool use_tiles = false; int nK = 0, nW = 0, ntiles = 0; int *dense = nullptr, *toff = nullptr, *nsegs = nullptr;
+    TileDesc *tiles = nullptr; double *rowpart = nullptr, *colpart = nullptr; int *trange = nullptr, *lsr = nullptr, *goff = nullptr, *gcol = nullptr, *srp = nullptr, *scol = nullptr;
+    double *gval = nullptr, *sval = nullptr; LRowMeta *lmeta = nullptr;
     int nseg = 0, nseg_loc = 0, seg_lo = 0; bool sharded = false; RowParts parts{}, *dparts = nullptr; double *xbuf = nullptr;
     if (use_runs) {
         runs = (RunDesc *)scratch(S_CG_RUNS, ((size_t)nnz / RUN_MIN_LEN + n_long + 2) * sizeof(RunDesc));
@@ -565,10 +937,66 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
         pS = (double *)scratch(S_CG_PS, (size_t)ns * 8);
         if (!runs || !rem || !nruns || !pS) return e.err_code;
         nrem = nruns + n_long;
-        hipLaunchKernelGGL((k_build_runs<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, ci, srank, runs, nruns, rem, nrem, seg_len);
+        // symmetric tiles (single-GPU solves; the sharded solve keeps the plain segment path and its bit-identity guarantee)
+        use_tiles = e.symmetric_tiles && !comm_attached() && ns > TILE_C;
+        hipLaunchKernelGGL((k_build_runs<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, ci, srank, runs, nruns, rem, nrem,
+                           use_tiles ? 0x7fffffff : seg_len, use_tiles ? 1 : 0);
         seg_off = (int *)scratch(S_CG_SEGOFF, (size_t)(n_long + 4) * 4);
         if (!seg_off) return e.err_code;
-        int rc = dkmc_exclusive_scan_i32(nruns, seg_off, n_long, seg_off + n_long); if (rc) return rc;
+        int rc = 0;
+        if (use_tiles) {
+            // raw runs -> tile flags -> tile descriptors -> segment list of what the tiles do not cover
+            nK = (ns + TILE_R - 1) / TILE_R; nW = (ns + TILE_C - 1) / TILE_C;
+            const long long ncand = (long long)nK * nW;
+            if (ncand > 0x7fffff00ll) return dkmc_fail(47, "CG: too many tile candidates", __FILE__, __LINE__);
+            int *s2r = (int *)scratch(S_CG_S2R, (size_t)ns * 4);
+            dense = (int *)scratch(S_CG_TDENSE, (size_t)(ncand + 4) * 4);
+            toff = (int *)scratch(S_CG_TOFF, (size_t)(ncand + 4) * 4);
+            nsegs = (int *)scratch(S_CG_NSEGS, (size_t)(n_long + 4) * 4);
+            if (!s2r || !dense || !toff || !nsegs) return e.err_code;
+            lsr = (int *)scratch(S_CG_LSR, (size_t)(n_long + 4) * 4);
+            if (!lsr) return e.err_code;
+            HIPCHK(hipMemsetAsync(s2r, 0xff, (size_t)ns * 4, st));
+            hipLaunchKernelGGL(k_s2r, dim3((n_long + 255) / 256), dim3(256), 0, st, n_long, long_rows, srank, s2r, lsr);
+            const int tb = (int)((ncand + 3) / 4);
+            hipLaunchKernelGGL((k_tile_flags<RP>), dim3(tb), dim3(256), 0, st, ns, nK, nW, (const int *)s2r, long_rows, rp, (const RunDesc *)runs,
+                               (const int *)nruns, dense);
+            rc = dkmc_exclusive_scan_i32(dense, toff, (int)ncand, toff + ncand); if (rc) return rc;
+            HIPCHK(hipMemcpyAsync(&ntiles, toff + ncand, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            // The tiles pay off when the tunnelling block is dense by classes (the reference's single devices: 95 % of X in tiles
+            // at 85 k sites).  On ragged structures (lateral tilings: 54 % at 235 k sites) the leftovers fragment into short
+            // segments and the plain segment path is faster: fall back to it.
+            if (2.0 * ntiles * TILE_R * TILE_C < tile_min_cover * (double)nnz) {
+                use_tiles = false; ntiles = 0;
+                hipLaunchKernelGGL((k_build_runs<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, ci, srank, runs, nruns, rem, nrem, seg_len, 0);
+            }
+        }
+        if (use_tiles) {
+            const long long ncand = (long long)nK * nW;
+            const int tb = (int)((ncand + 3) / 4);
+            const int *s2r = (const int *)scratch(S_CG_S2R, (size_t)ns * 4);
+            tiles = (TileDesc *)scratch(S_CG_TILES, (size_t)(ntiles + 1) * sizeof(TileDesc));
+            rowpart = (double *)scratch(S_CG_ROWPART, (size_t)(ncand + 1) * TILE_R * 8);      // one cell per grid position, zero where no tile
+            colpart = (double *)scratch(S_CG_COLPART, (size_t)(ncand + 1) * TILE_C * 8);
+            trange = (int *)scratch(S_CG_CSUM, (size_t)(2 * nK + nW + 8) * 4);
+            if (!tiles || !rowpart || !colpart || !trange) return e.err_code;
+            HIPCHK(hipMemsetAsync(rowpart, 0, (size_t)ncand * TILE_R * 8, st));
+            HIPCHK(hipMemsetAsync(colpart, 0, (size_t)ncand * TILE_C * 8, st));
+            hipLaunchKernelGGL(k_tile_ranges, dim3((std::max(nK, nW) + 255) / 256), dim3(256), 0, st, nK, nW, (const int *)dense, trange, trange + nK, trange + 2 * nK);
+            hipLaunchKernelGGL((k_tile_desc<RP>), dim3(tb), dim3(256), 0, st, ns, nK, nW, (const int *)dense, (const int *)toff, (const int *)s2r, long_rows, rp,
+                               (const RunDesc *)runs, (const int *)nruns, tiles);
+            // packed remainder entries: offsets now, values after the Jacobi scaling
+            goff = (int *)scratch(S_CG_GOFF, (size_t)(n_long + 4) * 4);
+            if (!goff) return e.err_code;
+            rc = dkmc_exclusive_scan_i32(nrem, goff, n_long, goff + n_long); if (rc) return rc;
+            hipLaunchKernelGGL((k_emit_segs<0, RP>), dim3((n_long + 255) / 256), dim3(256), 0, st, n_long, long_rows, rp, srank, (const RunDesc *)runs,
+                               (const int *)nruns, ns, nW, (const int *)dense, TILE_SEG_LEN, nsegs, (const int *)nullptr, (RunDesc *)nullptr, (const int *)goff);
+            rc = dkmc_exclusive_scan_i32(nsegs, seg_off, n_long, seg_off + n_long); if (rc) return rc;
+        } else {
+            rc = dkmc_exclusive_scan_i32(nruns, seg_off, n_long, seg_off + n_long); if (rc) return rc;
+            nsegs = nruns;
+        }
         HIPCHK(hipMemcpyAsync(&nseg, seg_off + n_long, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         // sharded solve (comm.hip): the long rows are dealt to the ranks at row boundaries, balanced by segment count; a
@@ -599,15 +1027,48 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
         segs = (RunDesc *)scratch(S_CG_SEGS, (size_t)(nseg + 1) * sizeof(RunDesc));
         seg_part = (double *)scratch(S_CG_SEGPART, (size_t)(nseg + 1) * 8);
         if (!segs || !seg_part) return e.err_code;
-        hipLaunchKernelGGL((k_compact_segs<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, (const RunDesc *)runs,
-                           (const int *)nruns, (const int *)seg_off, segs);
+        if (use_tiles)
+            hipLaunchKernelGGL((k_emit_segs<1, RP>), dim3((n_long + 255) / 256), dim3(256), 0, st, n_long, long_rows, rp, srank, (const RunDesc *)runs,
+                               (const int *)nruns, ns, nW, (const int *)dense, TILE_SEG_LEN, nsegs, (const int *)seg_off, segs, (const int *)goff);
+        else
+            hipLaunchKernelGGL((k_compact_segs<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, (const RunDesc *)runs,
+                               (const int *)nruns, (const int *)seg_off, segs);
+        if (use_tiles) {
+            lmeta = (LRowMeta *)scratch(S_CG_LMETA, (size_t)(n_long + 1) * sizeof(LRowMeta));
+            if (!lmeta) return e.err_code;
+            hipLaunchKernelGGL(k_lrow_meta, dim3((n_long + 255) / 256), dim3(256), 0, st, n_long, long_rows, (const int *)lsr, (const int *)nsegs,
+                               (const int *)seg_off, (const int *)trange, (const int *)(trange + nK), (const int *)(trange + 2 * nK), lmeta);
+        }
+        e.stats.spmv_tiles = ntiles;
     }
-    const int nsb = (nseg_loc + SEGK_NT / 64 - 1) / (SEGK_NT / 64);   // segment blocks of k_spmv_segs (this rank's share)
-    const int hsA = (use_runs && n_short > 0) ? grid_for(n_short, SEGK_NT / 16) : 0;   // its short-row blocks
+    // blocks of k_spmv_segs: segments (a wave each; 16 lanes each in tile mode), tiles (a wave each), short rows (16 / 8 lanes each)
+    const int nsb = use_tiles ? (nseg_loc + SEGK_NT / 16 - 1) / (SEGK_NT / 16) : (nseg_loc + SEGK_NT / 64 - 1) / (SEGK_NT / 64);
+    const int ntb = (ntiles + SEGK_NT / 64 - 1) / (SEGK_NT / 64);
+    const int hsA = (use_runs && n_short > 0) ? (use_tiles ? (n_short + SEGK_NT / 8 - 1) / (SEGK_NT / 8) : grid_for(n_short, SEGK_NT / 16)) : 0;
+    if (hsA + 4 > CG_MAX_PART / 2) return dkmc_fail(48, "CG: too many short-row blocks", __FILE__, __LINE__);
     if (use_runs) np_ap = hsA + hl2;
     // ---- Jacobi scaling ----
     SPMV(M_DIAG, (const double *)nullptr, s, x, y, (double *)nullptr);
     SPMV(M_SCALE, (const double *)s, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr);
+    if (use_tiles) {
+        // packed copies of the scaled remainder entries and short rows (k_pack_rem / k_pack_short)
+        int h_tot[2] = {0, 0};
+        int *slen = (int *)scratch(S_MISC0, (size_t)(n_short + 4) * 4);
+        srp = (int *)scratch(S_CG_SRP, (size_t)(n_short + 4) * 4);
+        if (!slen || !srp) return e.err_code;
+        hipLaunchKernelGGL((k_short_len<RP>), dim3((n_short + 255) / 256), dim3(256), 0, st, n_short, short_rows, rp, slen);
+        int rc = dkmc_exclusive_scan_i32(slen, srp, n_short, srp + n_short); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(&h_tot[0], srp + n_short, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&h_tot[1], goff + n_long, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        sval = (double *)scratch(S_CG_SVAL, (size_t)(h_tot[0] + 2) * 8); scol = (int *)scratch(S_CG_SCOL, (size_t)(h_tot[0] + 2) * 4);
+        gval = (double *)scratch(S_CG_GVAL, (size_t)(h_tot[1] + 2) * 8); gcol = (int *)scratch(S_CG_GCOL, (size_t)(h_tot[1] + 2) * 4);
+        if (!sval || !scol || !gval || !gcol) return e.err_code;
+        if (n_short > 0) hipLaunchKernelGGL((k_pack_short<RP>), dim3((n_short + 15) / 16), dim3(256), 0, st, n_short, short_rows, rp, ci, (const double *)a,
+                                            (const int *)srp, sval, scol);
+        hipLaunchKernelGGL((k_pack_rem<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, ci, (const double *)a, (const int *)rem,
+                           (const int *)nrem, (const int *)goff, gval, gcol);
+    }
     // ---- r = A y - x, p = -r ----
     SPMV(M_INIT, (const double *)y, r, x, p, part_rr);
     hipLaunchKernelGGL(k_cg_check0, dim3(1), dim3(CG_NT), 0, st, part_rr, np_spmv, ctrl, tol2);
@@ -631,6 +1092,13 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
             HIPCHK(hipMemcpy(hs_.data(), segs, (size_t)nseg * sizeof(RunDesc), hipMemcpyDeviceToHost));
             long long tot = 0; for (auto &d : hs_) tot += d.len;
             e.stats.spmv_segment_entries = tot;
+        }
+        e.stats.spmv_tile_entries = 0;
+        if (use_tiles && ntiles > 0) {
+            std::vector<TileDesc> ht((size_t)ntiles);
+            HIPCHK(hipMemcpy(ht.data(), tiles, (size_t)ntiles * sizeof(TileDesc), hipMemcpyDeviceToHost));
+            long long tot = 0; for (auto &d : ht) tot += (long long)d.ncols * TILE_R;
+            e.stats.spmv_tile_entries = tot;
         }
     }
     // ---- iterations, launched in batches; the host polls the control block between batches ----
@@ -669,12 +1137,23 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
             hipEvent_t e0 = pb ? evs[4 * b] : nullptr, e1 = pb ? evs[4 * b + 1] : nullptr, e2 = pb ? evs[4 * b + 2] : nullptr, e3 = pb ? evs[4 * b + 3] : nullptr;
             if (use_runs) {
 #define SEG_ARGS nseg_loc, (const RunDesc *)segs + seg_lo, (const double *)a, (const double *)pS, seg_part + seg_lo, (const CgCtrl *)ctrl, (const int *)rem, ci, \
-                 (const double *)p, nsb, n_short, short_rows, rp, long_rows, t, part_pAp
-                if (seg_nt && seg_unr == 8) hipExtLaunchKernelGGL((k_spmv_segs<1, RP, 8>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
-                else if (seg_nt) hipExtLaunchKernelGGL((k_spmv_segs<1, RP, 4>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
-                else if (seg_unr == 8) hipExtLaunchKernelGGL((k_spmv_segs<0, RP, 8>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
-                else hipExtLaunchKernelGGL((k_spmv_segs<0, RP, 4>), dim3(nsb + hsA), dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
+                 (const double *)p, nsb, n_short, short_rows, rp, long_rows, t, part_pAp, ntb, ntiles, nW, (const TileDesc *)tiles, rowpart, colpart, \
+                 (const double *)gval, (const int *)gcol, (const int *)srp, (const double *)sval, (const int *)scol
+                const dim3 sg(nsb + hsA + ntb);
+                if (use_tiles) {       // tile role compiled in; short rows and remainder entries from their packed copies
+                    if (seg_nt) hipExtLaunchKernelGGL((k_spmv_segs<1, RP, 4, 1>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
+                    else hipExtLaunchKernelGGL((k_spmv_segs<0, RP, 4, 1>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
+                }
+                else if (seg_nt && seg_unr == 8) hipExtLaunchKernelGGL((k_spmv_segs<1, RP, 8, 0>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
+                else if (seg_nt) hipExtLaunchKernelGGL((k_spmv_segs<1, RP, 4, 0>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
+                else if (seg_unr == 8) hipExtLaunchKernelGGL((k_spmv_segs<0, RP, 8, 0>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
+                else hipExtLaunchKernelGGL((k_spmv_segs<0, RP, 4, 0>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
 #undef SEG_ARGS
+                if (use_tiles) {
+                    hipExtLaunchKernelGGL(k_rowsum_tiles, dim3(hl2), dim3(SPMV_NT), 0, st, e2, e3, 0, n_long, (const LRowMeta *)lmeta,
+                                          (const double *)seg_part, nW, (const double *)rowpart, (const double *)colpart, (const double *)p, t,
+                                          part_pAp + hsA, (const CgCtrl *)ctrl);
+                } else
                 if (sharded) {
                     // row sums of the owned rows -> exchange step -> t and the p.t partials on every rank.  Every rank enqueues
                     // exactly the same sequence of collectives (the batch plan and the stop decisions depend only on values

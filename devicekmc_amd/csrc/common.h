@@ -103,6 +103,7 @@ struct Engine {
     double cg_tol = 1e-6;
     int current_warm_start = 0;
     int profiling = 0;
+    int symmetric_tiles = 1;       // CG on X: read dense blocks of the (symmetric) tunnelling part once for both triangles (cg.hip)
     int x_iter_hint = 0;           // iteration count of the previous CG solve of X (sizes the first launch batch)
     dkmc_stats stats{};
     char err[512] = {0};
@@ -111,7 +112,7 @@ struct Engine {
     double E_gen[DKMC_MAX_LAYERS] = {0}, E_rec[DKMC_MAX_LAYERS] = {0}, E_Vdiff[DKMC_MAX_LAYERS] = {0}, E_Odiff[DKMC_MAX_LAYERS] = {0};
     int num_layers = 0;
     // named persistent device buffers (grown on demand, never shrunk)
-    static const int NBUF = 64;
+    static const int NBUF = 96;
     void *buf[NBUF] = {nullptr};
     size_t bufsz[NBUF] = {0};
 };
@@ -127,7 +128,7 @@ inline MetalSet load_metals(const int *d_metals, int num_metals) { MetalSet ms; 
 
 // scratch slots
 enum {
-    S_CG_S = 0, S_CG_R, S_CG_P, S_CG_T, S_CG_PART, S_CG_CTRL, S_CG_RUNS, S_CG_REM, S_CG_NRUNS, S_CG_PS, S_CG_SEGOFF, S_CG_SEGS, S_CG_SEGPART, S_CG_XCHG, S_CG_PARTS,
+    S_CG_S = 0, S_CG_R, S_CG_P, S_CG_T, S_CG_PART, S_CG_CTRL, S_CG_RUNS, S_CG_REM, S_CG_NRUNS, S_CG_PS, S_CG_SEGOFF, S_CG_SEGS, S_CG_SEGPART, S_CG_XCHG, S_CG_PARTS, S_CG_S2R, S_CG_TDENSE, S_CG_TOFF, S_CG_NSEGS, S_CG_TILES, S_CG_ROWPART, S_CG_COLPART, S_CG_CSUM, S_CG_LSR, S_CG_GOFF, S_CG_SRP, S_CG_SVAL, S_CG_SCOL, S_CG_GVAL, S_CG_GCOL, S_CG_LMETA,
     S_K_DATA, S_K_RHS,
     S_PW_LIST, S_PW_CNT,
     S_EV_PROB, S_EV_ROWSUM, S_EV_G2, S_EV_G3, S_EV_CTRL, S_EV_UNI, S_EV_LOG,

@@ -73,6 +73,10 @@ typedef struct dkmc_stats {
     long long comm_count_per_rank;
     double comm_ms;
     int comm_launches, comm_pad;
+    /* symmetric tiles of the last CG solve on X: 32 x 256 blocks of the tunnelling block read once for both triangles
+     * (same launch as the segments) */
+    int spmv_tiles, spmv_pad2;
+    long long spmv_tile_entries;
 } dkmc_stats;
 
 const char *dkmc_last_error(void);
@@ -94,6 +98,11 @@ void dkmc_set_current_warm_start(int mode);
 /* 1: bracket every SpMV launch of the CG solves with HIP events on the engine's stream and accumulate
  * their durations into dkmc_stats (measurement aid for bench.py; off by default) */
 void dkmc_set_profiling(int on);
+/* 1 (default): the CG on X reads the dense blocks of its symmetric tunnelling part once per iteration for both triangles
+ * ("symmetric tiles") when at least 80 % of X sits in such blocks; 0: every stored entry is read, the
+ * arithmetic of the sharded solve (which never uses tiles).  Both agree to rounding (a_ij s_i s_j is formed in a different
+ * order for the two triangles). */
+void dkmc_set_symmetric_tiles(int on);
 
 /* ---- GPUBuffers (gpu_buffers.h:73-158, gpu_buffers.cpp:10-118) ---------------------------- */
 /* allocates every array of the struct with hipMalloc and uploads the constant ones */

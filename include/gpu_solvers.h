@@ -102,3 +102,22 @@ inline void update_temperatureglobal_gpu(const double *site_power, double *T_bg,
 {
     GPUBuffers::report(dkmc_update_temperatureglobal_gpu(site_power, T_bg, N, a_coeff, b_coeff, number_steps, C_thermal, small_step));
 }
+
+// ---- additions without a counterpart in the reference's gpu_solvers.h ------------------------------------------------------
+// Local temperature model: the reference keeps it on the host with dense inverses (heat_solver.cpp:40-246, 286-308, 354-513).
+// Device::constructLaplacian would call the first (N_left_tot / N_right_tot from get_num_in_contacts, gamma from :86), the
+// local branch of Device::updateTemperature the second; both work on the GPUBuffers arrays.
+inline void construct_laplacian_gpu(GPUBuffers &gpubuf, const int N_left_tot, const int N_right_tot, const double gamma)
+{
+    GPUBuffers::report(dkmc_construct_laplacian(&gpubuf, N_left_tot, N_right_tot, gamma));
+}
+
+inline double update_temperature_local_gpu(GPUBuffers &gpubuf, const double step_time, const double delta_t, const double tau,
+                                           const double background_temp, const double k_th_interface, const double k_th_vacancies,
+                                           const double nn_dist, const int num_atoms_contact)
+{
+    double T_bg = background_temp;
+    GPUBuffers::report(dkmc_update_temperature_local(&gpubuf, step_time, delta_t, tau, background_temp, k_th_interface, k_th_vacancies,
+                                                     nn_dist, num_atoms_contact, nullptr, nullptr, nullptr, &T_bg));
+    return T_bg;
+}

@@ -24,10 +24,12 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _supersteps(nsteps, seed=1):
-    """nsteps supersteps of the 2.5 nm device from a fresh state; returns everything a caller of the path can observe."""
+def _supersteps(nsteps, seed=1, tiles=0):
+    """nsteps supersteps of the 2.5 nm device from a fresh state; returns everything a caller of the path can observe.
+    tiles=0: the single-GPU solve reads every stored entry (the arithmetic the sharded solve reproduces bit for bit)."""
     import torch
-    from devicekmc_amd import host, params, structure
+    from devicekmc_amd import host, lib, params, structure
+    lib.load().dkmc_set_symmetric_tiles(tiles)
     g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     s = structure.load_structure(os.path.join(g, "device_2.5nm.npz"))
     p = params.KMCParameters(); p.solve_heating_global = True; p.rnd_seed_kmc = seed
@@ -54,12 +56,13 @@ def _worker(rank, world, port, q):
     parallel.init("gloo")
     torch.cuda.set_device(0)
     ref = _supersteps(NSTEPS) if rank == 0 else None           # single-GPU path, no communicator
+    ref_tiles = _supersteps(NSTEPS, tiles=1) if rank == 0 else None    # default single-GPU arithmetic (symmetric tiles)
     parallel.barrier()
     assert parallel.attach_solver_comm() == "host"
     got = _supersteps(NSTEPS)
     parallel.detach_solver_comm()
     parallel.barrier()
-    q.put((rank, ref, got))
+    q.put((rank, ref, got, ref_tiles))
     parallel.finalize()
 
 
@@ -73,7 +76,7 @@ def test_two_ranks_lockstep_bit_identical():
     for p in procs: p.start()
     out = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
     for p in procs: p.join(120); assert p.exitcode == 0
-    (_, ref, got0), (_, _, got1) = out
+    (_, ref, got0, ref_tiles), (_, _, got1, _) = out
     rtrace, riters, rfields, _ = ref
     for rank, (trace, iters, fields, st) in enumerate((got0, got1)):
         assert trace == rtrace, (rank, trace, rtrace)                 # dt, I_macro, T_bg of every step: exact
@@ -81,6 +84,10 @@ def test_two_ranks_lockstep_bit_identical():
         for n in rfields:
             assert np.array_equal(fields[n], rfields[n]), (rank, n)   # every field a caller can read back: bit-identical
         assert st["comm_ranks"] == 2 and st["comm_count_per_rank"] % 2 == 0
+    # against the default single-GPU arithmetic (symmetric tiles): same events, fields equal to rounding
+    for (dt, im, tb), (dt2, im2, tb2) in zip(rtrace, ref_tiles[0]):
+        assert abs(dt - dt2) <= 1e-9 * dt and abs(im - im2) <= 1e-9 * abs(im) and abs(tb - tb2) <= 1e-9 * tb
+    assert np.array_equal(rfields["site_element"], ref_tiles[2]["site_element"])
     nseg = got0[3]["spmv_segments"]
     assert got0[3]["comm_local_segments"] + got1[3]["comm_local_segments"] == nseg > 0      # the ranks split the segments
     assert abs(got0[3]["comm_local_segments"] - got1[3]["comm_local_segments"]) <= 64      # balanced up to one row
@@ -100,6 +107,7 @@ def test_rccl_transport_one_rank():
         got = _supersteps(2)
     finally:
         parallel.detach_solver_comm()
+        lib.load().dkmc_set_symmetric_tiles(1)
     assert got[0] == ref[0] and got[1] == ref[1]
     for name in ref[2]:
         assert np.array_equal(got[2][name], ref[2][name]), name

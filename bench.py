@@ -171,14 +171,17 @@ def main():
         nnz_all = st["spmv_long_nnz"] + st["spmv_short_nnz"]
         rows_all = st["spmv_long_rows"] + st["spmv_short_rows"]
         if st["spmv_segments"] > 0:
-            # dense-run mode: the dominant kernel is k_spmv_segs (one wave per <= 2048-entry segment of a tunnelling row);
-            # its layout moves 8 B per entry (value only; the direction vector is compacted over S and stays in L2),
-            # 16 B per segment descriptor and 8 B per segment result.  The CSR formulation of the same product
-            #  would move 12 B per entry.
+            # dense-run mode: the dominant kernel is k_spmv_segs (one wave per <= 2048-entry segment of a tunnelling row, and
+            # one wave per symmetric tile); its layout moves 8 B per entry read (value only; the direction vector is
+            # compacted over S and stays in L2), 16 B per segment descriptor and 8 B per segment result.  The CSR
+            # formulation of the same product would move 12 B per stored entry.
             kname = "k_spmv_segs"
             # the same launch also carries the short rows of X in CSR form (12 B per non-zero + 24 B per row)
             bytes_per_launch = (8.0 * st["spmv_segment_entries"] + 24.0 * st["spmv_segments"]
                                 + 12.0 * st["spmv_short_nnz"] + 24.0 * st["spmv_short_rows"])
+            # symmetric tiles (same launch): 8 B per entry of a 32 x 256 tile, read once for both triangles, + per tile its
+            # 272 B descriptor and the partial sums it writes (32 row sums, one column sum per column)
+            bytes_per_launch += 8.0 * st["spmv_tile_entries"] + st["spmv_tiles"] * (272.0 + 32 * 8.0) + 8.0 * st["spmv_tile_entries"] / 32.0
             csr_equiv = 12.0 * nnz_all + 24.0 * rows_all
         else:
             kname = "k_spmv_ap"
@@ -197,6 +200,8 @@ def main():
                 "avg_launch_us": round(avg_ms * 1e3, 2), "launches": prof["long_n"],
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "csr_equivalent_GBps": round(csr_equiv / (avg_ms * 1e-3) / 1e9, 1),
+                "symmetric_tiles": int(st["spmv_tiles"]), "tile_entries": int(st["spmv_tile_entries"]),
+                "segment_entries": int(st["spmv_segment_entries"]),
                 "row_kernel_us": round(prof["short_ms"] / max(prof["short_n"], 1) * 1e3, 2)}
 
     # ---- CPU baseline: the oracle (own OpenMP port of the same step) on this box's host cores, rank 0, N=1 only ----

@@ -179,9 +179,9 @@ def main():
             # the same launch also carries the short rows of X in CSR form (12 B per non-zero + 24 B per row)
             bytes_per_launch = (8.0 * st["spmv_segment_entries"] + 24.0 * st["spmv_segments"]
                                 + 12.0 * st["spmv_short_nnz"] + 24.0 * st["spmv_short_rows"])
-            # symmetric tiles (same launch): 8 B per entry of a 32 x 256 tile, read once for both triangles, + per tile its
-            # 272 B descriptor and the partial sums it writes (32 row sums, one column sum per column)
-            bytes_per_launch += 8.0 * st["spmv_tile_entries"] + st["spmv_tiles"] * (272.0 + 32 * 8.0) + 8.0 * st["spmv_tile_entries"] / 32.0
+            # symmetric tiles (same launch): each tile is 32 x 256 doubles of tile-major storage (zero where X has no entry), read
+            # once for both triangles, + its 8 B descriptor and the partial sums it writes (32 row sums, 256 column sums)
+            bytes_per_launch += st["spmv_tiles"] * (32 * 256 * 8.0 + 8.0 + 32 * 8.0 + 256 * 8.0)
             csr_equiv = 12.0 * nnz_all + 24.0 * rows_all
         else:
             kname = "k_spmv_ap"

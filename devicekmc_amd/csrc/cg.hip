@@ -43,12 +43,15 @@ enum { M_SCALE = 0, M_INIT = 1, M_AP = 2, M_DIAG = 3 };
 struct __attribute__((aligned(16))) RunDesc { long long pos; int len, sr0; };   // sr0 < 0: gather segment of long row -1-sr0
 // per long row, everything stage 2 needs in one 16-byte load (tile mode)
 struct __attribute__((aligned(16))) LRowMeta { int sr, nseg, segoff, row, wbeg, wend, kend, pad; };   // [wbeg, wend): windows of the row block's tiles; kend: 1 + last row block with a tile in the row's window
-// symmetric tiles of the tunnelling block (see k_tile_flags)
+// symmetric tiles of the tunnelling block (see k_tile_count)
 #define SEGK_NT 256            // workgroup of k_spmv_segs / k_spmv_tiles: 4 waves, one work item each
 #define TILE_SEG_LEN 256       // tile mode: what the tiles leave behind is cut into pieces of at most this many entries (16 lanes each)
 #define TILE_R 32
 #define TILE_C 256
-struct TileDesc { int k, w, ncols, pad; long long pos[TILE_R]; };     // S-rows [32k, 32k+32) x S-cols [256w, 256w+ncols)
+struct TileDesc { int k, w; };     // S-rows [32k, 32k+32) x S-cols [256w, 256w+256); values in tile-major storage, zero where X has no entry
+#define TILE_MIN_FILL 0.1      // a grid cell becomes a tile when at least this fraction of its slots holds an entry.  In bytes the break-even is 0.5, but
+                               // what a rejected cell leaves behind are short latency-bound pieces: measured at 235 k sites 333 us per launch at 0.6,
+                               // 256 us at 0.3, 241 us at 0.1 (runs only: 444 us)
 
 // block-uniform read of the stop flag (only the last kernel of an iteration ever sets it)
 __device__ __forceinline__ bool cg_done(const CgCtrl *ctrl)
@@ -446,15 +449,105 @@ __global__ __launch_bounds__(256) void k_compact_segs(int n_long, const int *__r
 }
 
 // ---- symmetric tiles of the tunnelling block --------------------------------------------------------------------------------
-// X is symmetric and its tunnelling block is dense by classes (contact x contact, vacancy x contact: every pair present), so
-// nearly every long-run entry a_ij has its mirror a_ji stored in row j.  A *tile* is TILE_R (32) consecutive S-rows x one TILE_C (256) wide
-// window of S-columns strictly above the diagonal that is completely dense AND whose mirror (the window's rows x the 32
-// columns) is completely dense: the tile's values are read ONCE per iteration and yield both the row products (t_i += a_ij p_j)
-// and the column products (t_j += a_ij p_i); the mirror entries are cut out of their rows' segment lists and never read in
-// the loop.  Everything that is not in such a tile (sparse parts near the diagonal, ragged edges, rows 0/1) stays in the
-// segment path, both triangles.  The values stay where they are (CSR order): a tile is 32 strips of 256 contiguous values
-// (64 KiB per wave); its partial results are 32 row sums and 256 column sums (3.5 % of the bytes read), combined in stage 2.
+// X is symmetric and its tunnelling block is dense by classes (contact x contact, vacancy x contact: nearly every pair present), so
+// nearly every long-run entry a_ij has its mirror a_ji stored in row j.  The S x S part is covered by a grid of TILE_R (32) S-rows x
+// TILE_C (256) S-columns; a cell strictly above the diagonal becomes a *tile* when it is at least TILE_MIN_FILL full and its
+// mirror cell holds exactly as many entries.  The values of a tile are copied (after the Jacobi scaling) into tile-major storage,
+// 32 strips of 256 doubles, zero where X has no entry: one wave reads the 64 KiB once per iteration and forms both the row
+// products (t_i += a_ij p_j) and the column products (t_j += a_ij p_i).  All entries of X inside a tile's cell, and all mirror
+// entries inside its mirror cell, are cut out of their rows' segment lists and are never read in the loop.  Everything else
+// (cells near the diagonal, sparse cells, rows 0/1, columns outside S) stays in the segment path, both triangles.
+// Partial sums: 32 row sums and 256 column sums per tile (3.5 % of the bytes read), combined in stage 2.
+template <typename RP>
+__device__ __forceinline__ const RunDesc *row_runs(int ridx, const int *long_rows, const RP *rp, const RunDesc *runs)
+{
+    return runs + ((long long)(rp[long_rows[ridx]] / RUN_MIN_LEN) + ridx);
+}
+__device__ __forceinline__ bool cell_eligible(int k, int w) { return w * TILE_C >= k * TILE_R + TILE_R; }      // strictly above the diagonal
 
+// entries per grid cell (choice heuristic): cntU[k * nW + w] = entries of the upper long runs of the rows of block k inside window w.
+// One thread per long row; integer atomics (order-independent).
+template <typename RP>
+__global__ __launch_bounds__(256) void k_tile_count(int n_long, const int *__restrict__ long_rows, const RP *__restrict__ rp, const int *__restrict__ srank,
+                                                    const RunDesc *__restrict__ runs, const int *__restrict__ nruns, int nW, int *__restrict__ cntU)
+{
+    const int ridx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ridx >= n_long) return;
+    const int s = srank[long_rows[ridx]];
+    if (s < 0) return;
+    const RunDesc *rr = row_runs(ridx, long_rows, rp, runs);
+    const int n = nruns[ridx], k = s / TILE_R;
+    for (int q = 0; q < n; ++q) {
+        const RunDesc d = rr[q];
+        if (d.sr0 < 0 || d.sr0 <= s) continue;
+        const int lo = d.sr0, hi = d.sr0 + d.len;
+        for (int w = lo / TILE_C; w * TILE_C < hi; ++w)
+            if (cell_eligible(k, w)) atomicAdd(&cntU[(long long)k * nW + w], min(hi, w * TILE_C + TILE_C) - max(lo, w * TILE_C));
+    }
+}
+
+// choose[cell] = 1 when the cell becomes a tile; covered[cell] = entries of X it takes out of the segment path (both triangles)
+__global__ void k_tile_choose(int ns, int nK, int nW, double min_fill, const int *__restrict__ cntU, int *__restrict__ choose, int *__restrict__ covered)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nK * nW) return;
+    const int k = (int)(i / nW), w = (int)(i % nW);
+    const bool ok = cell_eligible(k, w) && (double)cntU[i] >= min_fill * TILE_R * TILE_C;
+    choose[i] = ok ? 1 : 0;
+    covered[i] = ok ? 2 * cntU[i] : 0;
+}
+// Is the S x S entry (row rank s, column rank sc) inside a tile?  Returns the cell index or -1; upper = entry above the diagonal.
+__device__ __forceinline__ long long tiled_cell(int s, int sc, int nW, const int *__restrict__ choose, bool &upper)
+{
+    if (s < 0 || sc < 0 || s == sc) return -1;
+    upper = sc > s;
+    const int k = (upper ? s : sc) / TILE_R, w = (upper ? sc : s) / TILE_C;
+    if (!cell_eligible(k, w)) return -1;
+    const long long cell = (long long)k * nW + w;
+    return choose[cell] ? cell : -1;
+}
+__global__ void k_tile_list(int nK, int nW, const int *__restrict__ choose, const int *__restrict__ toff, TileDesc *__restrict__ tiles)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (long long)nK * nW && choose[i]) { TileDesc d; d.k = (int)(i / nW); d.w = (int)(i % nW); tiles[toff[i]] = d; }
+}
+
+// copy the (scaled) values of the upper entries inside tiles into the tile-major storage; one wave per long row
+template <typename RP>
+__global__ __launch_bounds__(256) void k_tile_scatter(int n_long, const int *__restrict__ long_rows, const RP *__restrict__ rp, const int *__restrict__ srank,
+                                                      const RunDesc *__restrict__ runs, const int *__restrict__ nruns, int nW,
+                                                      const int *__restrict__ choose, const int *__restrict__ toff, const double *__restrict__ a,
+                                                      double *__restrict__ tval, int *__restrict__ chk)
+{
+    const int lane = threadIdx.x & 63;
+    const int ridx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (ridx >= n_long) return;
+    const int s = srank[long_rows[ridx]];
+    if (s < 0) return;
+    const RunDesc *rr = row_runs(ridx, long_rows, rp, runs);
+    const int n = nruns[ridx], k = s / TILE_R;
+    for (int q = 0; q < n; ++q) {
+        const RunDesc d = rr[q];
+        if (d.sr0 < 0 || d.sr0 <= s) continue;                       // upper runs only
+        const int lo = d.sr0, hi = d.sr0 + d.len;
+        for (int w = lo / TILE_C; w * TILE_C < hi; ++w) {
+            const long long cell = (long long)k * nW + w;
+            if (!choose[cell]) continue;
+            const int c0 = max(lo, w * TILE_C), c1 = min(hi, w * TILE_C + TILE_C);
+            double *dst = tval + ((size_t)toff[cell] * TILE_R + (s % TILE_R)) * TILE_C - (size_t)w * TILE_C;
+            const double *src = a + d.pos - lo;
+            for (int c = c0 + lane; c < c1; c += 64) dst[c] = src[c];
+            if (lane == 0) atomicAdd(&chk[cell], c1 - c0);              // upper entries put into the tile (balanced by the mirror entries removed)
+        }
+    }
+}
+
+// lsr: long-row index -> S-rank (or -1)
+__global__ void k_lsr(int n_long, const int *__restrict__ long_rows, const int *__restrict__ srank, int *__restrict__ lsr)
+{
+    const int ridx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ridx < n_long) lsr[ridx] = srank[long_rows[ridx]];
+}
 // per row block: range of windows that hold a tile; per window: 1 + the last row block that holds a tile (0 = none)
 __global__ void k_tile_ranges(int nK, int nW, const int *__restrict__ dense, int *__restrict__ wbeg, int *__restrict__ wend, int *__restrict__ kend)
 {
@@ -480,66 +573,6 @@ __global__ void k_lrow_meta(int n_long, const int *__restrict__ long_rows, const
     if (m.sr >= 0) { m.wbeg = wbeg[m.sr / TILE_R]; m.wend = wend[m.sr / TILE_R]; m.kend = kend[m.sr / TILE_C]; }
     meta[ridx] = m;
 }
-// s2r: S-rank -> long-row index (or -1, preset); lsr: long-row index -> S-rank (or -1)
-__global__ void k_s2r(int n_long, const int *__restrict__ long_rows, const int *__restrict__ srank, int *__restrict__ s2r, int *__restrict__ lsr)
-{
-    const int ridx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ridx < n_long) { const int sr = srank[long_rows[ridx]]; lsr[ridx] = sr; if (sr >= 0) s2r[sr] = ridx; }
-}
-
-template <typename RP>
-__device__ __forceinline__ const RunDesc *row_runs(int ridx, const int *long_rows, const RP *rp, const RunDesc *runs)
-{
-    return runs + ((long long)(rp[long_rows[ridx]] / RUN_MIN_LEN) + ridx);
-}
-// position (index into a) of S-column `lo` in long row ridx if one of its raw runs covers [lo, hi); -1 otherwise
-template <typename RP>
-__device__ __forceinline__ long long run_covering(int ridx, int lo, int hi, const int *long_rows, const RP *rp, const RunDesc *runs, const int *nruns)
-{
-    const RunDesc *rr = row_runs(ridx, long_rows, rp, runs);
-    const int n = nruns[ridx];
-    for (int q = 0; q < n; ++q) {
-        const RunDesc d = rr[q];
-        if (d.sr0 >= 0 && d.sr0 <= lo && d.sr0 + d.len >= hi) return d.pos + (lo - d.sr0);
-    }
-    return -1;
-}
-
-// one wave per candidate tile (k, w): dense[k * nW + w] = 1 iff the tile and its mirror are completely present
-template <typename RP>
-__global__ __launch_bounds__(256) void k_tile_flags(int ns, int nK, int nW, const int *__restrict__ s2r, const int *__restrict__ long_rows,
-                                                    const RP *__restrict__ rp, const RunDesc *__restrict__ runs, const int *__restrict__ nruns,
-                                                    int *__restrict__ dense)
-{
-    const int lane = threadIdx.x & 63;
-    const long long tid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tid >= (long long)nK * nW) return;
-    const int k = (int)(tid / nW), w = (int)(tid % nW);
-    const int r0 = k * TILE_R, c0 = w * TILE_C;
-    bool ok = (r0 + TILE_R <= ns) && (c0 >= r0 + TILE_R);          // whole row block, strictly above the diagonal
-    if (ok) {
-        const int ncols = min(TILE_C, ns - c0);
-        if (lane < TILE_R) { const int ridx = s2r[r0 + lane]; ok = ridx >= 0 && run_covering(ridx, c0, c0 + ncols, long_rows, rp, runs, nruns) >= 0; }
-        for (int c = lane; c < ncols && ok; c += 64) { const int ridx = s2r[c0 + c]; ok = ridx >= 0 && run_covering(ridx, r0, r0 + TILE_R, long_rows, rp, runs, nruns) >= 0; }
-    }
-    const bool all_ok = __ballot(!ok) == 0ull;
-    if (lane == 0) dense[tid] = all_ok ? 1 : 0;
-}
-
-template <typename RP>
-__global__ __launch_bounds__(256) void k_tile_desc(int ns, int nK, int nW, const int *__restrict__ dense, const int *__restrict__ toff, const int *__restrict__ s2r,
-                                                   const int *__restrict__ long_rows, const RP *__restrict__ rp, const RunDesc *__restrict__ runs,
-                                                   const int *__restrict__ nruns, TileDesc *__restrict__ tiles)
-{
-    const int lane = threadIdx.x & 63;
-    const long long tid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tid >= (long long)nK * nW || !dense[tid]) return;
-    const int k = (int)(tid / nW), w = (int)(tid % nW);
-    TileDesc *d = tiles + toff[tid];
-    const int c0 = w * TILE_C, ncols = min(TILE_C, ns - c0);
-    if (lane == 0) { d->k = k; d->w = w; d->ncols = ncols; d->pad = 0; }
-    if (lane < TILE_R) d->pos[lane] = run_covering(s2r[k * TILE_R + lane], c0, c0 + ncols, long_rows, rp, runs, nruns);
-}
 
 // Segment list of one long row = its raw runs minus everything the tiles cover, cut into <= seg_len pieces, followed by its
 // gather segments.  One thread per row; FILL = 0 counts, FILL = 1 writes at seg_off[ridx].
@@ -547,7 +580,7 @@ template <int FILL, typename RP>
 __global__ __launch_bounds__(256) void k_emit_segs(int n_long, const int *__restrict__ long_rows, const RP *__restrict__ rp, const int *__restrict__ srank,
                                                    const RunDesc *__restrict__ runs, const int *__restrict__ nruns, int ns, int nW,
                                                    const int *__restrict__ dense, int seg_len, int *__restrict__ nsegs, const int *__restrict__ seg_off,
-                                                   RunDesc *__restrict__ segs, const int *__restrict__ goff)
+                                                   RunDesc *__restrict__ segs, const int *__restrict__ goff, int *__restrict__ chk)
 {
     const int ridx = blockIdx.x * blockDim.x + threadIdx.x;
     if (ridx >= n_long) return;
@@ -578,24 +611,24 @@ __global__ __launch_bounds__(256) void k_emit_segs(int n_long, const int *__rest
         if (s < 0 || dense == nullptr) { emit(d.pos, lo, d.len); continue; }
         int start = lo;                                                         // start of the current untiled stretch
         if (lo > s) {
-            // upper run: a window is skipped when tile (s/TILE_R, w) exists; dense tiles are whole windows inside this run
+            // upper run: the part inside window w is skipped when cell (s/TILE_R, w) is a tile
             const int k = s / TILE_R;
             for (int w = lo / TILE_C; w * TILE_C < hi; ++w) {
-                const int c0 = w * TILE_C, c1 = min(c0 + TILE_C, ns);
-                if (c0 >= lo && c1 <= hi && c0 >= k * TILE_R + TILE_R && dense[(long long)k * nW + w]) {
-                    if (c0 > start) emit(d.pos + (start - lo), start, c0 - start);
-                    start = c1;
-                }
+                if (!cell_eligible(k, w) || !dense[(long long)k * nW + w]) continue;
+                const int c0 = max(lo, w * TILE_C), c1 = min(hi, w * TILE_C + TILE_C);
+                if (c0 > start) emit(d.pos + (start - lo), start, c0 - start);
+                start = c1;
             }
         } else {
-            // lower run: the TILE_R columns of row block k' are skipped when tile (k', s/TILE_C) exists (this row is one of its columns)
+            // lower run: the part inside the TILE_R columns of row block k' is skipped when cell (k', s/TILE_C) is a tile (this row is
+            // one of its columns)
             const int w = s / TILE_C;
             for (int k = lo / TILE_R; k * TILE_R < hi; ++k) {
-                const int c0 = k * TILE_R, c1 = c0 + TILE_R;
-                if (c0 >= lo && c1 <= hi && w * TILE_C >= c1 && dense[(long long)k * nW + w]) {
-                    if (c0 > start) emit(d.pos + (start - lo), start, c0 - start);
-                    start = c1;
-                }
+                if (!cell_eligible(k, w) || !dense[(long long)k * nW + w]) continue;
+                const int c0 = max(lo, k * TILE_R), c1 = min(hi, k * TILE_R + TILE_R);
+                if (c0 > start) emit(d.pos + (start - lo), start, c0 - start);
+                start = c1;
+                if (FILL) atomicSub(&chk[(long long)k * nW + w], c1 - c0);      // mirror entries removed
             }
         }
         if (hi > start) emit(d.pos + (start - lo), start, hi - start);
@@ -605,17 +638,39 @@ __global__ __launch_bounds__(256) void k_emit_segs(int n_long, const int *__rest
 
 // Packed copies for the latency-bound roles of the tile-mode launch (fewer dependent loads per wave: descriptor -> packed
 // (value, column) -> p): the remainder entries of the long rows and the short rows, copied after the Jacobi scaling.
+// An entry of S x S that lies in a tile is represented by the tile alone, wherever X stores it: long runs are cut in k_emit_segs;
+// here the remainder entries and the short rows drop theirs (value 0, column 0 in the packed copy) and, for the upper ones, put
+// the value into the tile.  chk counts upper entries placed minus mirror entries removed per cell: all zero iff X is
+// structurally symmetric where it is tiled (checked on the host once per solve).
+__device__ __forceinline__ bool tile_take(int s, int sc, double v, int nW, const int *__restrict__ choose, const int *__restrict__ toff,
+                                          double *__restrict__ tval, int *__restrict__ chk)
+{
+    bool upper;
+    const long long cell = tiled_cell(s, sc, nW, choose, upper);
+    if (cell < 0) return false;
+    if (upper) { tval[((size_t)toff[cell] * TILE_R + (s % TILE_R)) * TILE_C + (sc % TILE_C)] = v; atomicAdd(&chk[cell], 1); }
+    else atomicSub(&chk[cell], 1);
+    return true;
+}
 template <typename RP>
 __global__ __launch_bounds__(256) void k_pack_rem(int n_long, const int *__restrict__ long_rows, const RP *__restrict__ rp, const int *__restrict__ ci,
                                                   const double *__restrict__ a, const int *__restrict__ rem, const int *__restrict__ nrem,
-                                                  const int *__restrict__ goff, double *__restrict__ gval, int *__restrict__ gcol)
+                                                  const int *__restrict__ goff, double *__restrict__ gval, int *__restrict__ gcol,
+                                                  const int *__restrict__ srank, int nW, const int *__restrict__ choose, const int *__restrict__ toff,
+                                                  double *__restrict__ tval, int *__restrict__ chk)
 {
     const int lane = threadIdx.x & 63;
     const int ridx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ridx >= n_long) return;
-    const RP p0 = rp[long_rows[ridx]];
-    const int n = nrem[ridx], o = goff[ridx];
-    for (int k = lane; k < n; k += 64) { const RP q = p0 + rem[p0 + k]; gval[o + k] = a[q]; gcol[o + k] = ci[q]; }
+    const int row = long_rows[ridx];
+    const RP p0 = rp[row];
+    const int n = nrem[ridx], o = goff[ridx], s = srank[row];
+    for (int k = lane; k < n; k += 64) {
+        const RP q = p0 + rem[p0 + k];
+        double v = a[q]; int c = ci[q];
+        if (tile_take(s, srank[c], v, nW, choose, toff, tval, chk)) { v = 0.0; c = 0; }
+        gval[o + k] = v; gcol[o + k] = c;
+    }
 }
 template <typename RP>
 __global__ void k_short_len(int n_short, const int *__restrict__ short_rows, const RP *__restrict__ rp, int *__restrict__ len)
@@ -625,14 +680,25 @@ __global__ void k_short_len(int n_short, const int *__restrict__ short_rows, con
 }
 template <typename RP>
 __global__ __launch_bounds__(256) void k_pack_short(int n_short, const int *__restrict__ short_rows, const RP *__restrict__ rp, const int *__restrict__ ci,
-                                                    const double *__restrict__ a, const int *__restrict__ srp, double *__restrict__ sval, int *__restrict__ scol)
+                                                    const double *__restrict__ a, const int *__restrict__ srp, double *__restrict__ sval, int *__restrict__ scol,
+                                                    const int *__restrict__ srank, int nW, const int *__restrict__ choose, const int *__restrict__ toff,
+                                                    double *__restrict__ tval, int *__restrict__ chk)
 {
     const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
     const int ridx = blockIdx.x * 16 + g;
     if (ridx >= n_short) return;
     const int row = short_rows[ridx];
-    const RP p0 = rp[row]; const int n = (int)(rp[row + 1] - p0), o = srp[ridx];
-    for (int k = l; k < n; k += 16) { sval[o + k] = a[p0 + k]; scol[o + k] = ci[p0 + k]; }
+    const RP p0 = rp[row]; const int n = (int)(rp[row + 1] - p0), o = srp[ridx], s = srank[row];
+    for (int k = l; k < n; k += 16) {
+        double v = a[p0 + k]; int c = ci[p0 + k];
+        if (s >= 0 && tile_take(s, srank[c], v, nW, choose, toff, tval, chk)) { v = 0.0; c = 0; }
+        sval[o + k] = v; scol[o + k] = c;
+    }
+}
+__global__ void k_chk_max(long long n, const int *__restrict__ chk, int *__restrict__ out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && chk[i] != 0) atomicMax(out, abs(chk[i]));
 }
 
 // stage 1 of the long-row product: one wave64 per segment, seg_part[seg] = sum a[pos+k] * pS[sr0+k].
@@ -646,7 +712,7 @@ __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *
                                                        int nsb, int n_short, const int *__restrict__ short_rows, const RP *__restrict__ rp,
                                                        const int *__restrict__ long_rows,
                                                        double *__restrict__ t, double *__restrict__ part,
-                                                       int ntb, int ntiles, int nW_t, const TileDesc *__restrict__ tiles,
+                                                       int ntb, int ntiles, int nW_t, int ns_t, const TileDesc *__restrict__ tiles, const double *__restrict__ tval,
                                                        double *__restrict__ rowpart, double *__restrict__ colpart,
                                                        const double *__restrict__ gval, const int *__restrict__ gcol,
                                                        const int *__restrict__ srp, const double *__restrict__ sval, const int *__restrict__ scol)
@@ -657,30 +723,28 @@ __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *
 #define LDM(ptr) (NTL ? __builtin_nontemporal_load(ptr) : *(ptr))
     if (TILES && (int)blockIdx.x < ntb) {
         // symmetric tiles (FIRST ntb blocks, so that the bandwidth-bound part of the launch starts at once and the latency-bound
-        // segment / short-row blocks fill in behind it; one wave per tile; see k_tile_flags): TILE_R strips of <= TILE_C contiguous values,
-        // read once, give the row products (one wave reduction per strip) and the column products (four columns per lane,
-        // accumulated in registers over the strips).  Only instantiated (TILES = 1) when tiles exist: the extra registers
-        // cost the segment waves occupancy, which does not matter once the tiles carry most of the matrix.
+        // segment / short-row blocks fill in behind it; one wave per tile; see k_tile_count): 32 strips of 256 values, contiguous
+        // in the tile-major storage, read once, give the row products and the column products (four columns per lane,
+        // accumulated in registers over the strips).  Only instantiated (TILES = 1) in tile mode: the extra registers cost the
+        // segment waves occupancy, which does not matter once the tiles carry most of the matrix.
         if (ctrl->done) return;
         const int lane = threadIdx.x & 63;
-        // the tile index is wave-uniform: say so, and the descriptor (strip positions) is fetched with scalar loads
+        // the tile index is wave-uniform: say so (scalar loads for the descriptor and the strip addresses)
         const int tile = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (SEGK_NT / 64) + (int)(threadIdx.x >> 6));
         if (tile >= ntiles) return;
-        const TileDesc *d = tiles + tile;
-        const int ncols = d->ncols;
-        const size_t cell = (size_t)d->k * nW_t + d->w;                    // position in the tile grid: where the partial sums go
-        const double *pc = pS + (size_t)d->w * TILE_C, *pr = pS + (size_t)d->k * TILE_R;
+        const TileDesc td = tiles[tile];
+        const size_t cell = (size_t)td.k * nW_t + td.w;                    // position in the tile grid: where the partial sums go
+        const double *pc = pS + (size_t)td.w * TILE_C, *pr = pS + (size_t)td.k * TILE_R;
+        const int ncols = min(TILE_C, ns_t - td.w * TILE_C);               // the last window may be narrower (its slots beyond are zero)
+        const double *tv = tval + (size_t)tile * TILE_R * TILE_C;
         double pcx[2], pcy[2], cax[2], cay[2];
-        int ix[2], iy[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int col = 2 * lane + 128 * u;
             pcx[u] = col < ncols ? pc[col] : 0.0; pcy[u] = col + 1 < ncols ? pc[col + 1] : 0.0;
-            ix[u] = min(col, ncols - 1); iy[u] = min(col + 1, ncols - 1);      // clamped: out-of-window lanes re-read the last column,
-            cax[u] = 0.0; cay[u] = 0.0;                                          // multiply it by 0 and never store their column sums
+            cax[u] = 0.0; cay[u] = 0.0;
         }
-        // Strips in 4 phases of 8 (a real loop, so that the register budget stays at one phase): the 32 loads of a phase (8-byte
-        // loads -- a strip starts at any element of its row, so its 16-byte alignment varies -- with clamped indices, no branches)
+        // Strips in 4 phases of 8 (a real loop, so that the register budget stays at one phase): the 16 16-byte loads of a phase
         // are issued together, 16 KiB in flight per wave.  Row sums: 32 sums over 64 lanes with 32 shuffles instead of 32 x 6.  In
         // every butterfly step a lane keeps the half of its values whose index bit matches its lane bit and adds the partner's:
         // xor 32, 16, 8 fold the 8 strips of a phase into one value per lane, xor 4, 2 fold the 4 phases, xor 1 completes the sum.
@@ -691,8 +755,9 @@ __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *
             double x0[8], y0[8], x1[8], y1[8], ra[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const double *strip = a + d->pos[8 * ph + q];
-                x0[q] = LDM(strip + ix[0]); y0[q] = LDM(strip + iy[0]); x1[q] = LDM(strip + ix[1]); y1[q] = LDM(strip + iy[1]);
+                const dbl2 *strip = reinterpret_cast<const dbl2 *>(tv + (size_t)(8 * ph + q) * TILE_C);
+                const dbl2 v0 = LDM(strip + lane), v1 = LDM(strip + 64 + lane);
+                x0[q] = v0.x; y0[q] = v0.y; x1[q] = v1.x; y1[q] = v1.y;
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -742,14 +807,14 @@ __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *
             // times the number of wave rounds: 8 lanes per row (the rows average 17 entries) from the packed copy, one row per
             // group and launch, so that half as many waves go through the descriptor -> (value, column) -> p chain once
             const int g8 = threadIdx.x >> 3, l8 = threadIdx.x & 7;
-            const int ridx = (bid - nsb) * (SEGK_NT / 8) + g8;
+            const int nb8 = gridDim.x - nsb - ntb;
             double acc = 0.0;
-            if (ridx < n_short) {
+            for (int ridx = (bid - nsb) * (SEGK_NT / 8) + g8; ridx < n_short; ridx += nb8 * (SEGK_NT / 8)) {      // one pass unless the grid is capped
                 const int q0 = srp[ridx], q1 = srp[ridx + 1];
                 double s = 0.0;
                 for (int q = q0 + l8; q < q1; q += 8) s += sval[q] * p[scol[q]];
                 s += __shfl_xor(s, 4, 8); s += __shfl_xor(s, 2, 8); s += __shfl_xor(s, 1, 8);
-                if (l8 == 0) { const int row = short_rows[ridx]; t[row] = s; acc = p[row] * s; }
+                if (l8 == 0) { const int row = short_rows[ridx]; t[row] = s; acc += p[row] * s; }
             }
             const double tot = block_sum_all<SEGK_NT>(acc, red);
             if (threadIdx.x == 0) part[bid - nsb] = tot;
@@ -925,16 +990,17 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
     static const int seg_len = getenv("DKMC_SEG_LEN") ? (atoi(getenv("DKMC_SEG_LEN")) < 2 * RUN_MIN_LEN ? 2 * RUN_MIN_LEN : atoi(getenv("DKMC_SEG_LEN"))) : SEG_LEN;
     const bool use_runs = use_runs_env && srank && n_long > 0 && ns > 0;
     RunDesc *runs = nullptr, *segs = nullptr; int *nruns = nullptr, *rem = nullptr, *nrem = nullptr, *seg_off = nullptr; double *pS = nullptr, *seg_part = nullptr;
+    static const double tile_min_fill = getenv("DKMC_TILE_FILL") ? atof(getenv("DKMC_TILE_FILL")) : TILE_MIN_FILL;
     static const double tile_min_cover = getenv("DKMC_TILE_COVER") ? atof(getenv("DKMC_TILE_COVER")) : 0.8;   // fraction of X that must sit in tiles
     bool use_tiles = false; int nK = 0, nW = 0, ntiles = 0; int *dense = nullptr, *toff = nullptr, *nsegs = nullptr;
-    TileDesc *tiles = nullptr; double *rowpart = nullptr, *colpart = nullptr; int *trange = nullptr, *lsr = nullptr, *goff = nullptr, *gcol = nullptr, *srp = nullptr, *scol = nullptr;
+    TileDesc *tiles = nullptr; double *rowpart = nullptr, *colpart = nullptr, *tval = nullptr; int *trange = nullptr, *lsr = nullptr, *chk = nullptr, *goff = nullptr, *gcol = nullptr, *srp = nullptr, *scol = nullptr;
     double *gval = nullptr, *sval = nullptr; LRowMeta *lmeta = nullptr;
     int nseg = 0, nseg_loc = 0, seg_lo = 0; bool sharded = false; RowParts parts{}, *dparts = nullptr; double *xbuf = nullptr;
     if (use_runs) {
         runs = (RunDesc *)scratch(S_CG_RUNS, ((size_t)nnz / RUN_MIN_LEN + n_long + 2) * sizeof(RunDesc));
         rem = (int *)scratch(S_CG_REM, (size_t)nnz * 4);
         nruns = (int *)scratch(S_CG_NRUNS, (size_t)n_long * 2 * 4);
-        pS = (double *)scratch(S_CG_PS, (size_t)ns * 8);
+        pS = (double *)scratch(S_CG_PS, (size_t)(ns + TILE_C) * 8);      // + zero padding for the last tile row block / window
         if (!runs || !rem || !nruns || !pS) return e.err_code;
         nrem = nruns + n_long;
         // symmetric tiles (single-GPU solves; the sharded solve keeps the plain segment path and its bit-identity guarantee)
@@ -949,49 +1015,53 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
             nK = (ns + TILE_R - 1) / TILE_R; nW = (ns + TILE_C - 1) / TILE_C;
             const long long ncand = (long long)nK * nW;
             if (ncand > 0x7fffff00ll) return dkmc_fail(47, "CG: too many tile candidates", __FILE__, __LINE__);
-            int *s2r = (int *)scratch(S_CG_S2R, (size_t)ns * 4);
             dense = (int *)scratch(S_CG_TDENSE, (size_t)(ncand + 4) * 4);
             toff = (int *)scratch(S_CG_TOFF, (size_t)(ncand + 4) * 4);
             nsegs = (int *)scratch(S_CG_NSEGS, (size_t)(n_long + 4) * 4);
-            if (!s2r || !dense || !toff || !nsegs) return e.err_code;
             lsr = (int *)scratch(S_CG_LSR, (size_t)(n_long + 4) * 4);
-            if (!lsr) return e.err_code;
-            HIPCHK(hipMemsetAsync(s2r, 0xff, (size_t)ns * 4, st));
-            hipLaunchKernelGGL(k_s2r, dim3((n_long + 255) / 256), dim3(256), 0, st, n_long, long_rows, srank, s2r, lsr);
-            const int tb = (int)((ncand + 3) / 4);
-            hipLaunchKernelGGL((k_tile_flags<RP>), dim3(tb), dim3(256), 0, st, ns, nK, nW, (const int *)s2r, long_rows, rp, (const RunDesc *)runs,
-                               (const int *)nruns, dense);
+            int *cnt = (int *)scratch(S_CG_S2R, (size_t)(3 * ncand + 8) * 4);                 // cntU | symmetry check | covered
+            long long *cov = (long long *)scratch(S_MISC3, (size_t)(ncand + 4) * 8);
+            if (!dense || !toff || !nsegs || !lsr || !cnt || !cov) return e.err_code;
+            HIPCHK(hipMemsetAsync(cnt, 0, (size_t)(2 * ncand) * 4, st));
+            hipLaunchKernelGGL(k_lsr, dim3((n_long + 255) / 256), dim3(256), 0, st, n_long, long_rows, srank, lsr);
+            chk = cnt + ncand;
+            hipLaunchKernelGGL((k_tile_count<RP>), dim3((n_long + 255) / 256), dim3(256), 0, st, n_long, long_rows, rp, srank, (const RunDesc *)runs,
+                               (const int *)nruns, nW, cnt);
+            hipLaunchKernelGGL(k_tile_choose, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, st, ns, nK, nW, tile_min_fill, (const int *)cnt, dense, cnt + 2 * ncand);
             rc = dkmc_exclusive_scan_i32(dense, toff, (int)ncand, toff + ncand); if (rc) return rc;
+            rc = dkmc_exclusive_scan_i32_i64(cnt + 2 * ncand, cov, (int)ncand, cov + ncand); if (rc) return rc;
+            long long covered = 0;
             HIPCHK(hipMemcpyAsync(&ntiles, toff + ncand, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(&covered, cov + ncand, sizeof(long long), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
-            // The tiles pay off when the tunnelling block is dense by classes (the reference's single devices: 95 % of X in tiles
-            // at 85 k sites).  On ragged structures (lateral tilings: 54 % at 235 k sites) the leftovers fragment into short
-            // segments and the plain segment path is faster: fall back to it.
-            if (2.0 * ntiles * TILE_R * TILE_C < tile_min_cover * (double)nnz) {
+            // Tiles pay off when they take most of X out of the segment path; otherwise the leftovers fragment into short segments
+            // and the plain segment path is faster: fall back to it.
+            if ((double)covered < tile_min_cover * (double)nnz) {
                 use_tiles = false; ntiles = 0;
                 hipLaunchKernelGGL((k_build_runs<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, ci, srank, runs, nruns, rem, nrem, seg_len, 0);
             }
+            e.stats.spmv_tile_entries = use_tiles ? covered / 2 : 0;
         }
         if (use_tiles) {
             const long long ncand = (long long)nK * nW;
-            const int tb = (int)((ncand + 3) / 4);
-            const int *s2r = (const int *)scratch(S_CG_S2R, (size_t)ns * 4);
             tiles = (TileDesc *)scratch(S_CG_TILES, (size_t)(ntiles + 1) * sizeof(TileDesc));
+            tval = (double *)scratch(S_CG_TVAL, (size_t)(ntiles + 1) * TILE_R * TILE_C * 8);
             rowpart = (double *)scratch(S_CG_ROWPART, (size_t)(ncand + 1) * TILE_R * 8);      // one cell per grid position, zero where no tile
             colpart = (double *)scratch(S_CG_COLPART, (size_t)(ncand + 1) * TILE_C * 8);
             trange = (int *)scratch(S_CG_CSUM, (size_t)(2 * nK + nW + 8) * 4);
-            if (!tiles || !rowpart || !colpart || !trange) return e.err_code;
+            if (!tiles || !tval || !rowpart || !colpart || !trange) return e.err_code;
             HIPCHK(hipMemsetAsync(rowpart, 0, (size_t)ncand * TILE_R * 8, st));
             HIPCHK(hipMemsetAsync(colpart, 0, (size_t)ncand * TILE_C * 8, st));
+            HIPCHK(hipMemsetAsync(tval, 0, (size_t)ntiles * TILE_R * TILE_C * 8, st));
+            HIPCHK(hipMemsetAsync(pS + ns, 0, (size_t)TILE_C * 8, st));              // padding read by tiles of a partial last row block / window
+            hipLaunchKernelGGL(k_tile_list, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, st, nK, nW, (const int *)dense, (const int *)toff, tiles);
             hipLaunchKernelGGL(k_tile_ranges, dim3((std::max(nK, nW) + 255) / 256), dim3(256), 0, st, nK, nW, (const int *)dense, trange, trange + nK, trange + 2 * nK);
-            hipLaunchKernelGGL((k_tile_desc<RP>), dim3(tb), dim3(256), 0, st, ns, nK, nW, (const int *)dense, (const int *)toff, (const int *)s2r, long_rows, rp,
-                               (const RunDesc *)runs, (const int *)nruns, tiles);
             // packed remainder entries: offsets now, values after the Jacobi scaling
             goff = (int *)scratch(S_CG_GOFF, (size_t)(n_long + 4) * 4);
             if (!goff) return e.err_code;
             rc = dkmc_exclusive_scan_i32(nrem, goff, n_long, goff + n_long); if (rc) return rc;
             hipLaunchKernelGGL((k_emit_segs<0, RP>), dim3((n_long + 255) / 256), dim3(256), 0, st, n_long, long_rows, rp, srank, (const RunDesc *)runs,
-                               (const int *)nruns, ns, nW, (const int *)dense, TILE_SEG_LEN, nsegs, (const int *)nullptr, (RunDesc *)nullptr, (const int *)goff);
+                               (const int *)nruns, ns, nW, (const int *)dense, TILE_SEG_LEN, nsegs, (const int *)nullptr, (RunDesc *)nullptr, (const int *)goff, (int *)nullptr);
             rc = dkmc_exclusive_scan_i32(nsegs, seg_off, n_long, seg_off + n_long); if (rc) return rc;
         } else {
             rc = dkmc_exclusive_scan_i32(nruns, seg_off, n_long, seg_off + n_long); if (rc) return rc;
@@ -1029,7 +1099,7 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
         if (!segs || !seg_part) return e.err_code;
         if (use_tiles)
             hipLaunchKernelGGL((k_emit_segs<1, RP>), dim3((n_long + 255) / 256), dim3(256), 0, st, n_long, long_rows, rp, srank, (const RunDesc *)runs,
-                               (const int *)nruns, ns, nW, (const int *)dense, TILE_SEG_LEN, nsegs, (const int *)seg_off, segs, (const int *)goff);
+                               (const int *)nruns, ns, nW, (const int *)dense, TILE_SEG_LEN, nsegs, (const int *)seg_off, segs, (const int *)goff, chk);
         else
             hipLaunchKernelGGL((k_compact_segs<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, (const RunDesc *)runs,
                                (const int *)nruns, (const int *)seg_off, segs);
@@ -1044,8 +1114,7 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
     // blocks of k_spmv_segs: segments (a wave each; 16 lanes each in tile mode), tiles (a wave each), short rows (16 / 8 lanes each)
     const int nsb = use_tiles ? (nseg_loc + SEGK_NT / 16 - 1) / (SEGK_NT / 16) : (nseg_loc + SEGK_NT / 64 - 1) / (SEGK_NT / 64);
     const int ntb = (ntiles + SEGK_NT / 64 - 1) / (SEGK_NT / 64);
-    const int hsA = (use_runs && n_short > 0) ? (use_tiles ? (n_short + SEGK_NT / 8 - 1) / (SEGK_NT / 8) : grid_for(n_short, SEGK_NT / 16)) : 0;
-    if (hsA + 4 > CG_MAX_PART / 2) return dkmc_fail(48, "CG: too many short-row blocks", __FILE__, __LINE__);
+    const int hsA = (use_runs && n_short > 0) ? grid_for(n_short, use_tiles ? SEGK_NT / 8 : SEGK_NT / 16) : 0;
     if (use_runs) np_ap = hsA + hl2;
     // ---- Jacobi scaling ----
     SPMV(M_DIAG, (const double *)nullptr, s, x, y, (double *)nullptr);
@@ -1065,9 +1134,22 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
         gval = (double *)scratch(S_CG_GVAL, (size_t)(h_tot[1] + 2) * 8); gcol = (int *)scratch(S_CG_GCOL, (size_t)(h_tot[1] + 2) * 4);
         if (!sval || !scol || !gval || !gcol) return e.err_code;
         if (n_short > 0) hipLaunchKernelGGL((k_pack_short<RP>), dim3((n_short + 15) / 16), dim3(256), 0, st, n_short, short_rows, rp, ci, (const double *)a,
-                                            (const int *)srp, sval, scol);
+                                            (const int *)srp, sval, scol, srank, nW, (const int *)dense, (const int *)toff, tval, chk);
         hipLaunchKernelGGL((k_pack_rem<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, ci, (const double *)a, (const int *)rem,
-                           (const int *)nrem, (const int *)goff, gval, gcol);
+                           (const int *)nrem, (const int *)goff, gval, gcol, srank, nW, (const int *)dense, (const int *)toff, tval, chk);
+        if (ntiles > 0) {
+            hipLaunchKernelGGL((k_tile_scatter<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, srank, (const RunDesc *)runs,
+                               (const int *)nruns, nW, (const int *)dense, (const int *)toff, (const double *)a, tval, chk);
+            // every upper entry placed in a tile must have had its mirror entry removed from the segment path, cell by cell
+            const long long ncand = (long long)nK * nW;
+            int *d_bad = (int *)scratch(S_MISC1, 16), h_bad = 0;
+            if (!d_bad) return e.err_code;
+            HIPCHK(hipMemsetAsync(d_bad, 0, 4, st));
+            hipLaunchKernelGGL(k_chk_max, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, st, ncand, (const int *)chk, d_bad);
+            HIPCHK(hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (h_bad) return dkmc_fail(49, "CG: symmetric tiles: X is not structurally symmetric inside a tile (dkmc_set_symmetric_tiles(0) avoids the tiles)", __FILE__, __LINE__);
+        }
     }
     // ---- r = A y - x, p = -r ----
     SPMV(M_INIT, (const double *)y, r, x, p, part_rr);
@@ -1092,13 +1174,6 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
             HIPCHK(hipMemcpy(hs_.data(), segs, (size_t)nseg * sizeof(RunDesc), hipMemcpyDeviceToHost));
             long long tot = 0; for (auto &d : hs_) tot += d.len;
             e.stats.spmv_segment_entries = tot;
-        }
-        e.stats.spmv_tile_entries = 0;
-        if (use_tiles && ntiles > 0) {
-            std::vector<TileDesc> ht((size_t)ntiles);
-            HIPCHK(hipMemcpy(ht.data(), tiles, (size_t)ntiles * sizeof(TileDesc), hipMemcpyDeviceToHost));
-            long long tot = 0; for (auto &d : ht) tot += (long long)d.ncols * TILE_R;
-            e.stats.spmv_tile_entries = tot;
         }
     }
     // ---- iterations, launched in batches; the host polls the control block between batches ----
@@ -1137,7 +1212,7 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
             hipEvent_t e0 = pb ? evs[4 * b] : nullptr, e1 = pb ? evs[4 * b + 1] : nullptr, e2 = pb ? evs[4 * b + 2] : nullptr, e3 = pb ? evs[4 * b + 3] : nullptr;
             if (use_runs) {
 #define SEG_ARGS nseg_loc, (const RunDesc *)segs + seg_lo, (const double *)a, (const double *)pS, seg_part + seg_lo, (const CgCtrl *)ctrl, (const int *)rem, ci, \
-                 (const double *)p, nsb, n_short, short_rows, rp, long_rows, t, part_pAp, ntb, ntiles, nW, (const TileDesc *)tiles, rowpart, colpart, \
+                 (const double *)p, nsb, n_short, short_rows, rp, long_rows, t, part_pAp, ntb, ntiles, nW, ns, (const TileDesc *)tiles, (const double *)tval, rowpart, colpart, \
                  (const double *)gval, (const int *)gcol, (const int *)srp, (const double *)sval, (const int *)scol
                 const dim3 sg(nsb + hsA + ntb);
                 if (use_tiles) {       // tile role compiled in; short rows and remainder entries from their packed copies

@@ -259,6 +259,26 @@ __global__ __launch_bounds__(SPMV_NT) void k_rowsum_apply(int n_long, const int 
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
 }
 
+// Large tunnelling sets: a row's window can hold hundreds of tiles, and their column partials lie 2 KiB apart.  This pre-pass adds
+// them with coalesced reads -- one workgroup per (window, slice of the row blocks), one thread per column -- into COLSUM_SLICES
+// partial column sums per S-rank, which stage 2 then adds in slice order.
+#define COLSUM_SLICES 8
+__global__ __launch_bounds__(TILE_C) void k_tile_colsum(int ns, int nK, int nW, const int *__restrict__ kend, const double *__restrict__ colpart,
+                                                        double *__restrict__ csum, int csum_pitch, const CgCtrl *ctrl)
+{
+    if (ctrl->done) return;
+    const int w = blockIdx.x / COLSUM_SLICES, sl = blockIdx.x % COLSUM_SLICES, c = threadIdx.x;
+    const int chunk = (nK + COLSUM_SLICES - 1) / COLSUM_SLICES;
+    const int k0 = sl * chunk, k1 = min(min(k0 + chunk, nK), kend[w]);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const double *cp = colpart + (size_t)w * TILE_C + c;
+    const size_t stride = (size_t)nW * TILE_C;
+    int k = k0;
+    for (; k + 3 < k1; k += 4) { s0 += cp[k * stride]; s1 += cp[(k + 1) * stride]; s2 += cp[(k + 2) * stride]; s3 += cp[(k + 3) * stride]; }
+    for (; k < k1; ++k) s0 += cp[k * stride];
+    if (w * TILE_C + c < ns) csum[(size_t)sl * csum_pitch + w * TILE_C + c] = (s0 + s1) + (s2 + s3);
+}
+
 // stage 2 in symmetric-tile mode: t[row] = the row's segment partials + the row partials of the tiles of its row block
 // (ascending window) + the column partials of the tiles of its window (ascending row block), lane-strided over 16 lanes and
 // combined in a fixed order; launch shape of the fused stage 2.  The partial arrays are indexed by the tile GRID position
@@ -266,6 +286,7 @@ __global__ __launch_bounds__(SPMV_NT) void k_rowsum_apply(int n_long, const int 
 // descriptor every load address is known: two dependent loads per row instead of three.
 __global__ __launch_bounds__(SPMV_NT) void k_rowsum_tiles(int n_long, const LRowMeta *__restrict__ meta, const double *__restrict__ seg_part,
                                                           int nW, const double *__restrict__ rowpart, const double *__restrict__ colpart,
+                                                          const double *__restrict__ csum, int csum_pitch,
                                                           const double *__restrict__ p, double *__restrict__ t, double *__restrict__ part,
                                                           const CgCtrl *ctrl)
 {
@@ -291,7 +312,8 @@ __global__ __launch_bounds__(SPMV_NT) void k_rowsum_tiles(int n_long, const LRow
                 s += (v[0] + v[1]) + (v[2] + v[3]);
             }
             const double *cpp = colpart + (size_t)w2 * TILE_C + (mt.sr % TILE_C);
-            for (int base = l; base < mt.kend; base += 64) {
+            if (csum) { if (l < COLSUM_SLICES && mt.kend > 0) s += csum[(size_t)l * csum_pitch + mt.sr]; }      // pre-summed slices (k_tile_colsum)
+            else for (int base = l; base < mt.kend; base += 64) {
                 double v[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) { const int k2 = base + 16 * u; v[u] = k2 < mt.kend ? cpp[((size_t)k2 * nW) * TILE_C] : 0.0; }
@@ -993,7 +1015,7 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
     static const double tile_min_fill = getenv("DKMC_TILE_FILL") ? atof(getenv("DKMC_TILE_FILL")) : TILE_MIN_FILL;
     static const double tile_min_cover = getenv("DKMC_TILE_COVER") ? atof(getenv("DKMC_TILE_COVER")) : 0.8;   // fraction of X that must sit in tiles
     bool use_tiles = false; int nK = 0, nW = 0, ntiles = 0; int *dense = nullptr, *toff = nullptr, *nsegs = nullptr;
-    TileDesc *tiles = nullptr; double *rowpart = nullptr, *colpart = nullptr, *tval = nullptr; int *trange = nullptr, *lsr = nullptr, *chk = nullptr, *goff = nullptr, *gcol = nullptr, *srp = nullptr, *scol = nullptr;
+    TileDesc *tiles = nullptr; double *rowpart = nullptr, *colpart = nullptr, *tval = nullptr, *csum = nullptr; int csum_pitch = 0; int *trange = nullptr, *lsr = nullptr, *chk = nullptr, *goff = nullptr, *gcol = nullptr, *srp = nullptr, *scol = nullptr;
     double *gval = nullptr, *sval = nullptr; LRowMeta *lmeta = nullptr;
     int nseg = 0, nseg_loc = 0, seg_lo = 0; bool sharded = false; RowParts parts{}, *dparts = nullptr; double *xbuf = nullptr;
     if (use_runs) {
@@ -1050,6 +1072,11 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
             colpart = (double *)scratch(S_CG_COLPART, (size_t)(ncand + 1) * TILE_C * 8);
             trange = (int *)scratch(S_CG_CSUM, (size_t)(2 * nK + nW + 8) * 4);
             if (!tiles || !tval || !rowpart || !colpart || !trange) return e.err_code;
+            if (nK > 128) {           // many row blocks per window: pre-sum the column partials (k_tile_colsum)
+                csum_pitch = (ns + 63) & ~63;
+                csum = (double *)scratch(S_CG_CSUM2, (size_t)COLSUM_SLICES * csum_pitch * 8);
+                if (!csum) return e.err_code;
+            }
             HIPCHK(hipMemsetAsync(rowpart, 0, (size_t)ncand * TILE_R * 8, st));
             HIPCHK(hipMemsetAsync(colpart, 0, (size_t)ncand * TILE_C * 8, st));
             HIPCHK(hipMemsetAsync(tval, 0, (size_t)ntiles * TILE_R * TILE_C * 8, st));
@@ -1225,9 +1252,11 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
                 else hipExtLaunchKernelGGL((k_spmv_segs<0, RP, 4, 0>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
 #undef SEG_ARGS
                 if (use_tiles) {
+                    if (csum) hipLaunchKernelGGL(k_tile_colsum, dim3(nW * COLSUM_SLICES), dim3(TILE_C), 0, st, ns, nK, nW, (const int *)(trange + 2 * nK),
+                                                 (const double *)colpart, csum, csum_pitch, (const CgCtrl *)ctrl);
                     hipExtLaunchKernelGGL(k_rowsum_tiles, dim3(hl2), dim3(SPMV_NT), 0, st, e2, e3, 0, n_long, (const LRowMeta *)lmeta,
-                                          (const double *)seg_part, nW, (const double *)rowpart, (const double *)colpart, (const double *)p, t,
-                                          part_pAp + hsA, (const CgCtrl *)ctrl);
+                                          (const double *)seg_part, nW, (const double *)rowpart, (const double *)colpart, (const double *)csum, csum_pitch,
+                                          (const double *)p, t, part_pAp + hsA, (const CgCtrl *)ctrl);
                 } else
                 if (sharded) {
                     // row sums of the owned rows -> exchange step -> t and the p.t partials on every rank.  Every rank enqueues

@@ -843,18 +843,13 @@ __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *
             return;
         }
         const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
-        const int nb = gridDim.x - nsb - (TILES ? ntb : 0);
+        const int nb = gridDim.x - nsb;
         double acc = 0.0;
         for (int ridx = (bid - nsb) * (SEGK_NT / 16) + g; ridx < n_short; ridx += nb * (SEGK_NT / 16)) {
             const int row = short_rows[ridx];
             double s = 0.0;
-            if (TILES) {          // packed copy of the short rows: row pointer by ridx, contiguous (value, column)
-                const int q0 = srp[ridx], q1 = srp[ridx + 1];
-                for (int q = q0 + l; q < q1; q += 16) s += sval[q] * p[scol[q]];
-            } else {
-                const RP p0 = rp[row], p1 = rp[row + 1];
-                for (RP q = p0 + l; q < p1; q += 16) s += a[q] * p[ci[q]];
-            }
+            const RP p0 = rp[row], p1 = rp[row + 1];
+            for (RP q = p0 + l; q < p1; q += 16) s += a[q] * p[ci[q]];
 #pragma unroll
             for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
             if (l == 0) { t[row] = s; acc += p[row] * s; }
@@ -885,11 +880,8 @@ __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *
     const RunDesc d = segs[seg];
     if (d.sr0 < 0) {                         // gather segment: entries outside long runs (<1 % of the matrix)
         double g = 0.0;
-        if (TILES) { for (int k = lane; k < d.len; k += 64) g += gval[d.pos + k] * p[gcol[d.pos + k]]; }      // packed remainder entries
-        else {
-            const RP rowp0 = rp[long_rows[-1 - d.sr0]];
-            for (int k = lane; k < d.len; k += 64) { const RP q = rowp0 + rem[d.pos + k]; g += a[q] * p[ci[q]]; }
-        }
+        const RP rowp0 = rp[long_rows[-1 - d.sr0]];
+        for (int k = lane; k < d.len; k += 64) { const RP q = rowp0 + rem[d.pos + k]; g += a[q] * p[ci[q]]; }
         g = wave_sum(g);
         if (lane == 0) seg_part[seg] = g;
         return;

@@ -333,13 +333,11 @@ def sharded_block(names, nsteps, devname, backend, rank, world):
         finally:
             parallel.detach_solver_comm()
         t_shard = parallel.max_over_ranks(t_shard, red_dev)
-        # bit-identity is against the single-GPU solve that reads every stored entry (the sharded solve's arithmetic); the timing
-        # baseline above is the default single-GPU solve, which may use symmetric tiles (equal to rounding)
-        trace_exact = trace_single
-        if trace_shard != trace_single and st1["spmv_tiles"] > 0:
-            _, trace_exact, _ = lockstep_run(name, nsteps, devname, tiles=0)
-        same_here = 1.0 if trace_shard == trace_exact else 0.0
-        close = all(abs(a - b) <= 1e-9 * abs(b) for ta, tb in zip(trace_shard, trace_single) for a, b in zip(ta, tb))
+        # default arithmetic on both sides (symmetric tiles where they apply): the sharded solve then completes the row sums with an
+        # all-reduce and equals the single-GPU run to rounding; all ranks must hold the same bits.  (The runs-only variant,
+        # dkmc_set_symmetric_tiles(0), is bit-identical to the single-GPU run: tests/test_dist_sharded.py.)
+        same_here = 1.0 if trace_shard == trace_single else 0.0
+        close = all(abs(a - b) <= 1e-6 * abs(b) for ta, tb in zip(trace_shard, trace_single) for a, b in zip(ta, tb))
         flag = torch.tensor([same_here], dtype=torch.float64, device=red_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         traces = [None] * world
@@ -348,10 +346,11 @@ def sharded_block(names, nsteps, devname, backend, rank, world):
             "sites": st1["sites"], "X_nnz": int(st1["X_nnz"]), "cg_iters_X": st1["cg_iters_X_per_step"],
             "single_gpu_ms_per_step": round(t_single / nsteps * 1e3, 3), "sharded_ms_per_step": round(t_shard / nsteps * 1e3, 3),
             "speedup": round(t_single / t_shard, 3),
-            "bit_identical_to_single_gpu_segment_path": bool(flag.item() == 1.0), "equal_to_default_single_gpu_within_1e-9": bool(close),
-            "single_gpu_symmetric_tiles": int(st1["spmv_tiles"]), "ranks_agree": all(t == traces[0] for t in traces),
-            "segments": int(st2["spmv_segments"]), "allgather_doubles_per_rank": int(st2["comm_count_per_rank"]),
-            "allgather_us": round(st2["comm_ms"] / max(st2["comm_launches"], 1) * 1e3, 2),
+            "bit_identical_to_single_gpu": bool(flag.item() == 1.0), "equal_to_single_gpu_within_1e-6": bool(close),
+            "symmetric_tiles": int(st2["spmv_tiles"]), "collective": "all-reduce" if st2["spmv_tiles"] > 0 else "all-gather",
+            "ranks_agree": all(t == traces[0] for t in traces),
+            "segments": int(st2["spmv_segments"]), "exchanged_doubles_per_rank": int(st2["comm_count_per_rank"]),
+            "exchange_us": round(st2["comm_ms"] / max(st2["comm_launches"], 1) * 1e3, 2),
             "segment_kernel_us": round(st2["spmv_long_ms"] / max(st2["spmv_long_launches"], 1) * 1e3, 2),
             "single_gpu_segment_kernel_us": round(st1["spmv_long_ms"] / max(st1["spmv_long_launches"], 1) * 1e3, 2),
         }

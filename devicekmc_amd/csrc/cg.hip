@@ -288,8 +288,10 @@ __global__ __launch_bounds__(SPMV_NT) void k_rowsum_tiles(int n_long, const LRow
                                                           int nW, const double *__restrict__ rowpart, const double *__restrict__ colpart,
                                                           const double *__restrict__ csum, int csum_pitch,
                                                           const double *__restrict__ p, double *__restrict__ t, double *__restrict__ part,
-                                                          const CgCtrl *ctrl)
+                                                          const CgCtrl *ctrl, double *__restrict__ xout)
 {
+    // xout != nullptr (sharded solve): only this rank's share of every long row's sum is formed and stored to xout[ridx]; the
+    // all-reduce and k_xbuf_apply finish the row
     __shared__ double red[SPMV_NT / 64];
     __shared__ int sdone;
     if (threadIdx.x == 0) sdone = ctrl->done;
@@ -322,7 +324,25 @@ __global__ __launch_bounds__(SPMV_NT) void k_rowsum_tiles(int n_long, const LRow
         }
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
-        if (l == 0) { t[mt.row] = s; acc += p[mt.row] * s; }
+        if (l == 0) { if (xout) xout[ridx] = s; else { t[mt.row] = s; acc += p[mt.row] * s; } }
+    }
+    if (xout) return;
+    const double tot = block_sum_all<SPMV_NT>(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+// sharded tile solve, after the all-reduce: t and the p.t partials from the completed row sums (launch shape of stage 2)
+__global__ __launch_bounds__(SPMV_NT) void k_xbuf_apply(int n_long, const LRowMeta *__restrict__ meta, const double *__restrict__ xbuf,
+                                                        const double *__restrict__ p, double *__restrict__ t, double *__restrict__ part, const CgCtrl *ctrl)
+{
+    __shared__ double red[SPMV_NT / 64];
+    __shared__ int sdone;
+    if (threadIdx.x == 0) sdone = ctrl->done;
+    __syncthreads();
+    if (sdone) return;
+    double acc = 0.0;
+    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;         // thread-to-row mapping of k_rowsum_tiles: same p.t partials
+    for (int ridx = blockIdx.x * (SPMV_NT / 16) + g; ridx < n_long; ridx += gridDim.x * (SPMV_NT / 16)) {
+        if (l == 0) { const int row = meta[ridx].row; const double s = xbuf[ridx]; t[row] = s; acc += p[row] * s; }
     }
     const double tot = block_sum_all<SPMV_NT>(acc, red);
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
@@ -587,11 +607,12 @@ __global__ void k_tile_ranges(int nK, int nW, const int *__restrict__ dense, int
 }
 __global__ void k_lrow_meta(int n_long, const int *__restrict__ long_rows, const int *__restrict__ lsr, const int *__restrict__ nsegs,
                             const int *__restrict__ seg_off, const int *__restrict__ wbeg, const int *__restrict__ wend, const int *__restrict__ kend,
-                            LRowMeta *__restrict__ meta)
+                            int own_lo, int own_hi, LRowMeta *__restrict__ meta)
 {
     const int ridx = blockIdx.x * blockDim.x + threadIdx.x;
     if (ridx >= n_long) return;
-    LRowMeta m; m.sr = lsr[ridx]; m.nseg = nsegs[ridx]; m.segoff = seg_off[ridx]; m.row = long_rows[ridx]; m.wbeg = 0; m.wend = 0; m.kend = 0; m.pad = 0;
+    // sharded solve: the segments of rows outside [own_lo, own_hi) belong to other ranks (their partials here are stale)
+    LRowMeta m; m.sr = lsr[ridx]; m.nseg = (ridx >= own_lo && ridx < own_hi) ? nsegs[ridx] : 0; m.segoff = seg_off[ridx]; m.row = long_rows[ridx]; m.wbeg = 0; m.wend = 0; m.kend = 0; m.pad = 0;
     if (m.sr >= 0) { m.wbeg = wbeg[m.sr / TILE_R]; m.wend = wend[m.sr / TILE_R]; m.kend = kend[m.sr / TILE_C]; }
     meta[ridx] = m;
 }
@@ -1009,7 +1030,7 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
     bool use_tiles = false; int nK = 0, nW = 0, ntiles = 0; int *dense = nullptr, *toff = nullptr, *nsegs = nullptr;
     TileDesc *tiles = nullptr; double *rowpart = nullptr, *colpart = nullptr, *tval = nullptr, *csum = nullptr; int csum_pitch = 0; int *trange = nullptr, *lsr = nullptr, *chk = nullptr, *goff = nullptr, *gcol = nullptr, *srp = nullptr, *scol = nullptr;
     double *gval = nullptr, *sval = nullptr; LRowMeta *lmeta = nullptr;
-    int nseg = 0, nseg_loc = 0, seg_lo = 0; bool sharded = false; RowParts parts{}, *dparts = nullptr; double *xbuf = nullptr;
+    int nseg = 0, nseg_loc = 0, seg_lo = 0, tile_lo = 0, ntiles_loc = 0; bool sharded = false; RowParts parts{}, *dparts = nullptr; double *xbuf = nullptr;
     if (use_runs) {
         runs = (RunDesc *)scratch(S_CG_RUNS, ((size_t)nnz / RUN_MIN_LEN + n_long + 2) * sizeof(RunDesc));
         rem = (int *)scratch(S_CG_REM, (size_t)nnz * 4);
@@ -1017,8 +1038,8 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
         pS = (double *)scratch(S_CG_PS, (size_t)(ns + TILE_C) * 8);      // + zero padding for the last tile row block / window
         if (!runs || !rem || !nruns || !pS) return e.err_code;
         nrem = nruns + n_long;
-        // symmetric tiles (single-GPU solves; the sharded solve keeps the plain segment path and its bit-identity guarantee)
-        use_tiles = e.symmetric_tiles && !comm_attached() && ns > TILE_C;
+        // symmetric tiles (also in the sharded solve: then one all-reduce per iteration instead of the bit-identical all-gather scheme)
+        use_tiles = e.symmetric_tiles && ns > TILE_C;
         hipLaunchKernelGGL((k_build_runs<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, ci, srank, runs, nruns, rem, nrem,
                            use_tiles ? 0x7fffffff : seg_len, use_tiles ? 1 : 0);
         seg_off = (int *)scratch(S_CG_SEGOFF, (size_t)(n_long + 4) * 4);
@@ -1106,12 +1127,14 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
             parts.chunk = (mx + 1) & ~1;
             if (parts.chunk == 0) parts.chunk = 2;
             seg_lo = hoff[parts.lo[me]]; nseg_loc = hoff[parts.lo[me + 1]] - seg_lo;
-            xbuf = (double *)scratch(S_CG_XCHG, (size_t)nr * parts.chunk * 8);
+            xbuf = (double *)scratch(S_CG_XCHG, std::max((size_t)nr * parts.chunk, (size_t)n_long + 2) * 8);
+            if (use_tiles) { tile_lo = (int)((long long)ntiles * me / nr); ntiles_loc = (int)((long long)ntiles * (me + 1) / nr) - tile_lo; }
             dparts = (RowParts *)scratch(S_CG_PARTS, sizeof(RowParts));
             if (!xbuf || !dparts) return e.err_code;
             HIPCHK(hipMemcpy(dparts, &parts, sizeof(RowParts), hipMemcpyHostToDevice));
             e.stats.comm_ranks = nr; e.stats.comm_local_segments = nseg_loc; e.stats.comm_count_per_rank = parts.chunk;
-        } else { nseg_loc = nseg; e.stats.comm_ranks = 0; }
+        } else { nseg_loc = nseg; e.stats.comm_ranks = 0; ntiles_loc = ntiles; }
+        if (sharded && use_tiles) e.stats.comm_count_per_rank = n_long;
         e.stats.spmv_segments = nseg;
         segs = (RunDesc *)scratch(S_CG_SEGS, (size_t)(nseg + 1) * sizeof(RunDesc));
         seg_part = (double *)scratch(S_CG_SEGPART, (size_t)(nseg + 1) * 8);
@@ -1126,13 +1149,14 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
             lmeta = (LRowMeta *)scratch(S_CG_LMETA, (size_t)(n_long + 1) * sizeof(LRowMeta));
             if (!lmeta) return e.err_code;
             hipLaunchKernelGGL(k_lrow_meta, dim3((n_long + 255) / 256), dim3(256), 0, st, n_long, long_rows, (const int *)lsr, (const int *)nsegs,
-                               (const int *)seg_off, (const int *)trange, (const int *)(trange + nK), (const int *)(trange + 2 * nK), lmeta);
+                               (const int *)seg_off, (const int *)trange, (const int *)(trange + nK), (const int *)(trange + 2 * nK),
+                               sharded ? parts.lo[comm_rank()] : 0, sharded ? parts.lo[comm_rank() + 1] : n_long, lmeta);
         }
         e.stats.spmv_tiles = ntiles;
     }
     // blocks of k_spmv_segs: segments (a wave each; 16 lanes each in tile mode), tiles (a wave each), short rows (16 / 8 lanes each)
     const int nsb = use_tiles ? (nseg_loc + SEGK_NT / 16 - 1) / (SEGK_NT / 16) : (nseg_loc + SEGK_NT / 64 - 1) / (SEGK_NT / 64);
-    const int ntb = (ntiles + SEGK_NT / 64 - 1) / (SEGK_NT / 64);
+    const int ntb = (ntiles_loc + SEGK_NT / 64 - 1) / (SEGK_NT / 64);            // (this rank's share of the tiles)
     const int hsA = (use_runs && n_short > 0) ? grid_for(n_short, use_tiles ? SEGK_NT / 8 : SEGK_NT / 16) : 0;
     if (use_runs) np_ap = hsA + hl2;
     // ---- Jacobi scaling ----
@@ -1231,7 +1255,7 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
             hipEvent_t e0 = pb ? evs[4 * b] : nullptr, e1 = pb ? evs[4 * b + 1] : nullptr, e2 = pb ? evs[4 * b + 2] : nullptr, e3 = pb ? evs[4 * b + 3] : nullptr;
             if (use_runs) {
 #define SEG_ARGS nseg_loc, (const RunDesc *)segs + seg_lo, (const double *)a, (const double *)pS, seg_part + seg_lo, (const CgCtrl *)ctrl, (const int *)rem, ci, \
-                 (const double *)p, nsb, n_short, short_rows, rp, long_rows, t, part_pAp, ntb, ntiles, nW, ns, (const TileDesc *)tiles, (const double *)tval, rowpart, colpart, \
+                 (const double *)p, nsb, n_short, short_rows, rp, long_rows, t, part_pAp, ntb, ntiles_loc, nW, ns, (const TileDesc *)tiles + tile_lo, (const double *)tval + (size_t)tile_lo * TILE_R * TILE_C, rowpart, colpart, \
                  (const double *)gval, (const int *)gcol, (const int *)srp, (const double *)sval, (const int *)scol
                 const dim3 sg(nsb + hsA + ntb);
                 if (use_tiles) {       // tile role compiled in; short rows and remainder entries from their packed copies
@@ -1246,9 +1270,20 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
                 if (use_tiles) {
                     if (csum) hipLaunchKernelGGL(k_tile_colsum, dim3(nW * COLSUM_SLICES), dim3(TILE_C), 0, st, ns, nK, nW, (const int *)(trange + 2 * nK),
                                                  (const double *)colpart, csum, csum_pitch, (const CgCtrl *)ctrl);
+                    if (sharded) {
+                        // this rank's share of every long row's sum -> one all-reduce -> t and the p.t partials on every rank.  All ranks
+                        // receive the same bits and enqueue exactly the same sequence of collectives.
+                        hipLaunchKernelGGL(k_rowsum_tiles, dim3(hl2), dim3(SPMV_NT), 0, st, n_long, (const LRowMeta *)lmeta, (const double *)seg_part, nW,
+                                           (const double *)rowpart, (const double *)colpart, (const double *)csum, csum_pitch, (const double *)p, t,
+                                           part_pAp + hsA, (const CgCtrl *)ctrl, xbuf);
+                        if (int rc = comm_allreduce_sum_f64(xbuf, (size_t)n_long)) return rc;
+                        if (pb) HIPCHK(hipEventRecord(evc[b / PROF_STRIDE], st));
+                        hipExtLaunchKernelGGL(k_xbuf_apply, dim3(hl2), dim3(SPMV_NT), 0, st, e2, e3, 0, n_long, (const LRowMeta *)lmeta, (const double *)xbuf,
+                                              (const double *)p, t, part_pAp + hsA, (const CgCtrl *)ctrl);
+                    } else
                     hipExtLaunchKernelGGL(k_rowsum_tiles, dim3(hl2), dim3(SPMV_NT), 0, st, e2, e3, 0, n_long, (const LRowMeta *)lmeta,
                                           (const double *)seg_part, nW, (const double *)rowpart, (const double *)colpart, (const double *)csum, csum_pitch,
-                                          (const double *)p, t, part_pAp + hsA, (const CgCtrl *)ctrl);
+                                          (const double *)p, t, part_pAp + hsA, (const CgCtrl *)ctrl, (double *)nullptr);
                 } else
                 if (sharded) {
                     // row sums of the owned rows -> exchange step -> t and the p.t partials on every rank.  Every rank enqueues

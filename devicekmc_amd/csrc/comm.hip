@@ -1,11 +1,15 @@
 // comm.hip -- the one exchange step of the multi-GPU current solve (SURVEY 8e, row "X-CG").
 //
 // The reference is single-GPU.  Here N processes (one per GPU) advance the SAME simulation in lockstep; every phase is
-// computed redundantly and identically on every rank except the dominant one, the segment stage of A*p in the CG solve of
-// X (cg.hip, k_spmv_segs): the long (tunnelling) rows are dealt to the ranks at row boundaries, balanced by segment count.
-// A rank multiplies the segments of its rows and adds them per row; one in-place all-gather per CG iteration hands every
-// rank every row sum (8 B per long row), and everything downstream (dot products, vector updates, stop test) is again
-// computed identically everywhere.  Consequences: the result is bit-identical to the single-GPU result, all ranks take the same control
+// computed redundantly and identically on every rank except the dominant one, the matrix stream of A*p in the CG solve of
+// X (cg.hip, k_spmv_segs).  Two variants, one collective per CG iteration each:
+//   * symmetric tiles (default): the tiles are dealt to the ranks in equal contiguous shares, the leftover segments by rows;
+//     every rank forms the partial sum of every long row from what it owns and ONE in-place all-reduce (8 B per long row)
+//     completes them.  All ranks receive the same bits (lockstep-safe); the result equals the single-GPU one to rounding.
+//   * runs only (dkmc_set_symmetric_tiles(0)): the long rows are dealt to the ranks at row boundaries, balanced by segment
+//     count; a rank multiplies the segments of its rows and adds them per row; one in-place all-gather hands every rank
+//     every row sum.  Values and summation orders are those of the single-GPU kernels: bit-identical to the single-GPU run.
+// Everything downstream (dot products, vector updates, stop test) is again computed identically everywhere.  Consequences: the result is bit-identical to the single-GPU result, all ranks take the same control
 // decisions (no rank can leave the iteration loop while another waits in the collective), and no dot-product all-reduce
 // is needed.
 //
@@ -25,6 +29,7 @@ typedef int (*fn_get_unique_id)(void *);
 typedef int (*fn_comm_init_rank)(void **, int, nccl_id_t, int);
 typedef int (*fn_comm_destroy)(void *);
 typedef int (*fn_all_gather)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef int (*fn_all_reduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
 typedef const char *(*fn_error_string)(int);
 
 struct Comm {
@@ -35,6 +40,7 @@ struct Comm {
     fn_comm_init_rank comm_init_rank = nullptr;
     fn_comm_destroy comm_destroy = nullptr;
     fn_all_gather all_gather = nullptr;
+    fn_all_reduce all_reduce = nullptr;
     fn_error_string error_string = nullptr;
     // host callback
     dkmc_allgather_fn cb = nullptr; void *cb_user = nullptr;
@@ -54,8 +60,9 @@ static int rccl_open()
     c.comm_init_rank = (fn_comm_init_rank)dlsym(h, "ncclCommInitRank");
     c.comm_destroy = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");
     c.all_gather = (fn_all_gather)dlsym(h, "ncclAllGather");
+    c.all_reduce = (fn_all_reduce)dlsym(h, "ncclAllReduce");
     c.error_string = (fn_error_string)dlsym(h, "ncclGetErrorString");
-    if (!c.get_unique_id || !c.comm_init_rank || !c.comm_destroy || !c.all_gather || !c.error_string)
+    if (!c.get_unique_id || !c.comm_init_rank || !c.comm_destroy || !c.all_gather || !c.all_reduce || !c.error_string)
         return dkmc_fail(41, "comm: librccl lacks a required symbol", __FILE__, __LINE__);
     c.dl = h;
     return 0;
@@ -145,6 +152,35 @@ int comm_allgather_f64(double *buf, size_t count)
         HIPCHK(hipStreamSynchronize(st));
         if (int rc = c.cb(c.stage, count * sizeof(double), c.rank, c.nranks, c.cb_user)) return dkmc_fail(45, "comm: all-gather callback failed", __FILE__, __LINE__);
         HIPCHK(hipMemcpyAsync(buf, c.stage, bytes, hipMemcpyHostToDevice, st));
+        return 0;
+    }
+    return 0;
+}
+
+// in-place sum over the ranks of `count` doubles on the engine's stream; every rank ends with the same bits (RCCL reduces each
+// chunk once and distributes the result; the host transport adds the gathered vectors in rank order)
+int comm_allreduce_sum_f64(double *buf, size_t count)
+{
+    Comm &c = g_comm; hipStream_t st = eng().stream;
+    if (c.transport == DKMC_COMM_RCCL) {
+        RCCLCHK(c.all_reduce(buf, buf, count, NCCL_FLOAT64, /* ncclSum */ 0, c.nccl, st));
+        return 0;
+    }
+    if (c.transport == DKMC_COMM_HOST) {
+        const size_t bytes = (size_t)c.nranks * count * sizeof(double);
+        if (c.stage_bytes < bytes) {
+            if (c.stage) (void)hipHostFree(c.stage);
+            c.stage = nullptr; c.stage_bytes = 0;
+            HIPCHK(hipHostMalloc((void **)&c.stage, bytes, hipHostMallocDefault));
+            c.stage_bytes = bytes;
+        }
+        double *mine = c.stage + (size_t)c.rank * count;
+        HIPCHK(hipMemcpyAsync(mine, buf, count * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (int rc = c.cb(c.stage, count * sizeof(double), c.rank, c.nranks, c.cb_user)) return dkmc_fail(45, "comm: all-gather callback failed", __FILE__, __LINE__);
+        for (int r = 1; r < c.nranks; ++r) { const double *src = c.stage + (size_t)r * count; for (size_t i = 0; i < count; ++i) c.stage[i] += src[i]; }
+        HIPCHK(hipMemcpyAsync(buf, c.stage, count * sizeof(double), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));                 // the staging buffer is reused by the next call
         return 0;
     }
     return 0;

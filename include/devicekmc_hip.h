@@ -218,10 +218,12 @@ int dkmc_update_temperature_local(dkmc_gpubuf *buf, double step_time, double del
                                   int *n_solves_out, int *steady_out, int *cg_iters_out, double *T_bg_out);
 
 /* ---- multi-GPU: one simulation advanced in lockstep by N processes, one GPU each (no reference counterpart) ----
- * While a communicator is attached, update_power_gpu_sparse deals the long rows of A*p of its CG solve to the ranks
- * and hands every rank every row sum with ONE in-place all-gather per iteration; every other phase is computed
- * redundantly and identically on every rank, so all ranks hold the same state after every call and the result is
- * bit-identical to the single-GPU one.  Every rank must make the same sequence of calls with the same inputs.
+ * While a communicator is attached, update_power_gpu_sparse deals the matrix stream of A*p of its CG solve to the ranks and
+ * completes the long rows' sums with ONE in-place collective per iteration: an all-reduce in the default arithmetic (symmetric
+ * tiles; all ranks receive the same bits, the result equals the single-GPU one to rounding), an all-gather with
+ * dkmc_set_symmetric_tiles(0) (bit-identical to the single-GPU result).  Every other phase is computed redundantly and identically
+ * on every rank, so all ranks hold the same state after every call.  Every rank must make the same sequence of calls with the
+ * same inputs.
  * Transports: RCCL over xGMI (unique id from rank 0, distributed by the caller), or a host callback that all-gathers a
  * pinned host buffer in place (rehearsal on machines where the ranks share a GPU, which RCCL refuses). */
 enum { DKMC_COMM_NONE = 0, DKMC_COMM_RCCL = 1, DKMC_COMM_HOST = 2 };

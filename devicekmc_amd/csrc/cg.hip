@@ -1085,7 +1085,7 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
             colpart = (double *)scratch(S_CG_COLPART, (size_t)(ncand + 1) * TILE_C * 8);
             trange = (int *)scratch(S_CG_CSUM, (size_t)(2 * nK + nW + 8) * 4);
             if (!tiles || !tval || !rowpart || !colpart || !trange) return e.err_code;
-            if (nK > 128) {           // many row blocks per window: pre-sum the column partials (k_tile_colsum)
+            if (nK >= 512) {          // many row blocks per window: pre-sum the column partials (k_tile_colsum; at 262 row blocks the extra launch costs more than it saves)
                 csum_pitch = (ns + 63) & ~63;
                 csum = (double *)scratch(S_CG_CSUM2, (size_t)COLSUM_SLICES * csum_pitch * 8);
                 if (!csum) return e.err_code;

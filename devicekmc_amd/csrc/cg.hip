@@ -13,9 +13,13 @@
 //     of X (tunnelling rows, thousands of entries) are not multiplied in CSR form at all inside the iteration loop: their
 //     entries are viewed as index-free dense runs cut into <= 2048-entry segments, one wave64 per segment, 8 B per entry
 //     (k_build_runs / k_spmv_segs below); a tiny second kernel adds a row's segment partials in a fixed order;
-//   * row pointers are a template parameter (int for K, 64-bit for X whose non-zeros outgrow 2^31 at ~4e5 sites).
+//   * X is symmetric and its tunnelling part is dense by classes: 32 x 256 blocks of it ("symmetric tiles", k_tile_count ff.)
+//     are copied into tile-major storage once per solve and read ONCE per iteration for both triangles;
+//   * row pointers are a template parameter (int for K, 64-bit for X whose non-zeros outgrow 2^31 at ~4e5 sites);
+//   * with a communicator attached (comm.hip) the matrix stream is dealt to the ranks and one collective per iteration
+//     completes the long rows' sums.
 // HBM traffic per iteration in the CSR formulation: 12*nnz + 4*(m+1) + 96*m bytes; with the segments the
-// matrix part of X drops to 8 B per entry.
+// matrix part of X drops to 8 B per entry, with the tiles to about 4 B per entry.
 #include "common.h"
 #include <hip/hip_ext.h>
 #include <vector>
@@ -748,7 +752,7 @@ __global__ void k_chk_max(long long n, const int *__restrict__ chk, int *__restr
 // Streams 8 B per entry, 4 independent 1-KiB strips in flight per wave; every wave has the same amount of work.
 // Default cache policy on the matrix stream (NTL = 0): the same 240 MB are re-read every CG iteration and partly stay in
 // the 256 MiB Infinity Cache -- measured 45 us per launch against 53 us with non-temporal loads (NTL = 1, DKMC_SPMV_VAR=3).
-template <int NTL, typename RP, int UNR, int TILES>
+template <int NTL, typename RP, int TILES>
 __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *__restrict__ segs, const double *__restrict__ a,
                                                        const double *__restrict__ pS, double *__restrict__ seg_part, const CgCtrl *ctrl,
                                                        const int *__restrict__ rem, const int *__restrict__ ci, const double *__restrict__ p,
@@ -917,20 +921,6 @@ __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *
     const int npair = len >> 1;
     const dbl2 *av2 = reinterpret_cast<const dbl2 *>(av);
     int k = lane;
-    if (UNR == 8) {
-        for (; k + 448 < npair; k += 512) {
-            dbl2 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = LDM(av2 + k + 64 * u);
-#pragma unroll
-            for (int u = 0; u < 8; u += 4) {
-                s0 += v[u].x * pv[2 * (k + 64 * u)] + v[u].y * pv[2 * (k + 64 * u) + 1];
-                s1 += v[u + 1].x * pv[2 * (k + 64 * (u + 1))] + v[u + 1].y * pv[2 * (k + 64 * (u + 1)) + 1];
-                s2 += v[u + 2].x * pv[2 * (k + 64 * (u + 2))] + v[u + 2].y * pv[2 * (k + 64 * (u + 2)) + 1];
-                s3 += v[u + 3].x * pv[2 * (k + 64 * (u + 3))] + v[u + 3].y * pv[2 * (k + 64 * (u + 3)) + 1];
-            }
-        }
-    }
     for (; k + 192 < npair; k += 256) {
         const dbl2 a0 = LDM(av2 + k), a1 = LDM(av2 + k + 64);
         const dbl2 a2 = LDM(av2 + k + 128), a3 = LDM(av2 + k + 192);
@@ -1046,7 +1036,7 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
         if (!seg_off) return e.err_code;
         int rc = 0;
         if (use_tiles) {
-            // raw runs -> tile flags -> tile descriptors -> segment list of what the tiles do not cover
+            // raw runs -> entries per grid cell -> choice of tiles -> segment list of what the tiles do not cover
             nK = (ns + TILE_R - 1) / TILE_R; nW = (ns + TILE_C - 1) / TILE_C;
             const long long ncand = (long long)nK * nW;
             if (ncand > 0x7fffff00ll) return dkmc_fail(47, "CG: too many tile candidates", __FILE__, __LINE__);
@@ -1226,7 +1216,6 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
     int batch = 8;
     if (iter_hint && *iter_hint > 24) batch = *iter_hint - 8;
     static const int spmv_var = getenv("DKMC_SPMV_VAR") ? atoi(getenv("DKMC_SPMV_VAR")) : 0;   // experiments only
-    static const int seg_unr = getenv("DKMC_SEG_UNR") ? atoi(getenv("DKMC_SEG_UNR")) : 4;
     // matrix stream: default cache policy while the values of one sweep fit the 256 MiB Infinity Cache (they are re-read
     // every iteration), non-temporal beyond that (measured: 45 vs 53 us at 240 MB, 478 vs 456 us at 1.86 GB); a rank of a
     // sharded solve streams only its share
@@ -1259,13 +1248,11 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
                  (const double *)gval, (const int *)gcol, (const int *)srp, (const double *)sval, (const int *)scol
                 const dim3 sg(nsb + hsA + ntb);
                 if (use_tiles) {       // tile role compiled in; short rows and remainder entries from their packed copies
-                    if (seg_nt) hipExtLaunchKernelGGL((k_spmv_segs<1, RP, 4, 1>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
-                    else hipExtLaunchKernelGGL((k_spmv_segs<0, RP, 4, 1>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
+                    if (seg_nt) hipExtLaunchKernelGGL((k_spmv_segs<1, RP, 1>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
+                    else hipExtLaunchKernelGGL((k_spmv_segs<0, RP, 1>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
                 }
-                else if (seg_nt && seg_unr == 8) hipExtLaunchKernelGGL((k_spmv_segs<1, RP, 8, 0>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
-                else if (seg_nt) hipExtLaunchKernelGGL((k_spmv_segs<1, RP, 4, 0>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
-                else if (seg_unr == 8) hipExtLaunchKernelGGL((k_spmv_segs<0, RP, 8, 0>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
-                else hipExtLaunchKernelGGL((k_spmv_segs<0, RP, 4, 0>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
+                else if (seg_nt) hipExtLaunchKernelGGL((k_spmv_segs<1, RP, 0>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
+                else hipExtLaunchKernelGGL((k_spmv_segs<0, RP, 0>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
 #undef SEG_ARGS
                 if (use_tiles) {
                     if (csum) hipLaunchKernelGGL(k_tile_colsum, dim3(nW * COLSUM_SLICES), dim3(TILE_C), 0, st, ns, nK, nW, (const int *)(trange + 2 * nK),

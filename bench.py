@@ -19,7 +19,8 @@ steps/s, "scaling": "weak".  The same run then measures the sharded current solv
 simulation in lockstep, the segment stage of A*p is dealt to the ranks, one RCCL all-gather per CG iteration) on the
 default workload and on a larger one, against the single-GPU time of the same steps, and checks bit-identity; that goes
 into the extra "sharded_solve" block (strong scaling, never `value`).  A watchdog prints the line without that block if
-the sharded part does not finish in time.
+the sharded part does not finish in time.  `--mode sharded` makes the sharded run the measured one instead (one simulation,
+`value` = its steps/s, "scaling": "strong").
 """
 import argparse
 import json
@@ -62,6 +63,8 @@ def main():
     ap.add_argument("--workload", default="7.5nm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--warm-start", type=int, default=0, help="dkmc_set_current_warm_start mode (0 = reference)")
+    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
+                    help="N > 1: replicas (weak scaling, default) or ONE simulation with the sharded current solve (strong scaling)")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the sharded-solve block")
     ap.add_argument("--sharded-workloads", default=None, help="comma list; default: the main workload and tile:5")
     ap.add_argument("--sharded-steps", type=int, default=2)
@@ -85,7 +88,11 @@ def main():
     L = lib.load()
     Vd = 5.0
     s, p = make_workload(args.workload)
-    p.rnd_seed_kmc = parallel.replica_kmc_seed(p.rnd_seed_kmc, rank)   # replicas follow different event streams
+    sharded_main = args.mode == "sharded" and world > 1
+    if sharded_main:
+        parallel.attach_solver_comm()          # every rank advances the same simulation (same seeds); the current solve is sharded
+    else:
+        p.rnd_seed_kmc = parallel.replica_kmc_seed(p.rnd_seed_kmc, rank)   # replicas follow different event streams
     dev = host.Device(s, p, gpu_neighbors=devname)       # HIP cell-list neighbour index (setup, outside the timed region)
     sim = host.KMCProcess(dev, p.freq)
     gb = dev.make_gpubuf(devname)
@@ -227,11 +234,12 @@ def main():
     if rank == 0:
         n = args.steps
         out = {
-            "metric": "KMC steps/sec", "value": round(parallel.aggregate_rate(n, world, elapsed), 4), "unit": "KMC steps/s",
+            "metric": "KMC steps/sec", "value": round(n / elapsed if sharded_main else parallel.aggregate_rate(n, world, elapsed), 4),
+            "unit": "KMC steps/s",
             "n_gpus": world, "steps": n, "warmup": args.warmup, "ms_per_step": round(elapsed / n * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if sharded_main else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": args.workload, "sites": int(s.N), "nn": int(dev.max_num_neighbors), "atoms": int(dev.N_atom),
-                       "Vd": Vd, "phases": "charge+potential+rates+current+heat", "parallelism": "replicas x%d" % world,
+                       "Vd": Vd, "phases": "charge+potential+rates+current+heat", "parallelism": ("sharded current solve x%d" if sharded_main else "replicas x%d") % world,
                        "current_warm_start": args.warm_start, "cg_tol": p.cg_tol},
             "split_ms": {k: round(v / n * 1e3, 3) for k, v in phases.items()},
             "per_step": {"events": counters["events"] / n, "cg_iters_K": counters["cg_iters_K"] / n,
@@ -255,7 +263,9 @@ def main():
                     out["sharded_solve"] = extra
                 print(json.dumps(out), flush=True)
 
-    if world > 1 and not args.no_sharded:
+    if sharded_main:
+        parallel.detach_solver_comm()
+    if world > 1 and not args.no_sharded and not sharded_main:
         def on_timeout():
             emit({"error": "sharded-solve block did not finish within %.0f s" % args.sharded_timeout})
             os._exit(0)             # a rank stuck in a collective cannot be unwound

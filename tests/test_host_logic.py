@@ -64,3 +64,47 @@ def test_site_layers_errors():
     import pytest
     with pytest.raises(ValueError):
         structure.site_layers(np.array([-30.0]), pm.default_layers())
+
+
+def test_local_heat_oracle_properties_and_contact_counting(cell_2p5):
+    """The local temperature model's restatement (oracle/heat_local.py) has no reference fixture to pin it; these are the
+    properties the model itself guarantees, plus the product's closed-form contact counting against the literal loops."""
+    from types import SimpleNamespace
+    from devicekmc_amd import host
+    from oracle import heat_local as hl
+    rng_ = np.random.default_rng(3)
+    # contact counting (heat_solver.cpp:5-37): literal loops vs the closed form of host.Device.get_num_in_contacts
+    for _ in range(100):
+        N = int(rng_.integers(5, 80)); el = rng_.integers(0, 4, N)
+        fake = SimpleNamespace(site_element=el, N=N)
+        nd = int((el != 0).sum())
+        for k in range(0, nd + 1):
+            assert host.Device.get_num_in_contacts(fake, k, "left") == hl.get_num_in_contacts(el, k, "left")
+            assert host.Device.get_num_in_contacts(fake, k, "right") == hl.get_num_in_contacts(el, k, "right")
+    # a small chain device: 4 contact sites | 12 interface sites | 4 contact sites, neighbours = adjacent sites
+    N = 20
+    el = np.array([6] * 4 + [3] * 12 + [6] * 4)                    # Ti contacts, oxygen in between (ELEMENT enum)
+    neigh = np.full((N, 2), -1, dtype=np.int64)
+    for i in range(N):
+        nb = [j for j in (i - 1, i + 1) if 0 <= j < N]
+        neigh[i, :len(nb)] = nb
+    p = pm.KMCParameters()
+    o = hl.LocalHeatOracle(el, neigh, (6, 8), 4, p.nn_dist, p.delta, p.delta_t, p.tau, p.k_th_interface, p.k_th_metal)
+    assert (o.N_left_tot, o.N_right_tot, o.N_interface) == (4, 4, 12)
+    L = o.L
+    assert np.allclose(L, L.T) and (np.linalg.eigvalsh(L) < 0).all()          # negative definite: boundary sites leak to the contacts
+    assert L[0, 0] == -o.gamma - 1 and L[5, 5] == -2                           # boundary row / interior row
+    T0 = p.background_temp
+    # no power: the temperature stays at the background, transient and steady state
+    T = np.full(N, T0); Tb = o.update_local_temperature(T, np.zeros(N), el, T0, p.delta_t, p.tau, p.k_th_interface, p.k_th_vacancies, 4)
+    assert np.allclose(T, T0) and abs(Tb - T0) < 1e-9
+    # constant power: many transient updates converge to the steady-state solution (the two branches are consistent)
+    P = np.zeros(N); P[8:12] = 1e-9
+    Ts = np.full(N, T0); o.update_local_temperature_steady_state(Ts, P, el, T0, p.k_th_interface, p.k_th_vacancies, 4)
+    Tt = np.full(N, T0)
+    for _ in range(4000):
+        o.update_local_temperature(Tt, P, el, T0, p.delta_t, p.tau, p.k_th_interface, p.k_th_vacancies, 4)
+    assert (Ts[4:16] > T0).all() and np.allclose(Tt, Ts, rtol=0, atol=1e-6 * (Ts.max() - T0))
+    # linear in the power
+    T2 = np.full(N, T0); o.update_local_temperature_steady_state(T2, 2 * P, el, T0, p.k_th_interface, p.k_th_vacancies, 4)
+    assert np.allclose(T2 - T0, 2 * (Ts - T0), rtol=1e-12)

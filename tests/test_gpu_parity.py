@@ -598,3 +598,30 @@ def _fresh_device(structure, p, hip):
     dev.setLaplacePotential(gb, p, Vd)
     gb.sync_HostToGPU(dev)
     return dev, sim, gb, None
+
+
+def test_supersteps_tiled_structure_with_symmetric_tiles(cell_2p5, hip):
+    """37 596 sites (the 2.5 nm cell tiled 2 x 2 laterally): large enough for the symmetric tiles of the current solve, small
+    enough for the CPU oracle.  Three full supersteps with global heating: the tile layout is rebuilt every step as the vacancies
+    move; events identical to the oracle's, KMC time / current / temperature within the tolerances of the other superstep tests
+    (both solves converged to a scaled residual of 1e-9)."""
+    from devicekmc_amd import params as pm
+    from devicekmc_amd import structure
+    host, L = hip
+    s = structure.tile_structure(cell_2p5, 2, 25.575, 25.575, 1440)
+    p = pm.KMCParameters().for_tiling(2); p.solve_heating_global = True; p.cg_tol = 1e-9
+    dev, sim, gb, o = make_pair(s, p, hip)
+    for k in range(3):
+        dev.updateCharge(gb); dev.updatePotential(gb, p, Vd, k)
+        _, dt = sim.executeKMCStep(gb, dev, want_log=True)
+        dev.updatePower(gb, p, Vd); dev.updateTemperature(gb, p, dt)
+        st = host.get_stats()
+        assert st["spmv_tiles"] > 0 and 2 * st["spmv_tile_entries"] >= 0.8 * st["X_nnz"]      # the tiles carry the solve
+        out = o.superstep(Vd)
+        assert np.array_equal(sim.last_event_log, o.last_events["log"]), k
+        # K mixes conductances of 1 and 1e-8 (cond ~1e8): potentials, hence rates and the KMC time, agree to cond(K) x residual
+        assert abs(dt / out["step_time"] - 1) <= 1e-5
+        assert abs(dev.imacro / out["imacro"] - 1) <= 1e-5
+        assert abs(dev.T_bg - out["T_bg"]) <= 1e-7
+    rp, ci, data = host.get_last_X()
+    assert np.array_equal(rp, o.last_X["row_ptr"]) and np.array_equal(ci, o.last_X["col"])

@@ -580,9 +580,9 @@ __global__ __launch_bounds__(256) void k_tile_scatter(int n_long, const int *__r
             const long long cell = (long long)k * nW + w;
             if (!choose[cell]) continue;
             const int c0 = max(lo, w * TILE_C), c1 = min(hi, w * TILE_C + TILE_C);
-            double *dst = tval + ((size_t)toff[cell] * TILE_R + (s % TILE_R)) * TILE_C - (size_t)w * TILE_C;
-            const double *src = a + d.pos - lo;
-            for (int c = c0 + lane; c < c1; c += 64) dst[c] = src[c];
+            double *dst = tval + ((size_t)toff[cell] * TILE_R + (s % TILE_R)) * TILE_C;       // the strip of this row in the tile
+            const double *src = a + d.pos;                                                     // a[pos + (c - lo)] is column rank c
+            for (int c = c0 + lane; c < c1; c += 64) dst[c - w * TILE_C] = src[c - lo];
             if (lane == 0) atomicAdd(&chk[cell], c1 - c0);              // upper entries put into the tile (balanced by the mirror entries removed)
         }
     }

@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--workload", default="7.5nm")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--warm-start", type=int, default=0, help="dkmc_set_current_warm_start mode (0 = reference)")
+    ap.add_argument("--x-format", type=int, default=1, help="1: tiled X (default); 0: CSR X as the reference stores it")
     ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
                     help="N > 1: replicas (weak scaling, default) or ONE simulation with the sharded current solve (strong scaling)")
     ap.add_argument("--no-sharded", action="store_true", help="N > 1: skip the sharded-solve block")
@@ -97,6 +98,7 @@ def main():
     sim = host.KMCProcess(dev, p.freq)
     gb = dev.make_gpubuf(devname)
     L.dkmc_set_current_warm_start(args.warm_start)
+    L.dkmc_set_x_format(args.x_format)
     dev.setLaplacePotential(gb, p, Vd)
     gb.sync_HostToGPU(dev)
 
@@ -177,7 +179,16 @@ def main():
         # 8 B result written, 8 B of p read for the fused dot; one launch covers every row of X
         nnz_all = st["spmv_long_nnz"] + st["spmv_short_nnz"]
         rows_all = st["spmv_long_rows"] + st["spmv_short_rows"]
-        if st["spmv_segments"] > 0:
+        if st["xt_subblocks"] > 0:
+            # tiled X (default): the dominant kernel is k_xt_apply -- one wave per run of tiles of the tunnelling block (8 KiB per stored
+            # 32 x 32 sub-block, read once for both triangles; 16 B descriptor, 32 row sums written per tile; 256 column sums per
+            # run) plus, in the same launch, the neighbour part Xs in CSR form (12 B per non-zero, 8 B row pointer, 8 B result,
+            # 8 B scale and 4 B class per row)
+            kname = "k_xt_apply"
+            bytes_per_launch = (8192.0 * st["xt_local_subblocks"] + (16.0 + 256.0) * st["spmv_tiles"] + (16.0 + 2048.0) * st["xt_items"]
+                                + 12.0 * st["xt_sparse_nnz"] + 28.0 * rows_all)
+            csr_equiv = 12.0 * nnz_all + 24.0 * rows_all
+        elif st["spmv_segments"] > 0:
             # dense-run mode: the dominant kernel is k_spmv_segs (one wave per <= 2048-entry segment of a tunnelling row, and
             # one wave per symmetric tile); its layout moves 8 B per entry read (value only; the direction vector is
             # compacted over S and stays in L2), 16 B per segment descriptor and 8 B per segment result.  The CSR
@@ -208,7 +219,7 @@ def main():
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "csr_equivalent_GBps": round(csr_equiv / (avg_ms * 1e-3) / 1e9, 1),
                 "symmetric_tiles": int(st["spmv_tiles"]), "tile_entries": int(st["spmv_tile_entries"]),
-                "segment_entries": int(st["spmv_segment_entries"]),
+                "segment_entries": int(st["spmv_segment_entries"]), "subblocks": int(st["xt_subblocks"]), "tile_runs": int(st["xt_items"]),
                 "row_kernel_us": round(prof["short_ms"] / max(prof["short_n"], 1) * 1e3, 2)}
 
     # ---- CPU baseline: the oracle (own OpenMP port of the same step) on this box's host cores, rank 0, N=1 only ----

@@ -103,7 +103,8 @@ struct Engine {
     double cg_tol = 1e-6;
     int current_warm_start = 0;
     int profiling = 0;
-    int symmetric_tiles = 1;       // CG on X: read dense blocks of the (symmetric) tunnelling part once for both triangles (cg.hip)
+    int x_format = 1;              // 1: tiled X (xt.hip, default); 0: CSR X as the reference stores it (current.hip + cg.hip)
+    int symmetric_tiles = 1;       // CSR X only: CG on X: read dense blocks of the (symmetric) tunnelling part once for both triangles (cg.hip)
     int x_iter_hint = 0;           // iteration count of the previous CG solve of X (sizes the first launch batch)
     dkmc_stats stats{};
     char err[512] = {0};
@@ -112,7 +113,7 @@ struct Engine {
     double E_gen[DKMC_MAX_LAYERS] = {0}, E_rec[DKMC_MAX_LAYERS] = {0}, E_Vdiff[DKMC_MAX_LAYERS] = {0}, E_Odiff[DKMC_MAX_LAYERS] = {0};
     int num_layers = 0;
     // named persistent device buffers (grown on demand, never shrunk)
-    static const int NBUF = 96;
+    static const int NBUF = 160;
     void *buf[NBUF] = {nullptr};
     size_t bufsz[NBUF] = {0};
 };
@@ -136,7 +137,10 @@ enum {
     S_AT_FLAG, S_AT_SITE, S_AT_OFSITE, S_AT_NEIGH,
     S_X_ROWPTR, S_X_COL, S_X_DATA, S_X_DATA2, S_X_CNT, S_X_SLIST, S_X_SCB, S_X_SFLAG, S_X_RHS, S_X_SRANK,
     S_P_IMACRO, S_HEAT, S_HEAT_A, S_HEAT_B, S_HEAT_Y,
-    S_MISC0, S_MISC1, S_MISC2, S_MISC3
+    S_MISC0, S_MISC1, S_MISC2, S_MISC3,
+    S_XT_DPOS, S_XT_SNODE_D, S_XT_SNODE_I, S_XT_CMASK, S_XT_ISTILE, S_XT_NSUBC, S_XT_TOFF, S_XT_SOFF, S_XT_TILES, S_XT_NITEMW, S_XT_WRANGE,
+    S_XT_ITEMS, S_XT_ISUB, S_XT_TVAL, S_XT_ROWPART, S_XT_COLPART, S_XT_CNT, S_XT_Q,
+    S_NSLOTS
 };
 
 // exchange step of the sharded current solve (comm.hip)

@@ -1,0 +1,917 @@
+// xt.hip -- the current solve on the TILED form of X (default; dkmc_set_x_format(1)).
+//
+// Replaces, for the solve itself, Assemble_X_sparsity / Assemble_X2 (iterative_solvers_gpu.cu:1909-1983, 2113-2156) and
+// solve_sparse_CG_Jacobi (:309-480) as update_power_gpu_sparse uses them (current_solver_gpu.cu:854-1147).  The reference
+// (and the CSR path of current.hip, kept for inspection) stores every entry of X in CSR.  X has two very different parts:
+//   * the neighbour part Xs: drivers, diagonal, <= nn direct couplings per atom -- O(N_atom) entries, a small CSR;
+//   * the tunnelling block T over the set S = {vacancies} U {inner-contact metals}: every non-neighbour pair (a, b) of S
+//     whose conduction-band edges differ by more than tol carries -T(a, b) (WKB, :1649-1693).  |S|^2-ish entries (3.7e9 at
+//     9.4e5 sites), symmetric bit for bit, dense by classes (contact x contact, vacancy x contact).
+// Here T is never written as CSR.  Its UPPER triangle is generated straight into tile-major storage: the S x S index space is
+// cut into cells of 32 S-rows x 256 S-columns, a cell into 8 sub-blocks of 32 x 32; a census (predicate only) finds the
+// non-empty sub-blocks, the fill kernel writes their values (zero where no entry, lower triangle of a diagonal sub-block
+// zero).  8 KiB per stored sub-block, no column indices, no mirror entries, no second (scaled) copy: the Jacobi scaling is
+// applied to the vectors (A p = S X (S p)), so the same unscaled tiles serve the solve, I_macro and the dissipated power.
+// One wave streams a tile once per CG iteration and forms both the row products (t_i += x_ij q_j) and the column products
+// (t_j += x_ij q_i): 4 B of HBM traffic per entry of X.  Work items are runs of up to KC tiles of one 256-column strip:
+// column sums stay in registers across the run, row sums (32 per tile) go to a grid-indexed array; a small second kernel
+// adds, per S-row, its row partials, its column partials and the sparse part.
+// Multi-GPU (comm.hip): work items are dealt to the ranks in contiguous, byte-balanced shares; a rank generates, stores
+// and streams only its tiles; one all-reduce of |S| doubles per matrix-vector product completes the rows.
+#include "xshared.h"
+#include <hip/hip_ext.h>
+#include <vector>
+#include <algorithm>
+#include <stdlib.h>
+
+#define XT_R 32                      // S-rows per tile
+#define XT_C 256                     // S-columns per tile
+#define XT_SBW 32                    // columns per sub-block
+#define XT_SUB (XT_R * XT_SBW)       // doubles per sub-block (8 KiB)
+#define XT_NT 256
+#define XT_MAXKC 16
+#define XT_PROF_STRIDE 8
+
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+
+struct __attribute__((aligned(16))) XTile { int k, w; unsigned mask; int soff; };   // cell (k, w); present sub-blocks; first sub-block slot
+struct __attribute__((aligned(16))) XItem { int t0, t1, w, c; };                    // tiles [t0, t1) of strip w; c = position of the run in its strip
+struct XCtrl { double rr[2]; double pad; int done; int iters; };
+
+struct SNodes {                      // S in rank order, padded to a multiple of XT_C (flag 0 = no entries)
+    const double *x, *y, *z, *cb;
+    const int *flag, *slot, *mr;     // class flags; row of the coefficient cache (vacancies) / column (metals), -1 if none
+};
+
+// value of the tunnelling entry between two members of S (0 = no entry); symmetric in its two atoms bit for bit
+__device__ __forceinline__ double xt_tvalue(const XParams &P, double prefac, const TCacheView &TC,
+                                            double x1, double y1, double z1, double cb1, int f1, int slot1, int mr1,
+                                            double x2, double y2, double z2, double cb2, int f2, int slot2, int mr2)
+{
+    const double d = site_dist(x1, y1, z1, x2, y2, z2, P.laty, P.latz, P.pbc);
+    if (d < P.nn_dist) return 0.0;                                   // neighbour pair: direct term, part of Xs
+    const int kind = tunnel_kind<AF_MP_VAL>(f1, f2, cb1, cb2, P.tol);
+    if (!kind) return 0.0;
+    if (kind == 1 && TC.enabled) {
+        const int slot = (f1 & AF_V) ? slot1 : slot2, mr = (f1 & AF_V) ? mr2 : mr1;
+        if (slot >= 0 && mr >= 0) return -TC.vals[(size_t)slot * TC.nM + mr];
+    }
+    return -wkb_T(kind, 1e-10 * d, fabs(cb1 - cb2), prefac, P.V0);
+}
+
+// ---- S in solver order ---------------------------------------------------------------------------------------------------
+__global__ void k_xt_snodes(int ns, int ns_pad, const SEntry *__restrict__ S, const double *__restrict__ ax, const double *__restrict__ ay,
+                            const double *__restrict__ az, const int *__restrict__ atom_site, TCacheView TC,
+                            double *sx, double *sy, double *sz, double *scb, int *sflag, int *sslot, int *smr, int *srow)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ns_pad) return;
+    if (s < ns) {
+        const SEntry e = S[s];
+        sx[s] = ax[e.idx]; sy[s] = ay[e.idx]; sz[s] = az[e.idx]; scb[s] = e.cb; sflag[s] = e.flag; srow[s] = e.idx + 2;
+        sslot[s] = (TC.enabled && (e.flag & AF_V)) ? TC.slot_of_site[atom_site[e.idx]] : -1;
+        smr[s] = TC.enabled ? TC.mrank_atom[e.idx] : -1;
+    } else { sx[s] = 0; sy[s] = 0; sz[s] = 0; scb[s] = 0; sflag[s] = 0; sslot[s] = -1; smr[s] = -1; srow[s] = -1; }
+}
+
+// ---- census: which 32 x 32 sub-blocks of the upper triangle hold an entry -----------------------------------------------------
+// One wave per cell, cells in strip-major order (ci = w * nK + k).  Predicate only (no WKB value): class flags, |dE| > tol,
+// not a neighbour pair, column rank above row rank.  A full cell is recognised after its first row.
+__global__ __launch_bounds__(XT_NT) void k_xt_census(XParams P, int ns, int nK, int nW, SNodes S, unsigned *__restrict__ cmask)
+{
+    const int lane = threadIdx.x & 63;
+    const long long ci = (long long)blockIdx.x * (XT_NT / 64) + (threadIdx.x >> 6);
+    if (ci >= (long long)nK * nW) return;
+    const int w = (int)(ci / nK), k = (int)(ci % nK);
+    unsigned m = 0;
+    if (XT_C * w + XT_C - 1 > XT_R * k) {                            // the cell reaches above the diagonal
+        double cx[4], cy[4], cz[4], ccb[4]; int cf[4], csc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int sc = XT_C * w + lane + 64 * j;                 // lanes 0-31: sub-block 2j, lanes 32-63: sub-block 2j+1
+            csc[j] = sc; cx[j] = S.x[sc]; cy[j] = S.y[sc]; cz[j] = S.z[sc]; ccb[j] = S.cb[sc]; cf[j] = S.flag[sc];
+        }
+        for (int r = 0; r < XT_R; ++r) {
+            const int s = XT_R * k + r;
+            if (s >= ns) break;
+            const double rx = S.x[s], ry = S.y[s], rz = S.z[s], rcb = S.cb[s]; const int rf = S.flag[s];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool pred = csc[j] > s && tunnel_kind<AF_MP_VAL>(rf, cf[j], rcb, ccb[j], P.tol) != 0 &&
+                                  !(site_dist(rx, ry, rz, cx[j], cy[j], cz[j], P.laty, P.latz, P.pbc) < P.nn_dist);
+                const unsigned long long bal = __ballot(pred);
+                if (bal & 0xffffffffull) m |= 1u << (2 * j);
+                if (bal >> 32) m |= 1u << (2 * j + 1);
+            }
+            if (m == 0xffu) break;
+        }
+    }
+    if (lane == 0) cmask[ci] = m;
+}
+__global__ void k_xt_cell_counts(long long ncell, const unsigned *__restrict__ cmask, int *__restrict__ is_tile, int *__restrict__ nsub)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ncell) { const unsigned m = cmask[i]; is_tile[i] = m != 0; nsub[i] = __popc(m); }
+}
+__global__ void k_xt_tile_list(int nK, long long ncell, const unsigned *__restrict__ cmask, const int *__restrict__ toff, const int *__restrict__ soff,
+                               XTile *__restrict__ tiles)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < ncell && cmask[i]) { XTile t; t.k = (int)(i % nK); t.w = (int)(i / nK); t.mask = cmask[i]; t.soff = soff[i]; tiles[toff[i]] = t; }
+}
+// per strip: number of work items; per row block: first / one-past-last window holding a tile
+__global__ void k_xt_strips(int nK, int nW, int kc, int ntiles, const int *__restrict__ toff, const unsigned *__restrict__ cmask,
+                            int *__restrict__ nitem_w, int2 *__restrict__ wrange)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nW) {
+        const int t0 = toff[(long long)i * nK], t1 = (i + 1 < nW) ? toff[(long long)(i + 1) * nK] : ntiles;
+        nitem_w[i] = (t1 - t0 + kc - 1) / kc;
+    }
+    if (i < nK) {
+        int b = nW, e = 0;
+        for (int w = 0; w < nW; ++w) if (cmask[(long long)w * nK + i]) { b = min(b, w); e = w + 1; }
+        wrange[i] = make_int2(b, e);
+    }
+}
+__global__ void k_xt_items(int nK, int nW, int kc, int ntiles, const int *__restrict__ toff, const int *__restrict__ ioff,
+                           const XTile *__restrict__ tiles, XItem *__restrict__ items, int *__restrict__ isub)
+{
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nW) return;
+    const int t0 = toff[(long long)w * nK], t1 = (w + 1 < nW) ? toff[(long long)(w + 1) * nK] : ntiles;
+    int o = ioff[w], c = 0;
+    for (int t = t0; t < t1; t += kc, ++o, ++c) { XItem it; it.t0 = t; it.t1 = min(t + kc, t1); it.w = w; it.c = c; items[o] = it; isub[o] = tiles[t].soff; }
+}
+
+// ---- fill: values of the stored sub-blocks --------------------------------------------------------------------------------
+// One workgroup per tile; thread (q = tid / 32, c = tid % 32) owns column 32 q + c of the tile and walks its 32 rows.
+// Element (row r, column 32 q + c) of sub-block slot sl sits at ((sl * 32 + r) * 32 + c): a sub-block is 8 consecutive
+// 1-KiB wave loads of the apply kernel.
+__global__ __launch_bounds__(XT_NT) void k_xt_fill(XParams P, int ns, const XTile *__restrict__ tiles, int sub_base, SNodes S, TCacheView TC,
+                                                   double *__restrict__ tval, unsigned long long *__restrict__ nnz_upper)
+{
+    __shared__ double rx[XT_R], ry[XT_R], rz[XT_R], rcb[XT_R];
+    __shared__ int rf[XT_R], rslot[XT_R], rmr[XT_R];
+    const XTile td = tiles[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (tid < XT_R) {
+        const int s = XT_R * td.k + tid;           // < ns_pad: the arrays are padded
+        rx[tid] = S.x[s]; ry[tid] = S.y[s]; rz[tid] = S.z[s]; rcb[tid] = S.cb[s]; rf[tid] = S.flag[s]; rslot[tid] = S.slot[s]; rmr[tid] = S.mr[s];
+    }
+    __syncthreads();
+    const int q = tid >> 5, c = tid & 31;
+    int cnt = 0;
+    if ((td.mask >> q) & 1u) {
+        const int sl = __popc(td.mask & ((1u << q) - 1u));
+        double *dst = tval + ((size_t)(td.soff - sub_base) + sl) * XT_SUB + c;
+        const int sc = XT_C * td.w + XT_SBW * q + c;
+        const double cx = S.x[sc], cy = S.y[sc], cz = S.z[sc], ccb = S.cb[sc];
+        const int cf = S.flag[sc], cslot = S.slot[sc], cmr = S.mr[sc];
+        const double prefac = -(sqrt(2 * P.m_e) / DKMC_HBAR) * (2.0 / 3.0);
+        for (int r = 0; r < XT_R; ++r) {
+            const int s = XT_R * td.k + r;
+            double v = 0.0;
+            if (sc > s && cf && rf[r])
+                v = xt_tvalue(P, prefac, TC, rx[r], ry[r], rz[r], rcb[r], rf[r], rslot[r], rmr[r], cx, cy, cz, ccb, cf, cslot, cmr);
+            dst[r * XT_SBW] = v;
+            cnt += v != 0.0;
+        }
+    }
+    cnt = wave_sum_all_i(cnt);
+    if ((tid & 63) == 0 && cnt) atomicAdd(nnz_upper, (unsigned long long)cnt);
+}
+
+// ---- apply: one pass over the tiles (+ the sparse rows in the same launch) -----------------------------------------------
+// OP 0: matrix-vector product; OP 1: dissipated power (host formula current_solver.cpp:288-357 on the pairs of T).
+template <int OP>
+__device__ __forceinline__ void xt_acc(const dbl2 v, const double pcx, const double pcy, const double pr, double &ra, double &cax, double &cay, bool vpos)
+{
+    if (OP == 0) { ra += v.x * pcx + v.y * pcy; cax += v.x * pr; cay += v.y * pr; }
+    else {
+        // entry x between row node i (potential pr) and column node j (pcx / pcy): ical = x (m_i - m_j); the pair heats the
+        // node the current flows INTO: row i when ical has the sign opposite to Vd, column j otherwise; amount x (m_i - m_j)^2
+        const double dx = pr - pcx, dy = pr - pcy;
+        const double ix = v.x * dx, iy = v.y * dy;
+        const double ex = ix * dx, ey = iy * dy;
+        const bool rx = vpos ? (ix < 0) : (ix > 0), ry = vpos ? (iy < 0) : (iy > 0);
+        ra += (rx ? ex : 0.0) + (ry ? ey : 0.0);
+        cax += rx ? 0.0 : ex; cay += ry ? 0.0 : ey;
+    }
+}
+
+template <int OP>
+__device__ __forceinline__ void xt_tile_role(const XItem it, const XTile *__restrict__ tiles, int sub_base, const double *__restrict__ tval,
+                                             const double *__restrict__ vS, int nW, int ns_pad, double *__restrict__ rowpart,
+                                             double *__restrict__ colpart, bool vpos)
+{
+    const int lane = threadIdx.x & 63, cc = lane & 15, rr = lane >> 4;
+    const double *vc = vS + (size_t)it.w * XT_C + 2 * cc;
+    double pcx[8], pcy[8], cax[8], cay[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { const dbl2 t = *reinterpret_cast<const dbl2 *>(vc + XT_SBW * q); pcx[q] = t.x; pcy[q] = t.y; cax[q] = 0.0; cay[q] = 0.0; }
+#pragma unroll 1
+    for (int t = it.t0; t < it.t1; ++t) {
+        const XTile td = tiles[t];
+        const double *vr = vS + (size_t)td.k * XT_R + rr;
+        double pr[8], ra[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { pr[j] = vr[4 * j]; ra[j] = 0.0; }
+        const dbl2 *base = reinterpret_cast<const dbl2 *>(tval + (size_t)(td.soff - sub_base) * XT_SUB) + lane;
+        if (td.mask == 0xffu) {
+            // full tile: 64 KiB contiguous, 16 KiB (two sub-blocks) in flight per wave
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                dbl2 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = __builtin_nontemporal_load(base + (size_t)(16 * h + u) * 64);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) xt_acc<OP>(v[u], pcx[2 * h + (u >> 3)], pcy[2 * h + (u >> 3)], pr[u & 7], ra[u & 7], cax[2 * h + (u >> 3)], cay[2 * h + (u >> 3)], vpos);
+            }
+        } else {
+            int sl = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if ((td.mask >> q) & 1u) {                      // wave-uniform
+                    dbl2 v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(base + (size_t)(8 * sl + j) * 64);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xt_acc<OP>(v[j], pcx[q], pcy[q], pr[j], ra[j], cax[q], cay[q], vpos);
+                    ++sl;
+                }
+            }
+        }
+        // 8 row sums per lane -> 32 row sums of the tile: butterfly over the 16 lanes that share rr (bits 3, 2, 1 of the lane
+        // select which half survives, bit 0 completes the sum); fixed order
+#pragma unroll
+        for (int half = 4, bit = 8; half >= 1; half >>= 1, bit >>= 1) {
+            const bool up = (lane & bit) != 0;
+#pragma unroll
+            for (int j = 0; j < half; ++j) {
+                const double keep = up ? ra[j + half] : ra[j];
+                const double send = up ? ra[j] : ra[j + half];
+                ra[j] = keep + __shfl_xor(send, bit, WAVE);
+            }
+        }
+        const double rs = ra[0] + __shfl_xor(ra[0], 1, WAVE);
+        const int j = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+        if (!(lane & 1)) rowpart[((size_t)td.k * nW + td.w) * XT_R + 4 * j + rr] = rs;
+    }
+    double *cp = colpart + (size_t)it.c * ns_pad + (size_t)it.w * XT_C + 2 * cc;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        double a = cax[q], b = cay[q];
+        a += __shfl_xor(a, 16, WAVE); b += __shfl_xor(b, 16, WAVE);
+        a += __shfl_xor(a, 32, WAVE); b += __shfl_xor(b, 32, WAVE);
+        if (rr == 0) { dbl2 o; o.x = a; o.y = b; *reinterpret_cast<dbl2 *>(cp + XT_SBW * q) = o; }
+    }
+}
+
+// Blocks [0, ntb): tile work items (one per wave).  Blocks [ntb, ntb + nsb): the atom rows of Xs, 8 lanes per row.  The last
+// two blocks: the two driver rows (thousands of entries each).  Non-S rows are finished here (scaled, p.t partial); S rows
+// leave their sparse sum in t for the row kernel.
+__global__ __launch_bounds__(XT_NT) void k_xt_apply(int nitems, const XItem *__restrict__ items, const XTile *__restrict__ tiles, int sub_base,
+                                                    const double *__restrict__ tval, const double *__restrict__ qS, int nW, int ns_pad,
+                                                    double *__restrict__ rowpart, double *__restrict__ colpart, const XCtrl *ctrl,
+                                                    int ntb, int nsb, int Nsub, const xrp_t *__restrict__ rp, const int *__restrict__ ci,
+                                                    const double *__restrict__ val, const double *__restrict__ q, const double *__restrict__ sc,
+                                                    const int *__restrict__ nsrank, const double *__restrict__ pvec, double *__restrict__ t,
+                                                    double *__restrict__ part)
+{
+    __shared__ double red[XT_NT / 64];
+    __shared__ int sdone;
+    if ((int)blockIdx.x < ntb) {
+        if (ctrl->done) return;
+        const int item = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (XT_NT / 64) + (int)(threadIdx.x >> 6));
+        if (item >= nitems) return;
+        xt_tile_role<0>(items[item], tiles, sub_base, tval, qS, nW, ns_pad, rowpart, colpart, true);
+        return;
+    }
+    if (threadIdx.x == 0) sdone = ctrl->done;
+    __syncthreads();
+    if (sdone) return;
+    const int bid = (int)blockIdx.x - ntb;
+    double acc = 0.0;
+    if (bid < nsb) {
+        const int g = threadIdx.x >> 3, l = threadIdx.x & 7;
+        for (int row = 2 + bid * (XT_NT / 8) + g; row < Nsub; row += nsb * (XT_NT / 8)) {
+            const xrp_t p0 = rp[row], p1 = rp[row + 1];
+            double s = 0.0;
+            for (xrp_t p = p0 + l; p < p1; p += 8) s += val[p] * q[ci[p]];
+            s += __shfl_xor(s, 4, 8); s += __shfl_xor(s, 2, 8); s += __shfl_xor(s, 1, 8);
+            if (l == 0) {
+                if (nsrank[row] < 0) { const double tv = sc[row] * s; t[row] = tv; acc += pvec[row] * tv; }
+                else t[row] = s;
+            }
+        }
+    } else {
+        const int row = bid - nsb;                                  // 0 or 1
+        const xrp_t p0 = rp[row], p1 = rp[row + 1];
+        double s0 = 0.0, s1 = 0.0;
+        xrp_t p = p0 + threadIdx.x;
+        for (; p + XT_NT < p1; p += 2 * XT_NT) { s0 += val[p] * q[ci[p]]; s1 += val[p + XT_NT] * q[ci[p + XT_NT]]; }
+        if (p < p1) s0 += val[p] * q[ci[p]];
+        const double s = block_sum_all<XT_NT>(s0 + s1, red);
+        const double tv = sc[row] * s;
+        if (threadIdx.x == 0) { t[row] = tv; part[bid] = pvec[row] * tv; }
+        return;
+    }
+    const double tot = block_sum_all<XT_NT>(acc, red);
+    if (threadIdx.x == 0) part[bid] = tot;
+}
+// tiles only (diagonal pass with q = 1, power pass with q = m)
+template <int OP>
+__global__ __launch_bounds__(XT_NT) void k_xt_tiles_only(int nitems, const XItem *__restrict__ items, const XTile *__restrict__ tiles, int sub_base,
+                                                         const double *__restrict__ tval, const double *__restrict__ vS, int nW, int ns_pad,
+                                                         double *__restrict__ rowpart, double *__restrict__ colpart, int vpos)
+{
+    const int item = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (XT_NT / 64) + (int)(threadIdx.x >> 6));
+    if (item >= nitems) return;
+    xt_tile_role<OP>(items[item], tiles, sub_base, tval, vS, nW, ns_pad, rowpart, colpart, vpos != 0);
+}
+
+// ---- row kernel: per S-row, row partials (ascending window) + column partials (ascending run) ------------------------------
+// One wave per row block (32 S-rows x 2 halves of the partial lists).  MODE 0: t = s_i (sparse sum + tile sums), p.t partial.
+// MODE 1: xout[s] = tile sums only (this rank's share / the diagonal and power passes).
+template <int MODE>
+__global__ __launch_bounds__(XT_NT) void k_xt_rows(int ns, int nK, int nW, int ns_pad, const int2 *__restrict__ wrange, const int *__restrict__ nitem_w,
+                                                   const double *__restrict__ rowpart, const double *__restrict__ colpart,
+                                                   const int *__restrict__ srow, const double *__restrict__ sS, const double *__restrict__ pvec,
+                                                   double *__restrict__ t, double *__restrict__ part, const XCtrl *ctrl, double *__restrict__ xout)
+{
+    __shared__ double red[XT_NT / 64];
+    __shared__ int sdone;
+    if (ctrl) {
+        if (threadIdx.x == 0) sdone = ctrl->done;
+        __syncthreads();
+        if (sdone) return;
+    }
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    double acc = 0.0;
+    for (int k = blockIdx.x * (XT_NT / 64) + (threadIdx.x >> 6); k < nK; k += gridDim.x * (XT_NT / 64)) {
+        const int s = XT_R * k + r;
+        const int2 wr = wrange[k];
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        const double *rpp = rowpart + (size_t)k * nW * XT_R + r;
+        int w = wr.x + h;
+        for (; w + 6 < wr.y; w += 8) { a0 += rpp[(size_t)w * XT_R]; a1 += rpp[(size_t)(w + 2) * XT_R]; a2 += rpp[(size_t)(w + 4) * XT_R]; a3 += rpp[(size_t)(w + 6) * XT_R]; }
+        for (; w < wr.y; w += 2) a0 += rpp[(size_t)w * XT_R];
+        const int nc = nitem_w[k / (XT_C / XT_R)];
+        const double *cpp = colpart + s;
+        int c = h;
+        for (; c + 6 < nc; c += 8) { a0 += cpp[(size_t)c * ns_pad]; a1 += cpp[(size_t)(c + 2) * ns_pad]; a2 += cpp[(size_t)(c + 4) * ns_pad]; a3 += cpp[(size_t)(c + 6) * ns_pad]; }
+        for (; c < nc; c += 2) a0 += cpp[(size_t)c * ns_pad];
+        double sum = (a0 + a1) + (a2 + a3);
+        sum += __shfl_xor(sum, 32, WAVE);
+        if (h == 0 && s < ns) {
+            if (MODE == 1) xout[s] = sum;
+            else { const int row = srow[s]; const double tv = sS[s] * (t[row] + sum); t[row] = tv; acc += pvec[row] * tv; }
+        }
+    }
+    if (MODE == 1) return;
+    const double tot = block_sum_all<XT_NT>(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+// sharded solve, after the all-reduce of xout: finish the S rows (same thread-to-row mapping as MODE 0: same partials)
+__global__ __launch_bounds__(XT_NT) void k_xt_rows_apply(int ns, int nK, const double *__restrict__ xbuf, const int *__restrict__ srow,
+                                                         const double *__restrict__ sS, const double *__restrict__ pvec, double *__restrict__ t,
+                                                         double *__restrict__ part, const XCtrl *ctrl)
+{
+    __shared__ double red[XT_NT / 64];
+    __shared__ int sdone;
+    if (threadIdx.x == 0) sdone = ctrl->done;
+    __syncthreads();
+    if (sdone) return;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    double acc = 0.0;
+    for (int k = blockIdx.x * (XT_NT / 64) + (threadIdx.x >> 6); k < nK; k += gridDim.x * (XT_NT / 64)) {
+        const int s = XT_R * k + r;
+        if (h == 0 && s < ns) { const int row = srow[s]; const double tv = sS[s] * (t[row] + xbuf[s]); t[row] = tv; acc += pvec[row] * tv; }
+    }
+    const double tot = block_sum_all<XT_NT>(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+
+// ---- vector kernels of the CG (sign convention and stop tests of solve_sparse_CG_Jacobi, iterative_solvers_gpu.cu:349-459) ----
+__device__ __forceinline__ double xt_reduce(const double *part, int n, double *red, const XCtrl *ctrl, bool *done)
+{
+    __shared__ int sdone;
+    if (threadIdx.x == 0) sdone = ctrl->done;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += XT_NT) s += part[i];
+    s = block_sum_all<XT_NT>(s, red);
+    *done = sdone != 0;
+    return s;
+}
+// diag -= tile row sums (S rows); s = 1/sqrt(diag); b *= s; y /= s; q = s * y (= the caller's y); compact copies over S
+__global__ void k_xt_scale_init(int Nsub, const xrp_t *__restrict__ diag_pos, double *__restrict__ val, const int *__restrict__ nsrank,
+                                const double *__restrict__ tsum, double *__restrict__ sc, double *__restrict__ b, double *__restrict__ y,
+                                double *__restrict__ q, double *__restrict__ sS, double *__restrict__ qS)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Nsub) return;
+    const int sr = nsrank[i];
+    double d = val[diag_pos[i]];
+    if (sr >= 0) { d = d + -tsum[sr]; val[diag_pos[i]] = d; }       // calc_diagonal_X_gpu: diag += -(sum of the row's off-diagonals)
+    const double s = 1.0 / sqrt(d);
+    sc[i] = s;
+    b[i] = b[i] * s;
+    const double ys = y[i] * 1 / s;
+    y[i] = ys;
+    const double qv = s * ys;
+    q[i] = qv;
+    if (sr >= 0) { sS[sr] = s; qS[sr] = qv; }
+}
+// r = t - b ; p = -r ; q = s p ; partial r.r
+__global__ __launch_bounds__(XT_NT) void k_xt_resid_init(int m, const double *__restrict__ t, const double *__restrict__ b, double *__restrict__ r,
+                                                         double *__restrict__ p, const double *__restrict__ sc, double *__restrict__ q,
+                                                         const int *__restrict__ nsrank, double *__restrict__ qS, double *__restrict__ part)
+{
+    __shared__ double red[XT_NT / 64];
+    double acc = 0.0;
+    for (int i = blockIdx.x * XT_NT + threadIdx.x; i < m; i += gridDim.x * XT_NT) {
+        const double rv = -b[i] + t[i];
+        r[i] = rv; p[i] = -rv; acc += rv * rv;
+        const double qv = sc[i] * -rv;
+        q[i] = qv;
+        const int sr = nsrank[i];
+        if (sr >= 0) qS[sr] = qv;
+    }
+    const double tot = block_sum_all<XT_NT>(acc, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(XT_NT) void k_xt_check0(const double *part, int npart, XCtrl *ctrl, double tol2)
+{
+    __shared__ double red[XT_NT / 64];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < npart; i += XT_NT) s += part[i];
+    const double rr = block_sum_all<XT_NT>(s, red);
+    if (threadIdx.x == 0) { ctrl->rr[0] = rr; ctrl->rr[1] = rr; ctrl->iters = 0; ctrl->done = !(sqrt(rr) > tol2); }
+}
+// alpha = rr / p.t ; y += alpha p ; r += alpha t ; partial r.r
+__global__ __launch_bounds__(XT_NT) void k_xt_update(int m, int it, const double *__restrict__ part_pt, int npart, const double *__restrict__ p,
+                                                     const double *__restrict__ t, double *__restrict__ y, double *__restrict__ r,
+                                                     double *__restrict__ part_rr, const XCtrl *ctrl)
+{
+    __shared__ double red[XT_NT / 64];
+    bool done;
+    const double pAp = xt_reduce(part_pt, npart, red, ctrl, &done);
+    if (done) return;
+    const double alpha = ctrl->rr[it & 1] / pAp;
+    double acc = 0.0;
+    for (int i = blockIdx.x * XT_NT + threadIdx.x; i < m; i += gridDim.x * XT_NT) {
+        y[i] += alpha * p[i];
+        const double rn = r[i] + alpha * t[i];
+        r[i] = rn;
+        acc += rn * rn;
+    }
+    const double tot = block_sum_all<XT_NT>(acc, red);
+    if (threadIdx.x == 0) part_rr[blockIdx.x] = tot;
+}
+// beta = rr' / rr ; p = beta p - r ; q = s p ; stop test on rr'
+__global__ __launch_bounds__(XT_NT) void k_xt_direction(int m, int it, const double *__restrict__ part_rr, int npart, const double *__restrict__ r,
+                                                        double *__restrict__ p, const double *__restrict__ sc, double *__restrict__ q,
+                                                        const int *__restrict__ nsrank, double *__restrict__ qS, XCtrl *ctrl, double tol2)
+{
+    __shared__ double red[XT_NT / 64];
+    bool done;
+    const double rr_new = xt_reduce(part_rr, npart, red, ctrl, &done);
+    if (done) return;
+    const double beta = rr_new / ctrl->rr[it & 1];
+    for (int i = blockIdx.x * XT_NT + threadIdx.x; i < m; i += gridDim.x * XT_NT) {
+        const double pn = p[i] * beta - r[i];
+        p[i] = pn;
+        const double qv = sc[i] * pn;
+        q[i] = qv;
+        const int sr = nsrank[i];
+        if (sr >= 0) qS[sr] = qv;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctrl->rr[(it + 1) & 1] = rr_new;
+        ctrl->iters = it + 1;
+        if (!(rr_new > tol2)) ctrl->done = 1;
+    }
+}
+__global__ void k_xt_vec_mul(int m, double *__restrict__ y, const double *__restrict__ s)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) y[i] = y[i] * s[i];
+}
+__global__ void k_xt_fill_f64(double *p, long long n, double v)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void k_xt_node_srank(int Nsub, const int *__restrict__ srank, int *__restrict__ node_srank)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Nsub) node_srank[i] = i < 2 ? -1 : srank[i - 2];
+}
+__global__ void k_xt_gather_S(int ns, const int *__restrict__ srow, const double *__restrict__ v, double *__restrict__ vS)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < ns) vS[s] = v[srow[s]];
+}
+// dissipated power of every atom row: sparse part (8 lanes per row) + the tile sums of S rows; host formula on X's pattern
+// (current_solver.cpp:299-357; see SURVEY B8/B9 for the index slips of the CUDA kernels this replaces)
+__global__ __launch_bounds__(XT_NT) void k_xt_power_rows(int Nsub, const xrp_t *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ val,
+                                                         const double *__restrict__ m, double Vd, const int *__restrict__ nsrank,
+                                                         const double *__restrict__ psumS, const int *__restrict__ aflag,
+                                                         const int *__restrict__ atom_site, double alpha, double *__restrict__ site_power)
+{
+    const int g = threadIdx.x >> 3, l = threadIdx.x & 7;
+    const int i = 2 + blockIdx.x * (XT_NT / 8) + g;
+    if (i >= Nsub) return;
+    const double mi = m[i];
+    double p = 0.0;
+    for (xrp_t q = rp[i] + l; q < rp[i + 1]; q += 8) {
+        const int c = ci[q];
+        if (c < 2 || c == i) continue;
+        const double ical = val[q] * (mi - m[c]);
+        double v = 0.0;
+        if ((ical < 0 && Vd > 0) || (ical > 0 && Vd < 0)) v = -ical;
+        p += v * (m[c] - mi);
+    }
+    p += __shfl_xor(p, 4, 8); p += __shfl_xor(p, 2, 8); p += __shfl_xor(p, 1, 8);
+    const int a = i - 2;
+    if (l == 0 && !(aflag[a] & AF_METAL)) {
+        const int sr = nsrank[i];
+        if (sr >= 0) p += psumS[sr];
+        site_power[atom_site[a]] = -1 * alpha * p;
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------------------------------------
+struct XTState {
+    // shape of the last assembly
+    int Nsub = 0, ns = 0, ns_pad = 0, nK = 0, nW = 0, ntiles = 0, nitems = 0, kc = 1, maxchunk = 1;
+    long long nsub_total = 0, xs_nnz = 0;
+    unsigned long long t_upper = 0;
+    // this rank's share
+    int item_lo = 0, item_n = 0, tile_lo = 0, tile_n = 0; long long sub_base = 0, sub_n = 0;
+    bool valid = false;
+};
+static XTState g_xt;
+
+struct XTBuffers {
+    SNodes S; int *srow; XTile *tiles; XItem *items; int2 *wrange; int *nitem_w; double *tval, *rowpart, *colpart;
+    xrp_t *rp, *dpos; int *ci; double *val; int *nsrank;
+};
+static XTBuffers g_xb;
+
+static inline int xt_grid(long long work, int per_block, int cap)
+{
+    long long b = (work + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+// one pass over this rank's tiles with the vector vS (compact over S), tile sums of every S-row into out[ns] (all ranks)
+template <int OP>
+static int xt_tile_sums(const double *vS, double *out, int vpos)
+{
+    Engine &e = eng(); hipStream_t st = e.stream; const XTState &X = g_xt;
+    if (X.item_n > 0)
+        hipLaunchKernelGGL((k_xt_tiles_only<OP>), dim3((X.item_n + 3) / 4), dim3(XT_NT), 0, st, X.item_n, (const XItem *)g_xb.items + X.item_lo,
+                           (const XTile *)g_xb.tiles, (int)X.sub_base, (const double *)g_xb.tval, vS, X.nW, X.ns_pad, g_xb.rowpart, g_xb.colpart, vpos);
+    hipLaunchKernelGGL((k_xt_rows<1>), dim3(xt_grid(X.nK, 4, 256)), dim3(XT_NT), 0, st, X.ns, X.nK, X.nW, X.ns_pad, (const int2 *)g_xb.wrange,
+                       (const int *)g_xb.nitem_w, (const double *)g_xb.rowpart, (const double *)g_xb.colpart, (const int *)nullptr,
+                       (const double *)nullptr, (const double *)nullptr, (double *)nullptr, (double *)nullptr, (const XCtrl *)nullptr, out);
+    KCHK();
+    if (comm_attached()) { int rc = comm_allreduce_sum_f64(out, (size_t)X.ns); if (rc) return rc; }
+    return 0;
+}
+
+// Assemble Xs + tiles and solve X m = rhs with the Jacobi-scaled CG.  aneigh/ancnt/aflag/srank/S/atom_site: current.hip steps 1-2.
+int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEntry *S, const int *aneigh, const int *ancnt, const int *aflag,
+                          const int *srank, const int *atom_site, const TCacheView &TC, double *rhs, double *y, int *iters_out, double *rr_out)
+{
+    Engine &e = eng(); hipStream_t st = e.stream;
+    XTState &X = g_xt; X.valid = false;
+    const int Na = P.Na, Nsub = Na + 1;
+    X.Nsub = Nsub; X.ns = ns;
+    const int ns_pad = ((ns + XT_C - 1) / XT_C) * XT_C + XT_C;          // one window of slack: tiles of the last row block read pS[32k + ...] up to ns_pad
+    X.ns_pad = ns_pad;
+    const int nK = (ns + XT_R - 1) / XT_R, nW = (ns + XT_C - 1) / XT_C;
+    X.nK = nK; X.nW = nW;
+    const long long ncell = (long long)nK * nW;
+    if (ncell > 0x7ffffff0ll) return dkmc_fail(47, "update_power: too many tile cells", __FILE__, __LINE__);
+
+    // ---- sparse part Xs: neighbour pattern of every row + values (same kernels as the CSR path, all rows) ----
+    int *cnt = (int *)scratch(S_X_CNT, (size_t)(Nsub + 4) * 4);
+    xrp_t *rp = (xrp_t *)scratch(S_X_ROWPTR, (size_t)(Nsub + 4) * sizeof(xrp_t));
+    xrp_t *dpos = (xrp_t *)scratch(S_XT_DPOS, (size_t)(Nsub + 4) * sizeof(xrp_t));
+    int *nsrank = (int *)scratch(S_X_SCB, (size_t)(Nsub + 4) * 4);
+    if (!cnt || !rp || !dpos || !nsrank) return e.err_code;
+    const int nbr = (Nsub + 255) / 256;
+    hipLaunchKernelGGL((k_xpat_plain<0>), dim3(nbr), dim3(256), 0, st, P, (const int *)nullptr, aneigh, ancnt, cnt, (const xrp_t *)nullptr, (int *)nullptr);
+    int rc = dkmc_exclusive_scan_i32_i64(cnt, rp, Nsub, rp + Nsub); if (rc) return rc;
+    long long xs_nnz = 0;
+    HIPCHK(hipMemcpyAsync(&xs_nnz, rp + Nsub, sizeof(long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (xs_nnz <= 0) return dkmc_fail(10, "update_power: empty X", __FILE__, __LINE__);
+    X.xs_nnz = xs_nnz;
+    int *col = (int *)scratch(S_X_COL, (size_t)xs_nnz * 4);
+    double *val = (double *)scratch(S_X_DATA, (size_t)xs_nnz * 8);
+    if (!col || !val) return e.err_code;
+    hipLaunchKernelGGL((k_xpat_plain<1>), dim3(nbr), dim3(256), 0, st, P, (const int *)nullptr, aneigh, ancnt, cnt, (const xrp_t *)rp, col);
+    hipLaunchKernelGGL((k_xval<16>), dim3((Nsub + 15) / 16), dim3(256), 0, st, P, Nsub, (const SEntry *)nullptr, 0, (const int *)nullptr, (const xrp_t *)rp,
+                       (const int *)col, (const double *)buf->atom_x, (const double *)buf->atom_y, (const double *)buf->atom_z, aflag,
+                       (const double *)buf->atom_CB_edge, val, TC, atom_site, dpos);
+    hipLaunchKernelGGL(k_xt_node_srank, dim3(nbr), dim3(256), 0, st, Nsub, srank, nsrank);
+    KCHK();
+    g_xb.rp = rp; g_xb.dpos = dpos; g_xb.ci = col; g_xb.val = val; g_xb.nsrank = nsrank;
+
+    // ---- S in solver order ----
+    double *sd = (double *)scratch(S_XT_SNODE_D, (size_t)ns_pad * 4 * 8);
+    int *si = (int *)scratch(S_XT_SNODE_I, (size_t)ns_pad * 4 * 4);
+    if (!sd || !si) return e.err_code;
+    SNodes SN; SN.x = sd; SN.y = sd + ns_pad; SN.z = sd + 2 * (size_t)ns_pad; SN.cb = sd + 3 * (size_t)ns_pad;
+    SN.flag = si; SN.slot = si + ns_pad; SN.mr = si + 2 * (size_t)ns_pad;
+    int *srow = si + 3 * (size_t)ns_pad;
+    hipLaunchKernelGGL(k_xt_snodes, dim3((ns_pad + 255) / 256), dim3(256), 0, st, ns, ns_pad, S, (const double *)buf->atom_x, (const double *)buf->atom_y,
+                       (const double *)buf->atom_z, atom_site, TC, sd, sd + ns_pad, sd + 2 * (size_t)ns_pad, sd + 3 * (size_t)ns_pad,
+                       si, si + ns_pad, si + 2 * (size_t)ns_pad, srow);
+    g_xb.S = SN; g_xb.srow = srow;
+
+    // ---- census -> tile list -> work items ----
+    X.ntiles = 0; X.nitems = 0; X.nsub_total = 0; X.t_upper = 0; X.kc = 1;
+    unsigned *cmask = nullptr; int *is_tile = nullptr, *nsubc = nullptr, *toff = nullptr, *soff = nullptr;
+    if (ncell > 0) {
+        cmask = (unsigned *)scratch(S_XT_CMASK, (size_t)(ncell + 4) * 4);
+        is_tile = (int *)scratch(S_XT_ISTILE, (size_t)(ncell + 4) * 4);
+        nsubc = (int *)scratch(S_XT_NSUBC, (size_t)(ncell + 4) * 4);
+        toff = (int *)scratch(S_XT_TOFF, (size_t)(ncell + 4) * 4);
+        soff = (int *)scratch(S_XT_SOFF, (size_t)(ncell + 4) * 4);
+        if (!cmask || !is_tile || !nsubc || !toff || !soff) return e.err_code;
+        hipLaunchKernelGGL(k_xt_census, dim3((unsigned)((ncell + 3) / 4)), dim3(XT_NT), 0, st, P, ns, nK, nW, SN, cmask);
+        hipLaunchKernelGGL(k_xt_cell_counts, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, ncell, (const unsigned *)cmask, is_tile, nsubc);
+        rc = dkmc_exclusive_scan_i32(is_tile, toff, (int)ncell, toff + ncell); if (rc) return rc;
+        rc = dkmc_exclusive_scan_i32(nsubc, soff, (int)ncell, soff + ncell); if (rc) return rc;
+        int h2[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(&h2[0], toff + ncell, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&h2[1], soff + ncell, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        X.ntiles = h2[0]; X.nsub_total = h2[1];
+        if (h2[1] < 0) return dkmc_fail(47, "update_power: more than 2^31 sub-blocks", __FILE__, __LINE__);
+    }
+    const int ntiles = X.ntiles;
+    X.kc = std::max(1, std::min(XT_MAXKC, ntiles / 4096));
+    X.maxchunk = std::max(1, (nK + X.kc - 1) / X.kc);
+    XTile *tiles = (XTile *)scratch(S_XT_TILES, (size_t)(ntiles + 1) * sizeof(XTile));
+    int *nitem_w = (int *)scratch(S_XT_NITEMW, (size_t)(nW + 4) * 4 * 2);
+    int2 *wrange = (int2 *)scratch(S_XT_WRANGE, (size_t)(nK + 4) * sizeof(int2));
+    if (!tiles || !nitem_w || !wrange) return e.err_code;
+    int *ioff = nitem_w + nW + 2;
+    if (ncell > 0) {
+        hipLaunchKernelGGL(k_xt_tile_list, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, nK, ncell, (const unsigned *)cmask, (const int *)toff, (const int *)soff, tiles);
+        hipLaunchKernelGGL(k_xt_strips, dim3((std::max(nK, nW) + 255) / 256), dim3(256), 0, st, nK, nW, X.kc, ntiles, (const int *)toff, (const unsigned *)cmask, nitem_w, wrange);
+        rc = dkmc_exclusive_scan_i32(nitem_w, ioff, nW, ioff + nW); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(&X.nitems, ioff + nW, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    const int nitems = X.nitems;
+    XItem *items = (XItem *)scratch(S_XT_ITEMS, (size_t)(nitems + 1) * sizeof(XItem));
+    int *isub = (int *)scratch(S_XT_ISUB, (size_t)(nitems + 2) * 4);
+    if (!items || !isub) return e.err_code;
+    if (nitems > 0) hipLaunchKernelGGL(k_xt_items, dim3((nW + 255) / 256), dim3(256), 0, st, nK, nW, X.kc, ntiles, (const int *)toff, (const int *)ioff, (const XTile *)tiles, items, isub);
+    KCHK();
+    g_xb.tiles = tiles; g_xb.items = items; g_xb.wrange = wrange; g_xb.nitem_w = nitem_w;
+
+    // ---- this rank's share of the work items (contiguous, balanced by stored bytes) ----
+    X.item_lo = 0; X.item_n = nitems; X.tile_lo = 0; X.tile_n = ntiles; X.sub_base = 0; X.sub_n = X.nsub_total;
+    const bool sharded = comm_attached() != 0;
+    if (sharded && nitems > 0) {
+        const int nr = comm_nranks(), me = comm_rank();
+        std::vector<int> hsub((size_t)nitems + 1);
+        HIPCHK(hipMemcpy(hsub.data(), isub, (size_t)nitems * 4, hipMemcpyDeviceToHost));
+        hsub[nitems] = (int)X.nsub_total;
+        auto cut = [&](int r) { const long long want = X.nsub_total * r / nr; return (int)(std::lower_bound(hsub.begin(), hsub.begin() + nitems, (int)want) - hsub.begin()); };
+        const int i0 = me == 0 ? 0 : cut(me), i1 = me == nr - 1 ? nitems : cut(me + 1);
+        X.item_lo = i0; X.item_n = std::max(0, i1 - i0);
+        XItem first{}, last{};
+        if (X.item_n > 0) {
+            HIPCHK(hipMemcpy(&first, items + i0, sizeof(XItem), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(&last, items + i1 - 1, sizeof(XItem), hipMemcpyDeviceToHost));
+            X.tile_lo = first.t0; X.tile_n = last.t1 - first.t0; X.sub_base = hsub[i0]; X.sub_n = hsub[i1] - hsub[i0];
+        } else { X.tile_lo = 0; X.tile_n = 0; X.sub_base = 0; X.sub_n = 0; }
+    }
+    e.stats.comm_ranks = sharded ? comm_nranks() : 0;
+    e.stats.comm_count_per_rank = sharded ? ns : 0;
+    e.stats.comm_local_segments = X.item_n;
+
+    // ---- storage + fill ----
+    double *tval = (double *)scratch(S_XT_TVAL, (size_t)(X.sub_n + 1) * XT_SUB * 8);
+    double *rowpart = (double *)scratch(S_XT_ROWPART, (size_t)(ncell + 1) * XT_R * 8);
+    double *colpart = (double *)scratch(S_XT_COLPART, (size_t)X.maxchunk * ns_pad * 8);
+    unsigned long long *d_cnt = (unsigned long long *)scratch(S_XT_CNT, 16);
+    if (!tval || !rowpart || !colpart || !d_cnt) return e.err_code;
+    HIPCHK(hipMemsetAsync(rowpart, 0, (size_t)(ncell + 1) * XT_R * 8, st));
+    HIPCHK(hipMemsetAsync(colpart, 0, (size_t)X.maxchunk * ns_pad * 8, st));
+    HIPCHK(hipMemsetAsync(d_cnt, 0, 16, st));
+    if (X.tile_n > 0)
+        hipLaunchKernelGGL(k_xt_fill, dim3(X.tile_n), dim3(XT_NT), 0, st, P, ns, (const XTile *)tiles + X.tile_lo, (int)X.sub_base, SN, TC, tval, d_cnt);
+    KCHK();
+    g_xb.tval = tval; g_xb.rowpart = rowpart; g_xb.colpart = colpart;
+    X.valid = true;
+
+    // ---- vectors ----
+    const int m = Nsub;
+    double *sc = (double *)scratch(S_CG_S, (size_t)m * 8), *r = (double *)scratch(S_CG_R, (size_t)m * 8);
+    double *p = (double *)scratch(S_CG_P, (size_t)m * 8), *t = (double *)scratch(S_CG_T, (size_t)m * 8);
+    double *q = (double *)scratch(S_XT_Q, (size_t)m * 8);
+    double *vS = (double *)scratch(S_CG_PS, (size_t)ns_pad * 3 * 8);       // qS | sS | scratch of the tile-sum passes (padding stays zero)
+    double *part = (double *)scratch(S_CG_PART, (size_t)3 * 8192 * 8);
+    XCtrl *ctrl = (XCtrl *)scratch(S_CG_CTRL, sizeof(XCtrl));
+    if (!sc || !r || !p || !t || !q || !vS || !part || !ctrl) return e.err_code;
+    double *qS = vS, *sS = vS + ns_pad, *xS = vS + 2 * (size_t)ns_pad;
+    HIPCHK(hipMemsetAsync(vS, 0, (size_t)ns_pad * 3 * 8, st));
+    double *part_pt = part, *part_rr = part + 4096;
+    const double tol2 = e.cg_tol * e.cg_tol;
+
+    // ---- diagonal: -(row sums of T), one pass with the vector of ones ----
+    if (ns > 0) {
+        hipLaunchKernelGGL(k_xt_fill_f64, dim3((ns + 255) / 256), dim3(256), 0, st, qS, (long long)ns, 1.0);
+        rc = xt_tile_sums<0>(qS, xS, 1); if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_xt_scale_init, dim3(nbr), dim3(256), 0, st, m, (const xrp_t *)dpos, val, (const int *)nsrank, (const double *)xS, sc, rhs, y, q, sS, qS);
+    KCHK();
+
+    // ---- launch shapes ----
+    const int ntb = (X.item_n + 3) / 4;
+    const int nsb = xt_grid(std::max(m - 2, 1), 128, 512);
+    const int n2b = xt_grid(std::max(nK, 1), 4, 256);
+    const int gv = xt_grid(m, XT_NT * 4, 256);
+    const int np_pt = nsb + 2 + (ns > 0 ? n2b : 0);
+    double *xbuf = nullptr;
+    if (sharded) { xbuf = (double *)scratch(S_CG_XCHG, (size_t)(ns + 2) * 8); if (!xbuf) return e.err_code; }
+
+    auto matvec = [&](hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t ec) -> int {
+        hipExtLaunchKernelGGL(k_xt_apply, dim3(ntb + nsb + 2), dim3(XT_NT), 0, st, e0, e1, 0, X.item_n, (const XItem *)items + X.item_lo, (const XTile *)tiles,
+                              (int)X.sub_base, (const double *)tval, (const double *)qS, nW, ns_pad, rowpart, colpart, (const XCtrl *)ctrl, ntb, nsb, m,
+                              (const xrp_t *)rp, (const int *)col, (const double *)val, (const double *)q, (const double *)sc, (const int *)nsrank,
+                              (const double *)p, t, part_pt);
+        if (ns <= 0) return 0;
+        if (sharded) {
+            hipLaunchKernelGGL((k_xt_rows<1>), dim3(n2b), dim3(XT_NT), 0, st, ns, nK, nW, ns_pad, (const int2 *)wrange, (const int *)nitem_w, (const double *)rowpart,
+                               (const double *)colpart, (const int *)srow, (const double *)sS, (const double *)p, t, part_pt + nsb + 2, (const XCtrl *)ctrl, xbuf);
+            if (int rcx = comm_allreduce_sum_f64(xbuf, (size_t)ns)) return rcx;
+            if (ec) HIPCHK(hipEventRecord(ec, st));
+            hipExtLaunchKernelGGL(k_xt_rows_apply, dim3(n2b), dim3(XT_NT), 0, st, e2, e3, 0, ns, nK, (const double *)xbuf, (const int *)srow, (const double *)sS,
+                                  (const double *)p, t, part_pt + nsb + 2, (const XCtrl *)ctrl);
+        } else
+            hipExtLaunchKernelGGL((k_xt_rows<0>), dim3(n2b), dim3(XT_NT), 0, st, e2, e3, 0, ns, nK, nW, ns_pad, (const int2 *)wrange, (const int *)nitem_w,
+                                  (const double *)rowpart, (const double *)colpart, (const int *)srow, (const double *)sS, (const double *)p, t,
+                                  part_pt + nsb + 2, (const XCtrl *)ctrl, (double *)nullptr);
+        return 0;
+    };
+
+    // ---- r = A y - b, p = -r ----
+    HIPCHK(hipMemsetAsync(ctrl, 0, sizeof(XCtrl), st));
+    HIPCHK(hipMemsetAsync(p, 0, (size_t)m * 8, st));
+    rc = matvec(nullptr, nullptr, nullptr, nullptr, nullptr); if (rc) return rc;
+    hipLaunchKernelGGL(k_xt_resid_init, dim3(gv), dim3(XT_NT), 0, st, m, (const double *)t, (const double *)rhs, r, p, (const double *)sc, q, (const int *)nsrank, qS, part_rr);
+    hipLaunchKernelGGL(k_xt_check0, dim3(1), dim3(XT_NT), 0, st, (const double *)part_rr, gv, ctrl, tol2);
+    KCHK();
+
+    // ---- optional kernel profile: start/stop events of sampled apply launches (bench.py roofline) ----
+    const bool prof = e.profiling != 0;
+    static hipEvent_t evs[4 * 64], evc[64 / XT_PROF_STRIDE]; static bool evs_ready = false;
+    double prof_long_ms = 0.0, prof_short_ms = 0.0, prof_comm_ms = 0.0; int prof_long_n = 0, prof_short_n = 0, prof_comm_n = 0;
+    if (prof && !evs_ready) { for (auto &ev : evs) HIPCHK(hipEventCreate(&ev)); for (auto &ev : evc) HIPCHK(hipEventCreate(&ev)); evs_ready = true; }
+
+    // ---- iterations in batches; the host polls the control block between batches (batch plan: see cg.hip) ----
+    int it = 0, launched = 0, batch = 8;
+    if (e.x_iter_hint > 24) batch = e.x_iter_hint - 8;
+    XCtrl h{};
+    int loop_rc = 0;
+    for (;;) {
+        HIPCHK(hipMemcpyAsync(&h, ctrl, sizeof(XCtrl), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (prof && launched) {
+            for (int b = 0; b < launched && b < 64; b += XT_PROF_STRIDE) {
+                if (it - launched + b >= h.iters) break;
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, evs[4 * b], evs[4 * b + 1])); prof_long_ms += ms; ++prof_long_n;
+                if (ns > 0) { HIPCHK(hipEventElapsedTime(&ms, evs[4 * b + 2], evs[4 * b + 3])); prof_short_ms += ms; ++prof_short_n; }
+                if (sharded && ns > 0) { HIPCHK(hipEventElapsedTime(&ms, evs[4 * b + 1], evc[b / XT_PROF_STRIDE])); prof_comm_ms += ms; ++prof_comm_n; }
+            }
+        }
+        if (h.done || loop_rc) break;
+        if (it >= 200000) { dkmc_fail(4, "CG: no convergence after 200000 iterations", __FILE__, __LINE__); break; }
+        for (int b = 0; b < batch; ++b, ++it) {
+            const bool pb = prof && b < 64 && (b % XT_PROF_STRIDE == 0);
+            loop_rc = matvec(pb ? evs[4 * b] : nullptr, pb ? evs[4 * b + 1] : nullptr, pb ? evs[4 * b + 2] : nullptr, pb ? evs[4 * b + 3] : nullptr,
+                             pb ? evc[b / XT_PROF_STRIDE] : nullptr);
+            if (loop_rc) break;
+            hipLaunchKernelGGL(k_xt_update, dim3(gv), dim3(XT_NT), 0, st, m, it, (const double *)part_pt, np_pt, (const double *)p, (const double *)t, y, r, part_rr, (const XCtrl *)ctrl);
+            hipLaunchKernelGGL(k_xt_direction, dim3(gv), dim3(XT_NT), 0, st, m, it, (const double *)part_rr, gv, (const double *)r, p, (const double *)sc, q,
+                               (const int *)nsrank, qS, ctrl, tol2);
+        }
+        launched = batch;
+        KCHK();
+        if (e.x_iter_hint > 24) batch = 8; else if (batch < 64) batch *= 2;
+    }
+    if (loop_rc) return loop_rc;
+    hipLaunchKernelGGL(k_xt_vec_mul, dim3(nbr), dim3(256), 0, st, m, y, (const double *)sc);
+    KCHK();
+    HIPCHK(hipMemcpyAsync(&X.t_upper, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    e.x_iter_hint = h.iters;
+    if (iters_out) *iters_out = h.iters;
+    if (rr_out) *rr_out = h.rr[h.iters & 1];
+    // ---- statistics ----
+    long long t_upper = (long long)X.t_upper;
+    if (sharded) {              // each rank counted its own tiles
+        double *cntbuf = (double *)scratch(S_XT_CNT, 16);
+        double hv = (double)t_upper;
+        HIPCHK(hipMemcpy(cntbuf, &hv, 8, hipMemcpyHostToDevice));
+        if (int rcx = comm_allreduce_sum_f64(cntbuf, 1)) return rcx;
+        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipMemcpy(&hv, cntbuf, 8, hipMemcpyDeviceToHost));
+        t_upper = (long long)(hv + 0.5);
+    }
+    e.stats.X_nnz = xs_nnz + 2 * t_upper;
+    e.stats.spmv_tiles = ntiles; e.stats.spmv_tile_entries = t_upper;
+    e.stats.xt_subblocks = X.nsub_total; e.stats.xt_local_subblocks = X.sub_n; e.stats.xt_items = nitems; e.stats.xt_kc = X.kc;
+    e.stats.xt_sparse_nnz = xs_nnz; e.stats.xt_ns = ns;
+    e.stats.spmv_segments = 0; e.stats.spmv_segment_entries = 0;
+    e.stats.spmv_long_rows = ns; e.stats.spmv_short_rows = m - ns; e.stats.spmv_long_nnz = 2 * t_upper; e.stats.spmv_short_nnz = xs_nnz;
+    if (prof) {
+        e.stats.spmv_long_ms = prof_long_ms; e.stats.spmv_short_ms = prof_short_ms;
+        e.stats.spmv_long_launches = prof_long_n; e.stats.spmv_short_launches = prof_short_n;
+        e.stats.comm_ms = prof_comm_ms; e.stats.comm_launches = prof_comm_n;
+    }
+    return e.err_code;
+}
+
+// dissipated power from the solved (G0-scaled, shifted) node potentials m
+int xt_power(dkmc_gpubuf *buf, const XParams &P, const int *aflag, const int *atom_site, const double *m, double Vd, double alpha)
+{
+    Engine &e = eng(); hipStream_t st = e.stream; const XTState &X = g_xt;
+    if (!X.valid) return dkmc_fail(13, "xt_power: no assembled X", __FILE__, __LINE__);
+    double *vS = (double *)e.buf[S_CG_PS];
+    double *mS = vS, *pS = vS + 2 * (size_t)X.ns_pad;
+    if (X.ns > 0) {
+        hipLaunchKernelGGL(k_xt_gather_S, dim3((X.ns + 255) / 256), dim3(256), 0, st, X.ns, (const int *)g_xb.srow, m, mS);
+        int rc = xt_tile_sums<1>(mS, pS, Vd > 0 ? 1 : 0); if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_xt_power_rows, dim3((X.Nsub + 31) / 32), dim3(XT_NT), 0, st, X.Nsub, (const xrp_t *)g_xb.rp, (const int *)g_xb.ci, (const double *)g_xb.val,
+                       m, Vd, (const int *)g_xb.nsrank, (const double *)pS, aflag, atom_site, alpha, buf->site_power);
+    KCHK();
+    (void)P;
+    return 0;
+}
+
+const xrp_t *xt_xs_rp() { return g_xb.rp; }
+const int *xt_xs_col() { return g_xb.ci; }
+const double *xt_xs_val() { return g_xb.val; }
+bool xt_valid() { return g_xt.valid; }
+
+// CSR of the whole X (inspection, small systems, one rank): Xs merged with both triangles of the tiles, rows column-sorted
+int xt_export_csr(int *rows_out, long long *nnz_out, int *h_rp, int *h_col, double *h_data)
+{
+    Engine &e = eng(); const XTState &X = g_xt;
+    if (!X.valid) return dkmc_fail(13, "get_last_X: no assembled X", __FILE__, __LINE__);
+    if (comm_attached()) return dkmc_fail(13, "get_last_X: not available on a sharded X", __FILE__, __LINE__);
+    HIPCHK(hipStreamSynchronize(e.stream));
+    const long long nnz = X.xs_nnz + 2 * (long long)X.t_upper;
+    if (rows_out) *rows_out = X.Nsub;
+    if (nnz_out) *nnz_out = nnz;
+    if (!h_rp && !h_col && !h_data) return 0;
+    if (nnz > 2147483647LL || X.nsub_total > (1ll << 18)) return dkmc_fail(12, "get_last_X: X is too large for the int32 CSR copy of this call", __FILE__, __LINE__);
+    std::vector<xrp_t> rp((size_t)X.Nsub + 1); std::vector<int> ci((size_t)X.xs_nnz); std::vector<double> va((size_t)X.xs_nnz);
+    HIPCHK(hipMemcpy(rp.data(), g_xb.rp, rp.size() * sizeof(xrp_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ci.data(), g_xb.ci, ci.size() * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(va.data(), g_xb.val, va.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<XTile> tl((size_t)X.ntiles); std::vector<double> tv((size_t)X.nsub_total * XT_SUB); std::vector<int> srow((size_t)X.ns_pad);
+    if (X.ntiles) HIPCHK(hipMemcpy(tl.data(), g_xb.tiles, tl.size() * sizeof(XTile), hipMemcpyDeviceToHost));
+    if (X.nsub_total) HIPCHK(hipMemcpy(tv.data(), g_xb.tval, tv.size() * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(srow.data(), g_xb.srow, srow.size() * 4, hipMemcpyDeviceToHost));
+    std::vector<std::vector<std::pair<int, double>>> rowsv((size_t)X.Nsub);
+    for (int i = 0; i < X.Nsub; ++i) for (xrp_t p = rp[i]; p < rp[i + 1]; ++p) rowsv[i].push_back({ci[p], va[p]});
+    for (const XTile &t : tl) {
+        int sl = 0;
+        for (int q = 0; q < 8; ++q) {
+            if (!((t.mask >> q) & 1u)) continue;
+            const double *sb = tv.data() + ((size_t)t.soff + sl) * XT_SUB; ++sl;
+            for (int r = 0; r < XT_R; ++r) for (int c = 0; c < XT_SBW; ++c) {
+                const double v = sb[r * XT_SBW + c];
+                if (v == 0.0) continue;
+                const int s = XT_R * t.k + r, sc = XT_C * t.w + XT_SBW * q + c;
+                rowsv[srow[s]].push_back({srow[sc], v}); rowsv[srow[sc]].push_back({srow[s], v});
+            }
+        }
+    }
+    long long pos = 0;
+    for (int i = 0; i < X.Nsub; ++i) {
+        std::sort(rowsv[i].begin(), rowsv[i].end(), [](const std::pair<int, double> &a, const std::pair<int, double> &b) { return a.first < b.first; });
+        if (h_rp) h_rp[i] = (int)pos;
+        for (auto &pr : rowsv[i]) { if (h_col) h_col[pos] = pr.first; if (h_data) h_data[pos] = pr.second; ++pos; }
+    }
+    if (h_rp) h_rp[X.Nsub] = (int)pos;
+    if (pos != nnz) return dkmc_fail(13, "get_last_X: entry count of the tiles does not match the fill count", __FILE__, __LINE__);
+    return 0;
+}

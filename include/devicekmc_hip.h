@@ -77,6 +77,13 @@ typedef struct dkmc_stats {
      * (same launch as the segments) */
     int spmv_tiles, spmv_pad2;
     long long spmv_tile_entries;
+    /* tiled X (dkmc_set_x_format(1), the default): stored 32 x 32 sub-blocks of the tunnelling block (8 KiB each; all ranks /
+     * this rank), work items of the apply kernel and tiles per item, entries of the neighbour part Xs, size of the tunnelling set;
+     * spmv_tiles / spmv_tile_entries then count the 32 x 256 tiles and the entries of the upper triangle they hold */
+    long long xt_subblocks, xt_local_subblocks;
+    int xt_items, xt_kc;
+    long long xt_sparse_nnz;
+    int xt_ns, xt_pad;
 } dkmc_stats;
 
 const char *dkmc_last_error(void);
@@ -103,6 +110,12 @@ void dkmc_set_profiling(int on);
  * arithmetic of the sharded solve (which never uses tiles).  Both agree to rounding (a_ij s_i s_j is formed in a different
  * order for the two triangles). */
 void dkmc_set_symmetric_tiles(int on);
+/* layout of the current-solve matrix X (update_power_gpu_sparse).  1 (default): tiled X -- the neighbour part as a small CSR,
+ * the tunnelling block generated straight into symmetric 32 x 256 tiles (upper triangle only, no column indices, one copy);
+ * per-rank storage and assembly when a communicator is attached.  0: CSR X exactly as the reference stores it
+ * (Assemble_X_sparsity / Assemble_X2), solved by reading every stored entry; both agree to rounding.  dkmc_get_last_X
+ * returns the same column-sorted CSR in both modes. */
+void dkmc_set_x_format(int tiled);
 
 /* ---- GPUBuffers (gpu_buffers.h:73-158, gpu_buffers.cpp:10-118) ---------------------------- */
 /* allocates every array of the struct with hipMalloc and uploads the constant ones */

@@ -35,7 +35,7 @@
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
 struct __attribute__((aligned(16))) XTile { int k, w; unsigned mask; int soff; };   // cell (k, w); present sub-blocks; first sub-block slot
-struct __attribute__((aligned(16))) XItem { int t0, t1, w, c; };                    // tiles [t0, t1) of strip w; c = position of the run in its strip
+struct __attribute__((aligned(32))) XItem { int t0, t1, w, c, k0; unsigned mask0; int soff0, pad; };   // tiles [t0, t1) of strip w; c = position of the run in its strip; descriptor of tile t0
 struct XCtrl { double rr[2]; double pad; int done; int iters; };
 
 struct SNodes {                      // S in rank order, padded to a multiple of XT_C (flag 0 = no entries)
@@ -141,7 +141,7 @@ __global__ void k_xt_items(int nK, int nW, int kc, int ntiles, const int *__rest
     if (w >= nW) return;
     const int t0 = toff[(long long)w * nK], t1 = (w + 1 < nW) ? toff[(long long)(w + 1) * nK] : ntiles;
     int o = ioff[w], c = 0;
-    for (int t = t0; t < t1; t += kc, ++o, ++c) { XItem it; it.t0 = t; it.t1 = min(t + kc, t1); it.w = w; it.c = c; items[o] = it; isub[o] = tiles[t].soff; }
+    for (int t = t0; t < t1; t += kc, ++o, ++c) { const XTile f = tiles[t]; XItem it; it.t0 = t; it.t1 = min(t + kc, t1); it.w = w; it.c = c; it.k0 = f.k; it.mask0 = f.mask; it.soff0 = f.soff; it.pad = 0; items[o] = it; isub[o] = f.soff; }
 }
 
 // ---- fill: values of the stored sub-blocks --------------------------------------------------------------------------------
@@ -200,46 +200,70 @@ __device__ __forceinline__ void xt_acc(const dbl2 v, const double pcx, const dou
     }
 }
 
-template <int OP>
+// One work item.  Lane (rr = lane / 16, cc = lane % 16) owns rows 4 j + rr (j = 0..7) and the column pair 2 cc, 2 cc + 1 of every
+// sub-block.  Per sub-block: 8 loads of 1 KiB per wave (two sub-blocks in flight), row sums accumulate in registers over the
+// tile, the two column sums are combined over rr and added to the wave's 256 column accumulators in LDS (lcol).
+template <int OP, int NTL>
 __device__ __forceinline__ void xt_tile_role(const XItem it, const XTile *__restrict__ tiles, int sub_base, const double *__restrict__ tval,
                                              const double *__restrict__ vS, int nW, int ns_pad, double *__restrict__ rowpart,
-                                             double *__restrict__ colpart, bool vpos)
+                                             double *__restrict__ colpart, bool vpos, double *lcol, double *lq)
 {
     const int lane = threadIdx.x & 63, cc = lane & 15, rr = lane >> 4;
-    const double *vc = vS + (size_t)it.w * XT_C + 2 * cc;
-    double pcx[8], pcy[8], cax[8], cay[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { const dbl2 t = *reinterpret_cast<const dbl2 *>(vc + XT_SBW * q); pcx[q] = t.x; pcy[q] = t.y; cax[q] = 0.0; cay[q] = 0.0; }
+    // the window's 256 vector entries and the 256 column accumulators live in wave-private LDS: their reads are counted by
+    // lgkmcnt, so waiting for them never drains the tile stream (vmcnt)
+    {
+        const dbl2 *src = reinterpret_cast<const dbl2 *>(vS + (size_t)it.w * XT_C) + 2 * lane;
+        const dbl2 q0 = src[0], q1 = src[1];
+        dbl2 z; z.x = 0.0; z.y = 0.0;
+        reinterpret_cast<dbl2 *>(lcol)[2 * lane] = z; reinterpret_cast<dbl2 *>(lcol)[2 * lane + 1] = z;
+        reinterpret_cast<dbl2 *>(lq)[2 * lane] = q0; reinterpret_cast<dbl2 *>(lq)[2 * lane + 1] = q1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    XTile td; td.k = it.k0; td.w = it.w; td.mask = it.mask0; td.soff = it.soff0;
+#define XT_LD(dst, slot) _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) dst[j_] = NTL ? __builtin_nontemporal_load(base + (size_t)(8 * (slot) + j_) * 64) : base[(size_t)(8 * (slot) + j_) * 64];
+#define XT_SUBBLOCK(vv, q)                                                                                                  \
+    {                                                                                                                       \
+        const dbl2 pc = *reinterpret_cast<const dbl2 *>(lq + XT_SBW * (q) + 2 * cc);                                        \
+        double cax = 0.0, cay = 0.0;                                                                                        \
+        _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) xt_acc<OP>(vv[j_], pc.x, pc.y, pr[j_], ra[j_], cax, cay, vpos);    \
+        cax += __shfl_xor(cax, 16, WAVE); cay += __shfl_xor(cay, 16, WAVE);                                                 \
+        cax += __shfl_xor(cax, 32, WAVE); cay += __shfl_xor(cay, 32, WAVE);                                                 \
+        if (rr == 0) { dbl2 *l_ = reinterpret_cast<dbl2 *>(lcol + XT_SBW * (q) + 2 * cc); dbl2 o_ = *l_; o_.x += cax; o_.y += cay; *l_ = o_; } \
+    }
 #pragma unroll 1
     for (int t = it.t0; t < it.t1; ++t) {
-        const XTile td = tiles[t];
+        XTile nxt = td;
+        if (t + 1 < it.t1) nxt = tiles[t + 1];                       // descriptor of the next tile: in flight behind this tile's stream
         const double *vr = vS + (size_t)td.k * XT_R + rr;
         double pr[8], ra[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { pr[j] = vr[4 * j]; ra[j] = 0.0; }
         const dbl2 *base = reinterpret_cast<const dbl2 *>(tval + (size_t)(td.soff - sub_base) * XT_SUB) + lane;
         if (td.mask == 0xffu) {
-            // full tile: 64 KiB contiguous, 16 KiB (two sub-blocks) in flight per wave
-#pragma unroll
-            for (int h = 0; h < 4; ++h) {
-                dbl2 v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = __builtin_nontemporal_load(base + (size_t)(16 * h + u) * 64);
-#pragma unroll
-                for (int u = 0; u < 16; ++u) xt_acc<OP>(v[u], pcx[2 * h + (u >> 3)], pcy[2 * h + (u >> 3)], pr[u & 7], ra[u & 7], cax[2 * h + (u >> 3)], cay[2 * h + (u >> 3)], vpos);
+            // full tile: 64 KiB contiguous, two sub-blocks (16 KiB) in flight per wave
+            dbl2 va[8], vb[8];
+            XT_LD(va, 0)
+#pragma unroll 1
+            for (int h = 0; h < 3; ++h) {                            // a real loop: the register budget stays at two sub-blocks
+                XT_LD(vb, 2 * h + 1)
+                XT_SUBBLOCK(va, 2 * h)
+                XT_LD(va, 2 * h + 2)
+                XT_SUBBLOCK(vb, 2 * h + 1)
             }
+            XT_LD(vb, 7)
+            XT_SUBBLOCK(va, 6)
+            XT_SUBBLOCK(vb, 7)
         } else {
-            int sl = 0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if ((td.mask >> q) & 1u) {                      // wave-uniform
-                    dbl2 v[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = __builtin_nontemporal_load(base + (size_t)(8 * sl + j) * 64);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) xt_acc<OP>(v[j], pcx[q], pcy[q], pr[j], ra[j], cax[q], cay[q], vpos);
-                    ++sl;
-                }
+            unsigned mm = td.mask; int sl = 0;                     // partial tile (a few per cent of the storage): one sub-block at a time
+#pragma unroll 1
+            while (mm) {
+                const int q = __ffs(mm) - 1; mm &= mm - 1;
+                dbl2 va[8];
+                XT_LD(va, sl)
+                XT_SUBBLOCK(va, q)
+                ++sl;
             }
         }
         // 8 row sums per lane -> 32 row sums of the tile: butterfly over the 16 lanes that share rr (bits 3, 2, 1 of the lane
@@ -257,68 +281,74 @@ __device__ __forceinline__ void xt_tile_role(const XItem it, const XTile *__rest
         const double rs = ra[0] + __shfl_xor(ra[0], 1, WAVE);
         const int j = ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
         if (!(lane & 1)) rowpart[((size_t)td.k * nW + td.w) * XT_R + 4 * j + rr] = rs;
+        td = nxt;
     }
-    double *cp = colpart + (size_t)it.c * ns_pad + (size_t)it.w * XT_C + 2 * cc;
+#undef XT_LD
+#undef XT_SUBBLOCK
+    if (rr == 0) {
+        double *cp = colpart + (size_t)it.c * ns_pad + (size_t)it.w * XT_C + 2 * cc;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        double a = cax[q], b = cay[q];
-        a += __shfl_xor(a, 16, WAVE); b += __shfl_xor(b, 16, WAVE);
-        a += __shfl_xor(a, 32, WAVE); b += __shfl_xor(b, 32, WAVE);
-        if (rr == 0) { dbl2 o; o.x = a; o.y = b; *reinterpret_cast<dbl2 *>(cp + XT_SBW * q) = o; }
+        for (int q = 0; q < 8; ++q) *reinterpret_cast<dbl2 *>(cp + XT_SBW * q) = *reinterpret_cast<const dbl2 *>(lcol + XT_SBW * q + 2 * cc);
     }
 }
 
-// Blocks [0, ntb): tile work items (one per wave).  Blocks [ntb, ntb + nsb): the atom rows of Xs, 8 lanes per row.  The last
-// two blocks: the two driver rows (thousands of entries each).  Non-S rows are finished here (scaled, p.t partial); S rows
-// leave their sparse sum in t for the row kernel.
+// Blocks 0, 1: the two driver rows (thousands of entries each: the longest dependent chain of the launch starts first).  Blocks
+// [2, 2 + ntb): tile work items (one per wave).  The rest: the atom rows of Xs, 8 lanes per row, one row per group (no barrier,
+// no partial sums: the p.t dot product is formed by the row kernel).  Non-S rows are finished here (scaled); S rows leave their sparse sum in t for the row kernel.
+// NTL: non-temporal loads of the tile stream once a sweep no longer fits the 256 MiB Infinity Cache (cg.hip: 45 vs 53 us at
+// 240 MB with the default policy, 478 vs 456 us at 1.86 GB).
+template <int NTL>
 __global__ __launch_bounds__(XT_NT) void k_xt_apply(int nitems, const XItem *__restrict__ items, const XTile *__restrict__ tiles, int sub_base,
                                                     const double *__restrict__ tval, const double *__restrict__ qS, int nW, int ns_pad,
                                                     double *__restrict__ rowpart, double *__restrict__ colpart, const XCtrl *ctrl,
                                                     int ntb, int nsb, int Nsub, const xrp_t *__restrict__ rp, const int *__restrict__ ci,
                                                     const double *__restrict__ val, const double *__restrict__ q, const double *__restrict__ sc,
-                                                    const int *__restrict__ nsrank, const double *__restrict__ pvec, double *__restrict__ t,
-                                                    double *__restrict__ part)
+                                                    const int *__restrict__ nsrank, double *__restrict__ t)
 {
     __shared__ double red[XT_NT / 64];
-    __shared__ int sdone;
-    if ((int)blockIdx.x < ntb) {
-        if (ctrl->done) return;
-        const int item = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (XT_NT / 64) + (int)(threadIdx.x >> 6));
-        if (item >= nitems) return;
-        xt_tile_role<0>(items[item], tiles, sub_base, tval, qS, nW, ns_pad, rowpart, colpart, true);
+    __shared__ __attribute__((aligned(16))) double lcol[XT_NT / 64][2 * XT_C];
+    if ((int)blockIdx.x >= 2 && (int)blockIdx.x < 2 + ntb) {
+        const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int item = ((int)blockIdx.x - 2) * (XT_NT / 64) + wv;
+        const XItem it = items[min(item, nitems - 1)];              // in flight together with the stop flag
+        if (ctrl->done || item >= nitems) return;                   // (the flag is set only by the last kernel of an iteration: uniform over the launch)
+        xt_tile_role<0, NTL>(it, tiles, sub_base, tval, qS, nW, ns_pad, rowpart, colpart, true, lcol[wv], lcol[wv] + XT_C);
         return;
     }
-    if (threadIdx.x == 0) sdone = ctrl->done;
-    __syncthreads();
-    if (sdone) return;
-    const int bid = (int)blockIdx.x - ntb;
-    double acc = 0.0;
+    const int bid = (int)blockIdx.x < 2 ? nsb + (int)blockIdx.x : (int)blockIdx.x - 2 - ntb;
     if (bid < nsb) {
+        // 8 lanes per row; the row's entries are fetched in chunks of 32 with every load of a chunk issued before the first use:
+        // three dependent memory latencies per row (row pointers -> values / columns -> q) instead of two per 8 entries
         const int g = threadIdx.x >> 3, l = threadIdx.x & 7;
-        for (int row = 2 + bid * (XT_NT / 8) + g; row < Nsub; row += nsb * (XT_NT / 8)) {
-            const xrp_t p0 = rp[row], p1 = rp[row + 1];
-            double s = 0.0;
-            for (xrp_t p = p0 + l; p < p1; p += 8) s += val[p] * q[ci[p]];
-            s += __shfl_xor(s, 4, 8); s += __shfl_xor(s, 2, 8); s += __shfl_xor(s, 1, 8);
-            if (l == 0) {
-                if (nsrank[row] < 0) { const double tv = sc[row] * s; t[row] = tv; acc += pvec[row] * tv; }
-                else t[row] = s;
-            }
-        }
-    } else {
-        const int row = bid - nsb;                                  // 0 or 1
+        const int row = 2 + bid * (XT_NT / 8) + g;
+        if (row >= Nsub) return;
         const xrp_t p0 = rp[row], p1 = rp[row + 1];
-        double s0 = 0.0, s1 = 0.0;
-        xrp_t p = p0 + threadIdx.x;
-        for (; p + XT_NT < p1; p += 2 * XT_NT) { s0 += val[p] * q[ci[p]]; s1 += val[p + XT_NT] * q[ci[p + XT_NT]]; }
-        if (p < p1) s0 += val[p] * q[ci[p]];
-        const double s = block_sum_all<XT_NT>(s0 + s1, red);
-        const double tv = sc[row] * s;
-        if (threadIdx.x == 0) { t[row] = tv; part[bid] = pvec[row] * tv; }
+        const int sr = nsrank[row];
+        const double scale = sc[row];
+        if (ctrl->done) return;
+        double s = 0.0;
+        for (xrp_t pb = p0 + l; pb < p1; pb += 32) {
+            double v[4]; int c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const xrp_t p = pb + 8 * u; const bool ok = p < p1; v[u] = ok ? val[p] : 0.0; c[u] = ok ? ci[p] : 0; }
+            double x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = q[c[u]];
+            s += (v[0] * x[0] + v[1] * x[1]) + (v[2] * x[2] + v[3] * x[3]);
+        }
+        s += __shfl_xor(s, 4, 8); s += __shfl_xor(s, 2, 8); s += __shfl_xor(s, 1, 8);
+        if (l == 0) t[row] = sr < 0 ? scale * s : s;
         return;
     }
-    const double tot = block_sum_all<XT_NT>(acc, red);
-    if (threadIdx.x == 0) part[bid] = tot;
+    if (ctrl->done) return;
+    const int row = bid - nsb;                                      // 0 or 1
+    const xrp_t p0 = rp[row], p1 = rp[row + 1];
+    double s0 = 0.0, s1 = 0.0;
+    xrp_t p = p0 + threadIdx.x;
+    for (; p + XT_NT < p1; p += 2 * XT_NT) { s0 += val[p] * q[ci[p]]; s1 += val[p + XT_NT] * q[ci[p + XT_NT]]; }
+    if (p < p1) s0 += val[p] * q[ci[p]];
+    const double s = block_sum_all<XT_NT>(s0 + s1, red);
+    if (threadIdx.x == 0) t[row] = sc[row] * s;
 }
 // tiles only (diagonal pass with q = 1, power pass with q = m)
 template <int OP>
@@ -326,69 +356,94 @@ __global__ __launch_bounds__(XT_NT) void k_xt_tiles_only(int nitems, const XItem
                                                          const double *__restrict__ tval, const double *__restrict__ vS, int nW, int ns_pad,
                                                          double *__restrict__ rowpart, double *__restrict__ colpart, int vpos)
 {
-    const int item = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (XT_NT / 64) + (int)(threadIdx.x >> 6));
+    __shared__ __attribute__((aligned(16))) double lcol[XT_NT / 64][2 * XT_C];
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int item = (int)blockIdx.x * (XT_NT / 64) + wv;
     if (item >= nitems) return;
-    xt_tile_role<OP>(items[item], tiles, sub_base, tval, vS, nW, ns_pad, rowpart, colpart, vpos != 0);
+    xt_tile_role<OP, 1>(items[item], tiles, sub_base, tval, vS, nW, ns_pad, rowpart, colpart, vpos != 0, lcol[wv], lcol[wv] + XT_C);
 }
 
 // ---- row kernel: per S-row, row partials (ascending window) + column partials (ascending run) ------------------------------
-// One wave per row block (32 S-rows x 2 halves of the partial lists).  MODE 0: t = s_i (sparse sum + tile sums), p.t partial.
-// MODE 1: xout[s] = tile sums only (this rank's share / the diagonal and power passes).
+// One workgroup per row block: 8 slices x 32 S-rows, slice sl adds every 8th window and every 8th run, the slices are combined
+// in a fixed order through LDS.  MODE 0: t = s_i (sparse sum + tile sums) for the S rows, then the workgroup adds p.t over its
+// share of ALL rows (the non-S rows were finished by the apply kernel) and writes one partial.  MODE 1: xout[s] = tile sums
+// only (this rank's share in the sharded solve; the diagonal and power passes).
+__device__ __forceinline__ double xt_row_block_sum(int k, int nW, int ns_pad, const int2 *__restrict__ wrange, const int *__restrict__ nitem_w,
+                                                   const double *__restrict__ rowpart, const double *__restrict__ colpart, double (*sl_sum)[XT_R])
+{
+    const int r = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int s = XT_R * k + r;
+    const int2 wr = wrange[k];
+    double a0 = 0.0, a1 = 0.0;
+    const double *rpp = rowpart + (size_t)k * nW * XT_R + r;
+    int w = wr.x + sl;
+    for (; w + 8 < wr.y; w += 16) { a0 += rpp[(size_t)w * XT_R]; a1 += rpp[(size_t)(w + 8) * XT_R]; }
+    if (w < wr.y) a0 += rpp[(size_t)w * XT_R];
+    const int nc = nitem_w[k / (XT_C / XT_R)];
+    const double *cpp = colpart + s;
+    int c = sl;
+    for (; c + 8 < nc; c += 16) { a0 += cpp[(size_t)c * ns_pad]; a1 += cpp[(size_t)(c + 8) * ns_pad]; }
+    if (c < nc) a0 += cpp[(size_t)c * ns_pad];
+    __syncthreads();                                                 // previous round's readers are done with sl_sum
+    sl_sum[sl][r] = a0 + a1;
+    __syncthreads();
+    double tot = 0.0;
+    if (sl == 0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tot += sl_sum[u][r];
+    }
+    return tot;                                                      // valid in threads 0..31
+}
 template <int MODE>
 __global__ __launch_bounds__(XT_NT) void k_xt_rows(int ns, int nK, int nW, int ns_pad, const int2 *__restrict__ wrange, const int *__restrict__ nitem_w,
                                                    const double *__restrict__ rowpart, const double *__restrict__ colpart,
                                                    const int *__restrict__ srow, const double *__restrict__ sS, const double *__restrict__ pvec,
-                                                   double *__restrict__ t, double *__restrict__ part, const XCtrl *ctrl, double *__restrict__ xout)
+                                                   double *__restrict__ t, double *__restrict__ part, const XCtrl *ctrl, double *__restrict__ xout,
+                                                   int m, const int *__restrict__ nsrank)
 {
     __shared__ double red[XT_NT / 64];
+    __shared__ double sl_sum[8][XT_R];
     __shared__ int sdone;
     if (ctrl) {
         if (threadIdx.x == 0) sdone = ctrl->done;
         __syncthreads();
         if (sdone) return;
     }
-    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     double acc = 0.0;
-    for (int k = blockIdx.x * (XT_NT / 64) + (threadIdx.x >> 6); k < nK; k += gridDim.x * (XT_NT / 64)) {
-        const int s = XT_R * k + r;
-        const int2 wr = wrange[k];
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        const double *rpp = rowpart + (size_t)k * nW * XT_R + r;
-        int w = wr.x + h;
-        for (; w + 6 < wr.y; w += 8) { a0 += rpp[(size_t)w * XT_R]; a1 += rpp[(size_t)(w + 2) * XT_R]; a2 += rpp[(size_t)(w + 4) * XT_R]; a3 += rpp[(size_t)(w + 6) * XT_R]; }
-        for (; w < wr.y; w += 2) a0 += rpp[(size_t)w * XT_R];
-        const int nc = nitem_w[k / (XT_C / XT_R)];
-        const double *cpp = colpart + s;
-        int c = h;
-        for (; c + 6 < nc; c += 8) { a0 += cpp[(size_t)c * ns_pad]; a1 += cpp[(size_t)(c + 2) * ns_pad]; a2 += cpp[(size_t)(c + 4) * ns_pad]; a3 += cpp[(size_t)(c + 6) * ns_pad]; }
-        for (; c < nc; c += 2) a0 += cpp[(size_t)c * ns_pad];
-        double sum = (a0 + a1) + (a2 + a3);
-        sum += __shfl_xor(sum, 32, WAVE);
-        if (h == 0 && s < ns) {
+    for (int k = blockIdx.x; k < nK; k += gridDim.x) {
+        const double sum = xt_row_block_sum(k, nW, ns_pad, wrange, nitem_w, rowpart, colpart, sl_sum);
+        const int s = XT_R * k + (int)threadIdx.x;
+        if (threadIdx.x < XT_R && s < ns) {
             if (MODE == 1) xout[s] = sum;
             else { const int row = srow[s]; const double tv = sS[s] * (t[row] + sum); t[row] = tv; acc += pvec[row] * tv; }
         }
     }
     if (MODE == 1) return;
+    // p.t over the non-S rows of this workgroup's share of the vector
+    const int chunk = (m + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int i0 = blockIdx.x * chunk, i1 = min(m, i0 + chunk);
+    for (int i = i0 + threadIdx.x; i < i1; i += XT_NT) if (nsrank[i] < 0) acc += pvec[i] * t[i];
     const double tot = block_sum_all<XT_NT>(acc, red);
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
 }
-// sharded solve, after the all-reduce of xout: finish the S rows (same thread-to-row mapping as MODE 0: same partials)
+// sharded solve, after the all-reduce of xout: finish the S rows, then the same p.t partials as MODE 0
 __global__ __launch_bounds__(XT_NT) void k_xt_rows_apply(int ns, int nK, const double *__restrict__ xbuf, const int *__restrict__ srow,
                                                          const double *__restrict__ sS, const double *__restrict__ pvec, double *__restrict__ t,
-                                                         double *__restrict__ part, const XCtrl *ctrl)
+                                                         double *__restrict__ part, const XCtrl *ctrl, int m, const int *__restrict__ nsrank)
 {
     __shared__ double red[XT_NT / 64];
     __shared__ int sdone;
     if (threadIdx.x == 0) sdone = ctrl->done;
     __syncthreads();
     if (sdone) return;
-    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     double acc = 0.0;
-    for (int k = blockIdx.x * (XT_NT / 64) + (threadIdx.x >> 6); k < nK; k += gridDim.x * (XT_NT / 64)) {
-        const int s = XT_R * k + r;
-        if (h == 0 && s < ns) { const int row = srow[s]; const double tv = sS[s] * (t[row] + xbuf[s]); t[row] = tv; acc += pvec[row] * tv; }
+    for (int k = blockIdx.x; k < nK; k += gridDim.x) {
+        const int s = XT_R * k + (int)threadIdx.x;
+        if (threadIdx.x < XT_R && s < ns) { const int row = srow[s]; const double tv = sS[s] * (t[row] + xbuf[s]); t[row] = tv; acc += pvec[row] * tv; }
     }
+    const int chunk = (m + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int i0 = blockIdx.x * chunk, i1 = min(m, i0 + chunk);
+    for (int i = i0 + threadIdx.x; i < i1; i += XT_NT) if (nsrank[i] < 0) acc += pvec[i] * t[i];
     const double tot = block_sum_all<XT_NT>(acc, red);
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
 }
@@ -576,9 +631,10 @@ static int xt_tile_sums(const double *vS, double *out, int vpos)
     if (X.item_n > 0)
         hipLaunchKernelGGL((k_xt_tiles_only<OP>), dim3((X.item_n + 3) / 4), dim3(XT_NT), 0, st, X.item_n, (const XItem *)g_xb.items + X.item_lo,
                            (const XTile *)g_xb.tiles, (int)X.sub_base, (const double *)g_xb.tval, vS, X.nW, X.ns_pad, g_xb.rowpart, g_xb.colpart, vpos);
-    hipLaunchKernelGGL((k_xt_rows<1>), dim3(xt_grid(X.nK, 4, 256)), dim3(XT_NT), 0, st, X.ns, X.nK, X.nW, X.ns_pad, (const int2 *)g_xb.wrange,
+    hipLaunchKernelGGL((k_xt_rows<1>), dim3(xt_grid(X.nK, 1, 1024)), dim3(XT_NT), 0, st, X.ns, X.nK, X.nW, X.ns_pad, (const int2 *)g_xb.wrange,
                        (const int *)g_xb.nitem_w, (const double *)g_xb.rowpart, (const double *)g_xb.colpart, (const int *)nullptr,
-                       (const double *)nullptr, (const double *)nullptr, (double *)nullptr, (double *)nullptr, (const XCtrl *)nullptr, out);
+                       (const double *)nullptr, (const double *)nullptr, (double *)nullptr, (double *)nullptr, (const XCtrl *)nullptr, out,
+                       0, (const int *)nullptr);
     KCHK();
     if (comm_attached()) { int rc = comm_allreduce_sum_f64(out, (size_t)X.ns); if (rc) return rc; }
     return 0;
@@ -741,30 +797,33 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
 
     // ---- launch shapes ----
     const int ntb = (X.item_n + 3) / 4;
-    const int nsb = xt_grid(std::max(m - 2, 1), 128, 512);
-    const int n2b = xt_grid(std::max(nK, 1), 4, 256);
+    const int nsb = (std::max(m - 2, 1) + XT_NT / 8 - 1) / (XT_NT / 8);
+    const int n2b = xt_grid(std::max(std::max(nK, (m + 4095) / 4096), 1), 1, 1024);    // row kernel: S row blocks + its share of the p.t dot
     const int gv = xt_grid(m, XT_NT * 4, 256);
-    const int np_pt = nsb + 2 + (ns > 0 ? n2b : 0);
+    const int np_pt = n2b;
+    const bool nt_loads = (size_t)X.sub_n * XT_SUB * 8 > ((size_t)200 << 20);
     double *xbuf = nullptr;
     if (sharded) { xbuf = (double *)scratch(S_CG_XCHG, (size_t)(ns + 2) * 8); if (!xbuf) return e.err_code; }
 
     auto matvec = [&](hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t ec) -> int {
-        hipExtLaunchKernelGGL(k_xt_apply, dim3(ntb + nsb + 2), dim3(XT_NT), 0, st, e0, e1, 0, X.item_n, (const XItem *)items + X.item_lo, (const XTile *)tiles,
-                              (int)X.sub_base, (const double *)tval, (const double *)qS, nW, ns_pad, rowpart, colpart, (const XCtrl *)ctrl, ntb, nsb, m,
-                              (const xrp_t *)rp, (const int *)col, (const double *)val, (const double *)q, (const double *)sc, (const int *)nsrank,
-                              (const double *)p, t, part_pt);
-        if (ns <= 0) return 0;
-        if (sharded) {
+#define XT_APPLY_ARGS X.item_n, (const XItem *)items + X.item_lo, (const XTile *)tiles, (int)X.sub_base, (const double *)tval, (const double *)qS, nW, ns_pad, \
+                      rowpart, colpart, (const XCtrl *)ctrl, ntb, nsb, m, (const xrp_t *)rp, (const int *)col, (const double *)val, (const double *)q, \
+                      (const double *)sc, (const int *)nsrank, t
+        if (nt_loads) hipExtLaunchKernelGGL((k_xt_apply<1>), dim3(ntb + nsb + 2), dim3(XT_NT), 0, st, e0, e1, 0, XT_APPLY_ARGS);
+        else hipExtLaunchKernelGGL((k_xt_apply<0>), dim3(ntb + nsb + 2), dim3(XT_NT), 0, st, e0, e1, 0, XT_APPLY_ARGS);
+#undef XT_APPLY_ARGS
+        if (sharded && ns > 0) {
             hipLaunchKernelGGL((k_xt_rows<1>), dim3(n2b), dim3(XT_NT), 0, st, ns, nK, nW, ns_pad, (const int2 *)wrange, (const int *)nitem_w, (const double *)rowpart,
-                               (const double *)colpart, (const int *)srow, (const double *)sS, (const double *)p, t, part_pt + nsb + 2, (const XCtrl *)ctrl, xbuf);
+                               (const double *)colpart, (const int *)srow, (const double *)sS, (const double *)p, t, part_pt, (const XCtrl *)ctrl, xbuf,
+                               m, (const int *)nsrank);
             if (int rcx = comm_allreduce_sum_f64(xbuf, (size_t)ns)) return rcx;
             if (ec) HIPCHK(hipEventRecord(ec, st));
             hipExtLaunchKernelGGL(k_xt_rows_apply, dim3(n2b), dim3(XT_NT), 0, st, e2, e3, 0, ns, nK, (const double *)xbuf, (const int *)srow, (const double *)sS,
-                                  (const double *)p, t, part_pt + nsb + 2, (const XCtrl *)ctrl);
+                                  (const double *)p, t, part_pt, (const XCtrl *)ctrl, m, (const int *)nsrank);
         } else
             hipExtLaunchKernelGGL((k_xt_rows<0>), dim3(n2b), dim3(XT_NT), 0, st, e2, e3, 0, ns, nK, nW, ns_pad, (const int2 *)wrange, (const int *)nitem_w,
                                   (const double *)rowpart, (const double *)colpart, (const int *)srow, (const double *)sS, (const double *)p, t,
-                                  part_pt + nsb + 2, (const XCtrl *)ctrl, (double *)nullptr);
+                                  part_pt, (const XCtrl *)ctrl, (double *)nullptr, m, (const int *)nsrank);
         return 0;
     };
 
@@ -795,7 +854,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
                 if (it - launched + b >= h.iters) break;
                 float ms = 0.f;
                 HIPCHK(hipEventElapsedTime(&ms, evs[4 * b], evs[4 * b + 1])); prof_long_ms += ms; ++prof_long_n;
-                if (ns > 0) { HIPCHK(hipEventElapsedTime(&ms, evs[4 * b + 2], evs[4 * b + 3])); prof_short_ms += ms; ++prof_short_n; }
+                HIPCHK(hipEventElapsedTime(&ms, evs[4 * b + 2], evs[4 * b + 3])); prof_short_ms += ms; ++prof_short_n;
                 if (sharded && ns > 0) { HIPCHK(hipEventElapsedTime(&ms, evs[4 * b + 1], evc[b / XT_PROF_STRIDE])); prof_comm_ms += ms; ++prof_comm_n; }
             }
         }

@@ -13,13 +13,13 @@
 //     of X (tunnelling rows, thousands of entries) are not multiplied in CSR form at all inside the iteration loop: their
 //     entries are viewed as index-free dense runs cut into <= 2048-entry segments, one wave64 per segment, 8 B per entry
 //     (k_build_runs / k_spmv_segs below); a tiny second kernel adds a row's segment partials in a fixed order;
-//   * X is symmetric and its tunnelling part is dense by classes: 32 x 256 blocks of it ("symmetric tiles", k_tile_count ff.)
-//     are copied into tile-major storage once per solve and read ONCE per iteration for both triangles;
+//   * (the default solve of X does not come through here at all: xt.hip generates the tunnelling block straight into symmetric
+//     tiles; this file solves K, the local-heat systems and X in its CSR form, dkmc_set_x_format(0));
 //   * row pointers are a template parameter (int for K, 64-bit for X whose non-zeros outgrow 2^31 at ~4e5 sites);
 //   * with a communicator attached (comm.hip) the matrix stream is dealt to the ranks and one collective per iteration
 //     completes the long rows' sums.
 // HBM traffic per iteration in the CSR formulation: 12*nnz + 4*(m+1) + 96*m bytes; with the segments the
-// matrix part of X drops to 8 B per entry, with the tiles to about 4 B per entry.
+// matrix part of X drops to 8 B per entry.
 #include "common.h"
 #include <hip/hip_ext.h>
 #include <vector>
@@ -45,17 +45,7 @@ enum { M_SCALE = 0, M_INIT = 1, M_AP = 2, M_DIAG = 3 };
 #define REM_SEG_LEN 256
 #define SEG_LEN 2048           // entries per segment = work item of one wave in k_spmv_segs
 struct __attribute__((aligned(16))) RunDesc { long long pos; int len, sr0; };   // sr0 < 0: gather segment of long row -1-sr0
-// per long row, everything stage 2 needs in one 16-byte load (tile mode)
-struct __attribute__((aligned(16))) LRowMeta { int sr, nseg, segoff, row, wbeg, wend, kend, pad; };   // [wbeg, wend): windows of the row block's tiles; kend: 1 + last row block with a tile in the row's window
-// symmetric tiles of the tunnelling block (see k_tile_count)
-#define SEGK_NT 256            // workgroup of k_spmv_segs / k_spmv_tiles: 4 waves, one work item each
-#define TILE_SEG_LEN 256       // tile mode: what the tiles leave behind is cut into pieces of at most this many entries (16 lanes each)
-#define TILE_R 32
-#define TILE_C 256
-struct TileDesc { int k, w; };     // S-rows [32k, 32k+32) x S-cols [256w, 256w+256); values in tile-major storage, zero where X has no entry
-#define TILE_MIN_FILL 0.1      // a grid cell becomes a tile when at least this fraction of its slots holds an entry.  In bytes the break-even is 0.5, but
-                               // what a rejected cell leaves behind are short latency-bound pieces: measured at 235 k sites 333 us per launch at 0.6,
-                               // 256 us at 0.3, 241 us at 0.1 (runs only: 444 us)
+#define SEGK_NT 256            // workgroup of k_spmv_segs: 4 waves, one segment each
 
 // block-uniform read of the stop flag (only the last kernel of an iteration ever sets it)
 __device__ __forceinline__ bool cg_done(const CgCtrl *ctrl)
@@ -263,95 +253,6 @@ __global__ __launch_bounds__(SPMV_NT) void k_rowsum_apply(int n_long, const int 
     if (threadIdx.x == 0) part[blockIdx.x] = tot;
 }
 
-// Large tunnelling sets: a row's window can hold hundreds of tiles, and their column partials lie 2 KiB apart.  This pre-pass adds
-// them with coalesced reads -- one workgroup per (window, slice of the row blocks), one thread per column -- into COLSUM_SLICES
-// partial column sums per S-rank, which stage 2 then adds in slice order.
-#define COLSUM_SLICES 8
-__global__ __launch_bounds__(TILE_C) void k_tile_colsum(int ns, int nK, int nW, const int *__restrict__ kend, const double *__restrict__ colpart,
-                                                        double *__restrict__ csum, int csum_pitch, const CgCtrl *ctrl)
-{
-    if (ctrl->done) return;
-    const int w = blockIdx.x / COLSUM_SLICES, sl = blockIdx.x % COLSUM_SLICES, c = threadIdx.x;
-    const int chunk = (nK + COLSUM_SLICES - 1) / COLSUM_SLICES;
-    const int k0 = sl * chunk, k1 = min(min(k0 + chunk, nK), kend[w]);
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    const double *cp = colpart + (size_t)w * TILE_C + c;
-    const size_t stride = (size_t)nW * TILE_C;
-    int k = k0;
-    for (; k + 3 < k1; k += 4) { s0 += cp[k * stride]; s1 += cp[(k + 1) * stride]; s2 += cp[(k + 2) * stride]; s3 += cp[(k + 3) * stride]; }
-    for (; k < k1; ++k) s0 += cp[k * stride];
-    if (w * TILE_C + c < ns) csum[(size_t)sl * csum_pitch + w * TILE_C + c] = (s0 + s1) + (s2 + s3);
-}
-
-// stage 2 in symmetric-tile mode: t[row] = the row's segment partials + the row partials of the tiles of its row block
-// (ascending window) + the column partials of the tiles of its window (ascending row block), lane-strided over 16 lanes and
-// combined in a fixed order; launch shape of the fused stage 2.  The partial arrays are indexed by the tile GRID position
-// (k * nW + w; cells without a tile stay zero from the memset at the start of the solve), so that after the row's 32-byte
-// descriptor every load address is known: two dependent loads per row instead of three.
-__global__ __launch_bounds__(SPMV_NT) void k_rowsum_tiles(int n_long, const LRowMeta *__restrict__ meta, const double *__restrict__ seg_part,
-                                                          int nW, const double *__restrict__ rowpart, const double *__restrict__ colpart,
-                                                          const double *__restrict__ csum, int csum_pitch,
-                                                          const double *__restrict__ p, double *__restrict__ t, double *__restrict__ part,
-                                                          const CgCtrl *ctrl, double *__restrict__ xout)
-{
-    // xout != nullptr (sharded solve): only this rank's share of every long row's sum is formed and stored to xout[ridx]; the
-    // all-reduce and k_xbuf_apply finish the row
-    __shared__ double red[SPMV_NT / 64];
-    __shared__ int sdone;
-    if (threadIdx.x == 0) sdone = ctrl->done;
-    __syncthreads();
-    if (sdone) return;
-    double acc = 0.0;
-    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
-    for (int ridx = blockIdx.x * (SPMV_NT / 16) + g; ridx < n_long; ridx += gridDim.x * (SPMV_NT / 16)) {
-        const LRowMeta mt = meta[ridx];
-        double s = 0.0;
-        const double *sp = seg_part + mt.segoff;
-        for (int j = l; j < mt.nseg; j += 16) s += sp[j];
-        if (mt.sr >= 0) {
-            const int k = mt.sr / TILE_R, w2 = mt.sr / TILE_C;
-            const double *rpp = rowpart + ((size_t)k * nW) * TILE_R + (mt.sr % TILE_R);
-            for (int base = mt.wbeg + l; base < mt.wend; base += 64) {
-                double v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const int w = base + 16 * u; v[u] = w < mt.wend ? rpp[(size_t)w * TILE_R] : 0.0; }
-                s += (v[0] + v[1]) + (v[2] + v[3]);
-            }
-            const double *cpp = colpart + (size_t)w2 * TILE_C + (mt.sr % TILE_C);
-            if (csum) { if (l < COLSUM_SLICES && mt.kend > 0) s += csum[(size_t)l * csum_pitch + mt.sr]; }      // pre-summed slices (k_tile_colsum)
-            else for (int base = l; base < mt.kend; base += 64) {
-                double v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const int k2 = base + 16 * u; v[u] = k2 < mt.kend ? cpp[((size_t)k2 * nW) * TILE_C] : 0.0; }
-                s += (v[0] + v[1]) + (v[2] + v[3]);
-            }
-        }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
-        if (l == 0) { if (xout) xout[ridx] = s; else { t[mt.row] = s; acc += p[mt.row] * s; } }
-    }
-    if (xout) return;
-    const double tot = block_sum_all<SPMV_NT>(acc, red);
-    if (threadIdx.x == 0) part[blockIdx.x] = tot;
-}
-// sharded tile solve, after the all-reduce: t and the p.t partials from the completed row sums (launch shape of stage 2)
-__global__ __launch_bounds__(SPMV_NT) void k_xbuf_apply(int n_long, const LRowMeta *__restrict__ meta, const double *__restrict__ xbuf,
-                                                        const double *__restrict__ p, double *__restrict__ t, double *__restrict__ part, const CgCtrl *ctrl)
-{
-    __shared__ double red[SPMV_NT / 64];
-    __shared__ int sdone;
-    if (threadIdx.x == 0) sdone = ctrl->done;
-    __syncthreads();
-    if (sdone) return;
-    double acc = 0.0;
-    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;         // thread-to-row mapping of k_rowsum_tiles: same p.t partials
-    for (int ridx = blockIdx.x * (SPMV_NT / 16) + g; ridx < n_long; ridx += gridDim.x * (SPMV_NT / 16)) {
-        if (l == 0) { const int row = meta[ridx].row; const double s = xbuf[ridx]; t[row] = s; acc += p[row] * s; }
-    }
-    const double tot = block_sum_all<SPMV_NT>(acc, red);
-    if (threadIdx.x == 0) part[blockIdx.x] = tot;
-}
-
 // after M_INIT: rr0 and the first stop test on the 2-norm (cublasDnrm2, :418)
 __global__ __launch_bounds__(CG_NT) void k_cg_check0(const double *part, int npart, CgCtrl *ctrl, double tol2)
 {
@@ -422,14 +323,12 @@ template <typename RP>
 __global__ __launch_bounds__(256) void k_build_runs(int n_long, const int *__restrict__ long_rows, const RP *__restrict__ rp,
                                                     const int *__restrict__ ci, const int *__restrict__ srank,
                                                     RunDesc *__restrict__ runs, int *__restrict__ nruns,
-                                                    int *__restrict__ rem, int *__restrict__ nrem, int seg_len, int diag_break)
+                                                    int *__restrict__ rem, int *__restrict__ nrem, int seg_len)
 {
     const int lane = threadIdx.x & 63;
     const int ridx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (ridx >= n_long) return;
     const int row = long_rows[ridx];
-    // symmetric-tile mode: a run never crosses the row's own S-rank, so that every run is wholly in one triangle
-    const int self_sr = diag_break ? srank[row] : -1;
     const RP p0 = rp[row], p1 = rp[row + 1];
     const long long run_base = (long long)(p0 / RUN_MIN_LEN) + ridx;
     int nr = 0, nrm = 0;
@@ -453,7 +352,7 @@ __global__ __launch_bounds__(256) void k_build_runs(int n_long, const int *__res
         const int sr = valid ? srank[ci[q]] : -1;
         int prev = __shfl_up(sr, 1, WAVE);
         if (lane == 0) prev = carry;
-        const bool brk = valid && (q == p0 || sr < 0 || prev < 0 || sr != prev + 1 || (self_sr >= 0 && (sr == self_sr || prev == self_sr)));
+        const bool brk = valid && (q == p0 || sr < 0 || prev < 0 || sr != prev + 1);
         unsigned long long mask = __ballot(brk);
         while (mask) {
             const int b = __ffsll((long long)mask) - 1;
@@ -494,379 +393,28 @@ __global__ __launch_bounds__(256) void k_compact_segs(int n_long, const int *__r
     for (int j = lane; j < nruns[ridx]; j += WAVE) dst[j] = src[j];
 }
 
-// ---- symmetric tiles of the tunnelling block --------------------------------------------------------------------------------
-// X is symmetric and its tunnelling block is dense by classes (contact x contact, vacancy x contact: nearly every pair present), so
-// nearly every long-run entry a_ij has its mirror a_ji stored in row j.  The S x S part is covered by a grid of TILE_R (32) S-rows x
-// TILE_C (256) S-columns; a cell strictly above the diagonal becomes a *tile* when it is at least TILE_MIN_FILL full and its
-// mirror cell holds exactly as many entries.  The values of a tile are copied (after the Jacobi scaling) into tile-major storage,
-// 32 strips of 256 doubles, zero where X has no entry: one wave reads the 64 KiB once per iteration and forms both the row
-// products (t_i += a_ij p_j) and the column products (t_j += a_ij p_i).  All entries of X inside a tile's cell, and all mirror
-// entries inside its mirror cell, are cut out of their rows' segment lists and are never read in the loop.  Everything else
-// (cells near the diagonal, sparse cells, rows 0/1, columns outside S) stays in the segment path, both triangles.
-// Partial sums: 32 row sums and 256 column sums per tile (3.5 % of the bytes read), combined in stage 2.
-template <typename RP>
-__device__ __forceinline__ const RunDesc *row_runs(int ridx, const int *long_rows, const RP *rp, const RunDesc *runs)
-{
-    return runs + ((long long)(rp[long_rows[ridx]] / RUN_MIN_LEN) + ridx);
-}
-__device__ __forceinline__ bool cell_eligible(int k, int w) { return w * TILE_C >= k * TILE_R + TILE_R; }      // strictly above the diagonal
-
-// entries per grid cell (choice heuristic): cntU[k * nW + w] = entries of the upper long runs of the rows of block k inside window w.
-// One thread per long row; integer atomics (order-independent).
-template <typename RP>
-__global__ __launch_bounds__(256) void k_tile_count(int n_long, const int *__restrict__ long_rows, const RP *__restrict__ rp, const int *__restrict__ srank,
-                                                    const RunDesc *__restrict__ runs, const int *__restrict__ nruns, int nW, int *__restrict__ cntU)
-{
-    const int ridx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ridx >= n_long) return;
-    const int s = srank[long_rows[ridx]];
-    if (s < 0) return;
-    const RunDesc *rr = row_runs(ridx, long_rows, rp, runs);
-    const int n = nruns[ridx], k = s / TILE_R;
-    for (int q = 0; q < n; ++q) {
-        const RunDesc d = rr[q];
-        if (d.sr0 < 0 || d.sr0 <= s) continue;
-        const int lo = d.sr0, hi = d.sr0 + d.len;
-        for (int w = lo / TILE_C; w * TILE_C < hi; ++w)
-            if (cell_eligible(k, w)) atomicAdd(&cntU[(long long)k * nW + w], min(hi, w * TILE_C + TILE_C) - max(lo, w * TILE_C));
-    }
-}
-
-// choose[cell] = 1 when the cell becomes a tile; covered[cell] = entries of X it takes out of the segment path (both triangles)
-__global__ void k_tile_choose(int ns, int nK, int nW, double min_fill, const int *__restrict__ cntU, int *__restrict__ choose, int *__restrict__ covered)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)nK * nW) return;
-    const int k = (int)(i / nW), w = (int)(i % nW);
-    const bool ok = cell_eligible(k, w) && (double)cntU[i] >= min_fill * TILE_R * TILE_C;
-    choose[i] = ok ? 1 : 0;
-    covered[i] = ok ? 2 * cntU[i] : 0;
-}
-// Is the S x S entry (row rank s, column rank sc) inside a tile?  Returns the cell index or -1; upper = entry above the diagonal.
-__device__ __forceinline__ long long tiled_cell(int s, int sc, int nW, const int *__restrict__ choose, bool &upper)
-{
-    if (s < 0 || sc < 0 || s == sc) return -1;
-    upper = sc > s;
-    const int k = (upper ? s : sc) / TILE_R, w = (upper ? sc : s) / TILE_C;
-    if (!cell_eligible(k, w)) return -1;
-    const long long cell = (long long)k * nW + w;
-    return choose[cell] ? cell : -1;
-}
-__global__ void k_tile_list(int nK, int nW, const int *__restrict__ choose, const int *__restrict__ toff, TileDesc *__restrict__ tiles)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < (long long)nK * nW && choose[i]) { TileDesc d; d.k = (int)(i / nW); d.w = (int)(i % nW); tiles[toff[i]] = d; }
-}
-
-// copy the (scaled) values of the upper entries inside tiles into the tile-major storage; one wave per long row
-template <typename RP>
-__global__ __launch_bounds__(256) void k_tile_scatter(int n_long, const int *__restrict__ long_rows, const RP *__restrict__ rp, const int *__restrict__ srank,
-                                                      const RunDesc *__restrict__ runs, const int *__restrict__ nruns, int nW,
-                                                      const int *__restrict__ choose, const int *__restrict__ toff, const double *__restrict__ a,
-                                                      double *__restrict__ tval, int *__restrict__ chk)
-{
-    const int lane = threadIdx.x & 63;
-    const int ridx = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ridx >= n_long) return;
-    const int s = srank[long_rows[ridx]];
-    if (s < 0) return;
-    const RunDesc *rr = row_runs(ridx, long_rows, rp, runs);
-    const int n = nruns[ridx], k = s / TILE_R;
-    for (int q = 0; q < n; ++q) {
-        const RunDesc d = rr[q];
-        if (d.sr0 < 0 || d.sr0 <= s) continue;                       // upper runs only
-        const int lo = d.sr0, hi = d.sr0 + d.len;
-        for (int w = lo / TILE_C; w * TILE_C < hi; ++w) {
-            const long long cell = (long long)k * nW + w;
-            if (!choose[cell]) continue;
-            const int c0 = max(lo, w * TILE_C), c1 = min(hi, w * TILE_C + TILE_C);
-            double *dst = tval + ((size_t)toff[cell] * TILE_R + (s % TILE_R)) * TILE_C;       // the strip of this row in the tile
-            const double *src = a + d.pos;                                                     // a[pos + (c - lo)] is column rank c
-            for (int c = c0 + lane; c < c1; c += 64) dst[c - w * TILE_C] = src[c - lo];
-            if (lane == 0) atomicAdd(&chk[cell], c1 - c0);              // upper entries put into the tile (balanced by the mirror entries removed)
-        }
-    }
-}
-
-// lsr: long-row index -> S-rank (or -1)
-__global__ void k_lsr(int n_long, const int *__restrict__ long_rows, const int *__restrict__ srank, int *__restrict__ lsr)
-{
-    const int ridx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ridx < n_long) lsr[ridx] = srank[long_rows[ridx]];
-}
-// per row block: range of windows that hold a tile; per window: 1 + the last row block that holds a tile (0 = none)
-__global__ void k_tile_ranges(int nK, int nW, const int *__restrict__ dense, int *__restrict__ wbeg, int *__restrict__ wend, int *__restrict__ kend)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nK) {
-        int b = nW, e = 0;
-        for (int w = 0; w < nW; ++w) if (dense[(long long)i * nW + w]) { b = min(b, w); e = w + 1; }
-        wbeg[i] = b; wend[i] = e;
-    }
-    if (i < nW) {
-        int e = 0;
-        for (int k = 0; k < nK; ++k) if (dense[(long long)k * nW + i]) e = k + 1;
-        kend[i] = e;
-    }
-}
-__global__ void k_lrow_meta(int n_long, const int *__restrict__ long_rows, const int *__restrict__ lsr, const int *__restrict__ nsegs,
-                            const int *__restrict__ seg_off, const int *__restrict__ wbeg, const int *__restrict__ wend, const int *__restrict__ kend,
-                            int own_lo, int own_hi, LRowMeta *__restrict__ meta)
-{
-    const int ridx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ridx >= n_long) return;
-    // sharded solve: the segments of rows outside [own_lo, own_hi) belong to other ranks (their partials here are stale)
-    LRowMeta m; m.sr = lsr[ridx]; m.nseg = (ridx >= own_lo && ridx < own_hi) ? nsegs[ridx] : 0; m.segoff = seg_off[ridx]; m.row = long_rows[ridx]; m.wbeg = 0; m.wend = 0; m.kend = 0; m.pad = 0;
-    if (m.sr >= 0) { m.wbeg = wbeg[m.sr / TILE_R]; m.wend = wend[m.sr / TILE_R]; m.kend = kend[m.sr / TILE_C]; }
-    meta[ridx] = m;
-}
-
-// Segment list of one long row = its raw runs minus everything the tiles cover, cut into <= seg_len pieces, followed by its
-// gather segments.  One thread per row; FILL = 0 counts, FILL = 1 writes at seg_off[ridx].
-template <int FILL, typename RP>
-__global__ __launch_bounds__(256) void k_emit_segs(int n_long, const int *__restrict__ long_rows, const RP *__restrict__ rp, const int *__restrict__ srank,
-                                                   const RunDesc *__restrict__ runs, const int *__restrict__ nruns, int ns, int nW,
-                                                   const int *__restrict__ dense, int seg_len, int *__restrict__ nsegs, const int *__restrict__ seg_off,
-                                                   RunDesc *__restrict__ segs, const int *__restrict__ goff, int *__restrict__ chk)
-{
-    const int ridx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ridx >= n_long) return;
-    const int s = srank[long_rows[ridx]];
-    const RunDesc *rr = row_runs(ridx, long_rows, rp, runs);
-    const int n = nruns[ridx];
-    int cnt = 0;
-    RunDesc *out = FILL ? segs + seg_off[ridx] : nullptr;
-    auto emit = [&](long long pos, int sr0, int len) {              // one untiled stretch, cut into segments
-        for (int c = 0; c < len; c += seg_len) {
-            if (FILL) { RunDesc d; d.pos = pos + c; d.len = min(seg_len, len - c); d.sr0 = sr0 + c; out[cnt] = d; }
-            ++cnt;
-        }
-    };
-    for (int q = 0; q < n; ++q) {
-        const RunDesc d = rr[q];
-        if (d.sr0 < 0) {                                                          // gather segment
-            if (goff == nullptr) { if (FILL) out[cnt] = d; ++cnt; continue; }    // (legacy layout: unchanged)
-            // packed layout: position in the compact (value, column) arrays of the remainder entries, 64 entries per wave
-            const long long base = (long long)goff[ridx] + (d.pos - (long long)rp[long_rows[ridx]]);
-            for (int c = 0; c < d.len; c += 64) {
-                if (FILL) { RunDesc g; g.pos = base + c; g.len = min(64, d.len - c); g.sr0 = d.sr0; out[cnt] = g; }
-                ++cnt;
-            }
-            continue;
-        }
-        const int lo = d.sr0, hi = d.sr0 + d.len;
-        if (s < 0 || dense == nullptr) { emit(d.pos, lo, d.len); continue; }
-        int start = lo;                                                         // start of the current untiled stretch
-        if (lo > s) {
-            // upper run: the part inside window w is skipped when cell (s/TILE_R, w) is a tile
-            const int k = s / TILE_R;
-            for (int w = lo / TILE_C; w * TILE_C < hi; ++w) {
-                if (!cell_eligible(k, w) || !dense[(long long)k * nW + w]) continue;
-                const int c0 = max(lo, w * TILE_C), c1 = min(hi, w * TILE_C + TILE_C);
-                if (c0 > start) emit(d.pos + (start - lo), start, c0 - start);
-                start = c1;
-            }
-        } else {
-            // lower run: the part inside the TILE_R columns of row block k' is skipped when cell (k', s/TILE_C) is a tile (this row is
-            // one of its columns)
-            const int w = s / TILE_C;
-            for (int k = lo / TILE_R; k * TILE_R < hi; ++k) {
-                if (!cell_eligible(k, w) || !dense[(long long)k * nW + w]) continue;
-                const int c0 = max(lo, k * TILE_R), c1 = min(hi, k * TILE_R + TILE_R);
-                if (c0 > start) emit(d.pos + (start - lo), start, c0 - start);
-                start = c1;
-                if (FILL) atomicSub(&chk[(long long)k * nW + w], c1 - c0);      // mirror entries removed
-            }
-        }
-        if (hi > start) emit(d.pos + (start - lo), start, hi - start);
-    }
-    if (!FILL) nsegs[ridx] = cnt;
-}
-
-// Packed copies for the latency-bound roles of the tile-mode launch (fewer dependent loads per wave: descriptor -> packed
-// (value, column) -> p): the remainder entries of the long rows and the short rows, copied after the Jacobi scaling.
-// An entry of S x S that lies in a tile is represented by the tile alone, wherever X stores it: long runs are cut in k_emit_segs;
-// here the remainder entries and the short rows drop theirs (value 0, column 0 in the packed copy) and, for the upper ones, put
-// the value into the tile.  chk counts upper entries placed minus mirror entries removed per cell: all zero iff X is
-// structurally symmetric where it is tiled (checked on the host once per solve).
-__device__ __forceinline__ bool tile_take(int s, int sc, double v, int nW, const int *__restrict__ choose, const int *__restrict__ toff,
-                                          double *__restrict__ tval, int *__restrict__ chk)
-{
-    bool upper;
-    const long long cell = tiled_cell(s, sc, nW, choose, upper);
-    if (cell < 0) return false;
-    if (upper) { tval[((size_t)toff[cell] * TILE_R + (s % TILE_R)) * TILE_C + (sc % TILE_C)] = v; atomicAdd(&chk[cell], 1); }
-    else atomicSub(&chk[cell], 1);
-    return true;
-}
-template <typename RP>
-__global__ __launch_bounds__(256) void k_pack_rem(int n_long, const int *__restrict__ long_rows, const RP *__restrict__ rp, const int *__restrict__ ci,
-                                                  const double *__restrict__ a, const int *__restrict__ rem, const int *__restrict__ nrem,
-                                                  const int *__restrict__ goff, double *__restrict__ gval, int *__restrict__ gcol,
-                                                  const int *__restrict__ srank, int nW, const int *__restrict__ choose, const int *__restrict__ toff,
-                                                  double *__restrict__ tval, int *__restrict__ chk)
-{
-    const int lane = threadIdx.x & 63;
-    const int ridx = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (ridx >= n_long) return;
-    const int row = long_rows[ridx];
-    const RP p0 = rp[row];
-    const int n = nrem[ridx], o = goff[ridx], s = srank[row];
-    for (int k = lane; k < n; k += 64) {
-        const RP q = p0 + rem[p0 + k];
-        double v = a[q]; int c = ci[q];
-        if (tile_take(s, srank[c], v, nW, choose, toff, tval, chk)) { v = 0.0; c = 0; }
-        gval[o + k] = v; gcol[o + k] = c;
-    }
-}
-template <typename RP>
-__global__ void k_short_len(int n_short, const int *__restrict__ short_rows, const RP *__restrict__ rp, int *__restrict__ len)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_short) { const int row = short_rows[i]; len[i] = (int)(rp[row + 1] - rp[row]); }
-}
-template <typename RP>
-__global__ __launch_bounds__(256) void k_pack_short(int n_short, const int *__restrict__ short_rows, const RP *__restrict__ rp, const int *__restrict__ ci,
-                                                    const double *__restrict__ a, const int *__restrict__ srp, double *__restrict__ sval, int *__restrict__ scol,
-                                                    const int *__restrict__ srank, int nW, const int *__restrict__ choose, const int *__restrict__ toff,
-                                                    double *__restrict__ tval, int *__restrict__ chk)
-{
-    const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
-    const int ridx = blockIdx.x * 16 + g;
-    if (ridx >= n_short) return;
-    const int row = short_rows[ridx];
-    const RP p0 = rp[row]; const int n = (int)(rp[row + 1] - p0), o = srp[ridx], s = srank[row];
-    for (int k = l; k < n; k += 16) {
-        double v = a[p0 + k]; int c = ci[p0 + k];
-        if (s >= 0 && tile_take(s, srank[c], v, nW, choose, toff, tval, chk)) { v = 0.0; c = 0; }
-        sval[o + k] = v; scol[o + k] = c;
-    }
-}
-__global__ void k_chk_max(long long n, const int *__restrict__ chk, int *__restrict__ out)
-{
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && chk[i] != 0) atomicMax(out, abs(chk[i]));
-}
-
 // stage 1 of the long-row product: one wave64 per segment, seg_part[seg] = sum a[pos+k] * pS[sr0+k].
 // Streams 8 B per entry, 4 independent 1-KiB strips in flight per wave; every wave has the same amount of work.
 // Default cache policy on the matrix stream (NTL = 0): the same 240 MB are re-read every CG iteration and partly stay in
-// the 256 MiB Infinity Cache -- measured 45 us per launch against 53 us with non-temporal loads (NTL = 1, DKMC_SPMV_VAR=3).
-template <int NTL, typename RP, int TILES>
+// the 256 MiB Infinity Cache -- measured 45 us per launch against 53 us with non-temporal loads (NTL = 1).
+// Blocks [0, nsb): segments; the rest: the short rows, 16 lanes per row, p.t partial per block.
+template <int NTL, typename RP>
 __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *__restrict__ segs, const double *__restrict__ a,
                                                        const double *__restrict__ pS, double *__restrict__ seg_part, const CgCtrl *ctrl,
                                                        const int *__restrict__ rem, const int *__restrict__ ci, const double *__restrict__ p,
                                                        int nsb, int n_short, const int *__restrict__ short_rows, const RP *__restrict__ rp,
-                                                       const int *__restrict__ long_rows,
-                                                       double *__restrict__ t, double *__restrict__ part,
-                                                       int ntb, int ntiles, int nW_t, int ns_t, const TileDesc *__restrict__ tiles, const double *__restrict__ tval,
-                                                       double *__restrict__ rowpart, double *__restrict__ colpart,
-                                                       const double *__restrict__ gval, const int *__restrict__ gcol,
-                                                       const int *__restrict__ srp, const double *__restrict__ sval, const int *__restrict__ scol)
+                                                       const int *__restrict__ long_rows, double *__restrict__ t, double *__restrict__ part)
 {
     __shared__ double red[SEGK_NT / 64];
     __shared__ int sdone;
     typedef double dbl2 __attribute__((ext_vector_type(2)));
 #define LDM(ptr) (NTL ? __builtin_nontemporal_load(ptr) : *(ptr))
-    if (TILES && (int)blockIdx.x < ntb) {
-        // symmetric tiles (FIRST ntb blocks, so that the bandwidth-bound part of the launch starts at once and the latency-bound
-        // segment / short-row blocks fill in behind it; one wave per tile; see k_tile_count): 32 strips of 256 values, contiguous
-        // in the tile-major storage, read once, give the row products and the column products (four columns per lane,
-        // accumulated in registers over the strips).  Only instantiated (TILES = 1) in tile mode: the extra registers cost the
-        // segment waves occupancy, which does not matter once the tiles carry most of the matrix.
-        if (ctrl->done) return;
-        const int lane = threadIdx.x & 63;
-        // the tile index is wave-uniform: say so (scalar loads for the descriptor and the strip addresses)
-        const int tile = __builtin_amdgcn_readfirstlane((int)blockIdx.x * (SEGK_NT / 64) + (int)(threadIdx.x >> 6));
-        if (tile >= ntiles) return;
-        const TileDesc td = tiles[tile];
-        const size_t cell = (size_t)td.k * nW_t + td.w;                    // position in the tile grid: where the partial sums go
-        const double *pc = pS + (size_t)td.w * TILE_C, *pr = pS + (size_t)td.k * TILE_R;
-        const int ncols = min(TILE_C, ns_t - td.w * TILE_C);               // the last window may be narrower (its slots beyond are zero)
-        const double *tv = tval + (size_t)tile * TILE_R * TILE_C;
-        double pcx[2], pcy[2], cax[2], cay[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int col = 2 * lane + 128 * u;
-            pcx[u] = col < ncols ? pc[col] : 0.0; pcy[u] = col + 1 < ncols ? pc[col + 1] : 0.0;
-            cax[u] = 0.0; cay[u] = 0.0;
-        }
-        // Strips in 4 phases of 8 (a real loop, so that the register budget stays at one phase): the 16 16-byte loads of a phase
-        // are issued together, 16 KiB in flight per wave.  Row sums: 32 sums over 64 lanes with 32 shuffles instead of 32 x 6.  In
-        // every butterfly step a lane keeps the half of its values whose index bit matches its lane bit and adds the partner's:
-        // xor 32, 16, 8 fold the 8 strips of a phase into one value per lane, xor 4, 2 fold the 4 phases, xor 1 completes the sum.
-        // Fixed order: deterministic.
-        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-#pragma unroll 1
-        for (int ph = 0; ph < TILE_R / 8; ++ph) {
-            double x0[8], y0[8], x1[8], y1[8], ra[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const dbl2 *strip = reinterpret_cast<const dbl2 *>(tv + (size_t)(8 * ph + q) * TILE_C);
-                const dbl2 v0 = LDM(strip + lane), v1 = LDM(strip + 64 + lane);
-                x0[q] = v0.x; y0[q] = v0.y; x1[q] = v1.x; y1[q] = v1.y;
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const double prow = pr[8 * ph + q];
-                ra[q] = (x0[q] * pcx[0] + y0[q] * pcy[0]) + (x1[q] * pcx[1] + y1[q] * pcy[1]);
-                cax[0] += x0[q] * prow; cay[0] += y0[q] * prow; cax[1] += x1[q] * prow; cay[1] += y1[q] * prow;
-            }
-#pragma unroll
-            for (int half = 4, bit = 32; half >= 1; half >>= 1, bit >>= 1) {
-                const bool up = (lane & bit) != 0;
-#pragma unroll
-                for (int j = 0; j < half; ++j) {
-                    const double keep = up ? ra[j + half] : ra[j];
-                    const double send = up ? ra[j] : ra[j + half];
-                    ra[j] = keep + __shfl_xor(send, bit, WAVE);
-                }
-            }
-            acc0 = ph == 0 ? ra[0] : acc0; acc1 = ph == 1 ? ra[0] : acc1; acc2 = ph == 2 ? ra[0] : acc2; acc3 = ph == 3 ? ra[0] : acc3;
-        }
-        {
-            const bool up4 = (lane & 4) != 0, up2 = (lane & 2) != 0;
-            const double b0 = (up4 ? acc2 : acc0) + __shfl_xor(up4 ? acc0 : acc2, 4, WAVE);      // phases 0|2 by lane bit 2
-            const double b1 = (up4 ? acc3 : acc1) + __shfl_xor(up4 ? acc1 : acc3, 4, WAVE);      // phases 1|3
-            const double c0 = (up2 ? b1 : b0) + __shfl_xor(up2 ? b0 : b1, 2, WAVE);              // +1 by lane bit 1
-            const double rsum = c0 + __shfl_xor(c0, 1, WAVE);
-            // strip of this lane: phase = 2*bit2 + bit1, index in the phase = 4*bit5 + 2*bit4 + bit3
-            const int rr = 8 * (((lane >> 2) & 1) * 2 + ((lane >> 1) & 1)) + ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
-            if ((lane & 1) == 0) rowpart[cell * TILE_R + rr] = rsum;
-        }
-        double *cp = colpart + cell * TILE_C;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int col = 2 * lane + 128 * u;
-            if (col + 1 < ncols) { dbl2 v; v.x = cax[u]; v.y = cay[u]; *reinterpret_cast<dbl2 *>(cp + col) = v; }
-            else if (col < ncols) cp[col] = cax[u];
-        }
-        return;
-    }
-    const int bid = (int)blockIdx.x - (TILES ? ntb : 0);          // block index among the segment + short-row blocks
+    const int bid = (int)blockIdx.x;
     if (bid >= nsb) {
         // the short rows ride along in the same launch (independent of the segments): 16 lanes per row, p.t partial per block
         if (threadIdx.x == 0) sdone = ctrl->done;
         __syncthreads();
         if (sdone) return;
-        if (TILES) {
-            // tile mode: this work is no longer hidden behind a long matrix stream, and what it costs is dependent loads per wave
-            // times the number of wave rounds: 8 lanes per row (the rows average 17 entries) from the packed copy, one row per
-            // group and launch, so that half as many waves go through the descriptor -> (value, column) -> p chain once
-            const int g8 = threadIdx.x >> 3, l8 = threadIdx.x & 7;
-            const int nb8 = gridDim.x - nsb - ntb;
-            double acc = 0.0;
-            for (int ridx = (bid - nsb) * (SEGK_NT / 8) + g8; ridx < n_short; ridx += nb8 * (SEGK_NT / 8)) {      // one pass unless the grid is capped
-                const int q0 = srp[ridx], q1 = srp[ridx + 1];
-                double s = 0.0;
-                for (int q = q0 + l8; q < q1; q += 8) s += sval[q] * p[scol[q]];
-                s += __shfl_xor(s, 4, 8); s += __shfl_xor(s, 2, 8); s += __shfl_xor(s, 1, 8);
-                if (l8 == 0) { const int row = short_rows[ridx]; t[row] = s; acc += p[row] * s; }
-            }
-            const double tot = block_sum_all<SEGK_NT>(acc, red);
-            if (threadIdx.x == 0) part[bid - nsb] = tot;
-            return;
-        }
         const int g = threadIdx.x >> 4, l = threadIdx.x & 15;
         const int nb = gridDim.x - nsb;
         double acc = 0.0;
@@ -884,21 +432,6 @@ __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *
         return;
     }
     if (ctrl->done) return;                  // no barrier on this path: a per-wave read is fine
-    if (TILES) {
-        // tile mode: what the tiles leave behind are short pieces (63 entries on average at 85 k sites): 16 lanes per segment,
-        // 16 segments per workgroup, for the same reason as above
-        const int l16 = threadIdx.x & 15;
-        const int seg = bid * (SEGK_NT / 16) + (threadIdx.x >> 4);
-        if (seg >= nseg) return;
-        const RunDesc d = segs[seg];
-        double g = 0.0;
-        if (d.sr0 < 0) { for (int k = l16; k < d.len; k += 16) g += gval[d.pos + k] * p[gcol[d.pos + k]]; }      // packed remainder entries
-        else { const double *av = a + d.pos, *pv = pS + d.sr0; for (int k = l16; k < d.len; k += 16) g += LDM(av + k) * pv[k]; }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) g += __shfl_xor(g, off, 16);
-        if (l16 == 0) seg_part[seg] = g;
-        return;
-    }
     const int lane = threadIdx.x & 63;
     const int seg = bid * (SEGK_NT / 64) + (threadIdx.x >> 6);
     if (seg >= nseg) return;
@@ -934,6 +467,7 @@ __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *
     double s = (s0 + s1) + (s2 + s3);
     s = wave_sum(s);
     if (lane == 0) seg_part[seg] = s;
+#undef LDM
 }
 
 // row binning: flag long rows, build the two row lists
@@ -1010,93 +544,20 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
     } while (0)
 
     // ---- dense-run view of the long rows ----
-    static const int use_runs_env = getenv("DKMC_NO_RUNS") ? 0 : 1;
-    // experiments only; the descriptor capacity per row (nnz/RUN_MIN_LEN + 1) needs segments of at least 2 * RUN_MIN_LEN entries
-    static const int seg_len = getenv("DKMC_SEG_LEN") ? (atoi(getenv("DKMC_SEG_LEN")) < 2 * RUN_MIN_LEN ? 2 * RUN_MIN_LEN : atoi(getenv("DKMC_SEG_LEN"))) : SEG_LEN;
-    const bool use_runs = use_runs_env && srank && n_long > 0 && ns > 0;
+    const bool use_runs = srank && n_long > 0 && ns > 0;
     RunDesc *runs = nullptr, *segs = nullptr; int *nruns = nullptr, *rem = nullptr, *nrem = nullptr, *seg_off = nullptr; double *pS = nullptr, *seg_part = nullptr;
-    static const double tile_min_fill = getenv("DKMC_TILE_FILL") ? atof(getenv("DKMC_TILE_FILL")) : TILE_MIN_FILL;
-    static const double tile_min_cover = getenv("DKMC_TILE_COVER") ? atof(getenv("DKMC_TILE_COVER")) : 0.8;   // fraction of X that must sit in tiles
-    bool use_tiles = false; int nK = 0, nW = 0, ntiles = 0; int *dense = nullptr, *toff = nullptr, *nsegs = nullptr;
-    TileDesc *tiles = nullptr; double *rowpart = nullptr, *colpart = nullptr, *tval = nullptr, *csum = nullptr; int csum_pitch = 0; int *trange = nullptr, *lsr = nullptr, *chk = nullptr, *goff = nullptr, *gcol = nullptr, *srp = nullptr, *scol = nullptr;
-    double *gval = nullptr, *sval = nullptr; LRowMeta *lmeta = nullptr;
-    int nseg = 0, nseg_loc = 0, seg_lo = 0, tile_lo = 0, ntiles_loc = 0; bool sharded = false; RowParts parts{}, *dparts = nullptr; double *xbuf = nullptr;
+    int nseg = 0, nseg_loc = 0, seg_lo = 0; bool sharded = false; RowParts parts{}, *dparts = nullptr; double *xbuf = nullptr;
     if (use_runs) {
         runs = (RunDesc *)scratch(S_CG_RUNS, ((size_t)nnz / RUN_MIN_LEN + n_long + 2) * sizeof(RunDesc));
         rem = (int *)scratch(S_CG_REM, (size_t)nnz * 4);
         nruns = (int *)scratch(S_CG_NRUNS, (size_t)n_long * 2 * 4);
-        pS = (double *)scratch(S_CG_PS, (size_t)(ns + TILE_C) * 8);      // + zero padding for the last tile row block / window
+        pS = (double *)scratch(S_CG_PS, (size_t)(ns + 2) * 8);
         if (!runs || !rem || !nruns || !pS) return e.err_code;
         nrem = nruns + n_long;
-        // symmetric tiles (also in the sharded solve: then one all-reduce per iteration instead of the bit-identical all-gather scheme)
-        use_tiles = e.symmetric_tiles && ns > TILE_C;
-        hipLaunchKernelGGL((k_build_runs<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, ci, srank, runs, nruns, rem, nrem,
-                           use_tiles ? 0x7fffffff : seg_len, use_tiles ? 1 : 0);
+        hipLaunchKernelGGL((k_build_runs<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, ci, srank, runs, nruns, rem, nrem, SEG_LEN);
         seg_off = (int *)scratch(S_CG_SEGOFF, (size_t)(n_long + 4) * 4);
         if (!seg_off) return e.err_code;
-        int rc = 0;
-        if (use_tiles) {
-            // raw runs -> entries per grid cell -> choice of tiles -> segment list of what the tiles do not cover
-            nK = (ns + TILE_R - 1) / TILE_R; nW = (ns + TILE_C - 1) / TILE_C;
-            const long long ncand = (long long)nK * nW;
-            if (ncand > 0x7fffff00ll) return dkmc_fail(47, "CG: too many tile candidates", __FILE__, __LINE__);
-            dense = (int *)scratch(S_CG_TDENSE, (size_t)(ncand + 4) * 4);
-            toff = (int *)scratch(S_CG_TOFF, (size_t)(ncand + 4) * 4);
-            nsegs = (int *)scratch(S_CG_NSEGS, (size_t)(n_long + 4) * 4);
-            lsr = (int *)scratch(S_CG_LSR, (size_t)(n_long + 4) * 4);
-            int *cnt = (int *)scratch(S_CG_S2R, (size_t)(3 * ncand + 8) * 4);                 // cntU | symmetry check | covered
-            long long *cov = (long long *)scratch(S_MISC3, (size_t)(ncand + 4) * 8);
-            if (!dense || !toff || !nsegs || !lsr || !cnt || !cov) return e.err_code;
-            HIPCHK(hipMemsetAsync(cnt, 0, (size_t)(2 * ncand) * 4, st));
-            hipLaunchKernelGGL(k_lsr, dim3((n_long + 255) / 256), dim3(256), 0, st, n_long, long_rows, srank, lsr);
-            chk = cnt + ncand;
-            hipLaunchKernelGGL((k_tile_count<RP>), dim3((n_long + 255) / 256), dim3(256), 0, st, n_long, long_rows, rp, srank, (const RunDesc *)runs,
-                               (const int *)nruns, nW, cnt);
-            hipLaunchKernelGGL(k_tile_choose, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, st, ns, nK, nW, tile_min_fill, (const int *)cnt, dense, cnt + 2 * ncand);
-            rc = dkmc_exclusive_scan_i32(dense, toff, (int)ncand, toff + ncand); if (rc) return rc;
-            rc = dkmc_exclusive_scan_i32_i64(cnt + 2 * ncand, cov, (int)ncand, cov + ncand); if (rc) return rc;
-            long long covered = 0;
-            HIPCHK(hipMemcpyAsync(&ntiles, toff + ncand, sizeof(int), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipMemcpyAsync(&covered, cov + ncand, sizeof(long long), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            // Tiles pay off when they take most of X out of the segment path; otherwise the leftovers fragment into short segments
-            // and the plain segment path is faster: fall back to it.
-            if ((double)covered < tile_min_cover * (double)nnz) {
-                use_tiles = false; ntiles = 0;
-                hipLaunchKernelGGL((k_build_runs<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, ci, srank, runs, nruns, rem, nrem, seg_len, 0);
-            }
-            e.stats.spmv_tile_entries = use_tiles ? covered / 2 : 0;
-        }
-        if (use_tiles) {
-            const long long ncand = (long long)nK * nW;
-            tiles = (TileDesc *)scratch(S_CG_TILES, (size_t)(ntiles + 1) * sizeof(TileDesc));
-            tval = (double *)scratch(S_CG_TVAL, (size_t)(ntiles + 1) * TILE_R * TILE_C * 8);
-            rowpart = (double *)scratch(S_CG_ROWPART, (size_t)(ncand + 1) * TILE_R * 8);      // one cell per grid position, zero where no tile
-            colpart = (double *)scratch(S_CG_COLPART, (size_t)(ncand + 1) * TILE_C * 8);
-            trange = (int *)scratch(S_CG_CSUM, (size_t)(2 * nK + nW + 8) * 4);
-            if (!tiles || !tval || !rowpart || !colpart || !trange) return e.err_code;
-            if (nK >= 512) {          // many row blocks per window: pre-sum the column partials (k_tile_colsum; at 262 row blocks the extra launch costs more than it saves)
-                csum_pitch = (ns + 63) & ~63;
-                csum = (double *)scratch(S_CG_CSUM2, (size_t)COLSUM_SLICES * csum_pitch * 8);
-                if (!csum) return e.err_code;
-            }
-            HIPCHK(hipMemsetAsync(rowpart, 0, (size_t)ncand * TILE_R * 8, st));
-            HIPCHK(hipMemsetAsync(colpart, 0, (size_t)ncand * TILE_C * 8, st));
-            HIPCHK(hipMemsetAsync(tval, 0, (size_t)ntiles * TILE_R * TILE_C * 8, st));
-            HIPCHK(hipMemsetAsync(pS + ns, 0, (size_t)TILE_C * 8, st));              // padding read by tiles of a partial last row block / window
-            hipLaunchKernelGGL(k_tile_list, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, st, nK, nW, (const int *)dense, (const int *)toff, tiles);
-            hipLaunchKernelGGL(k_tile_ranges, dim3((std::max(nK, nW) + 255) / 256), dim3(256), 0, st, nK, nW, (const int *)dense, trange, trange + nK, trange + 2 * nK);
-            // packed remainder entries: offsets now, values after the Jacobi scaling
-            goff = (int *)scratch(S_CG_GOFF, (size_t)(n_long + 4) * 4);
-            if (!goff) return e.err_code;
-            rc = dkmc_exclusive_scan_i32(nrem, goff, n_long, goff + n_long); if (rc) return rc;
-            hipLaunchKernelGGL((k_emit_segs<0, RP>), dim3((n_long + 255) / 256), dim3(256), 0, st, n_long, long_rows, rp, srank, (const RunDesc *)runs,
-                               (const int *)nruns, ns, nW, (const int *)dense, TILE_SEG_LEN, nsegs, (const int *)nullptr, (RunDesc *)nullptr, (const int *)goff, (int *)nullptr);
-            rc = dkmc_exclusive_scan_i32(nsegs, seg_off, n_long, seg_off + n_long); if (rc) return rc;
-        } else {
-            rc = dkmc_exclusive_scan_i32(nruns, seg_off, n_long, seg_off + n_long); if (rc) return rc;
-            nsegs = nruns;
-        }
+        int rc = dkmc_exclusive_scan_i32(nruns, seg_off, n_long, seg_off + n_long); if (rc) return rc;
         HIPCHK(hipMemcpyAsync(&nseg, seg_off + n_long, sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         // sharded solve (comm.hip): the long rows are dealt to the ranks at row boundaries, balanced by segment count; a
@@ -1118,72 +579,27 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
             if (parts.chunk == 0) parts.chunk = 2;
             seg_lo = hoff[parts.lo[me]]; nseg_loc = hoff[parts.lo[me + 1]] - seg_lo;
             xbuf = (double *)scratch(S_CG_XCHG, std::max((size_t)nr * parts.chunk, (size_t)n_long + 2) * 8);
-            if (use_tiles) { tile_lo = (int)((long long)ntiles * me / nr); ntiles_loc = (int)((long long)ntiles * (me + 1) / nr) - tile_lo; }
             dparts = (RowParts *)scratch(S_CG_PARTS, sizeof(RowParts));
             if (!xbuf || !dparts) return e.err_code;
             HIPCHK(hipMemcpy(dparts, &parts, sizeof(RowParts), hipMemcpyHostToDevice));
             e.stats.comm_ranks = nr; e.stats.comm_local_segments = nseg_loc; e.stats.comm_count_per_rank = parts.chunk;
-        } else { nseg_loc = nseg; e.stats.comm_ranks = 0; ntiles_loc = ntiles; }
-        if (sharded && use_tiles) e.stats.comm_count_per_rank = n_long;
+        } else { nseg_loc = nseg; e.stats.comm_ranks = 0; }
         e.stats.spmv_segments = nseg;
         segs = (RunDesc *)scratch(S_CG_SEGS, (size_t)(nseg + 1) * sizeof(RunDesc));
         seg_part = (double *)scratch(S_CG_SEGPART, (size_t)(nseg + 1) * 8);
         if (!segs || !seg_part) return e.err_code;
-        if (use_tiles)
-            hipLaunchKernelGGL((k_emit_segs<1, RP>), dim3((n_long + 255) / 256), dim3(256), 0, st, n_long, long_rows, rp, srank, (const RunDesc *)runs,
-                               (const int *)nruns, ns, nW, (const int *)dense, TILE_SEG_LEN, nsegs, (const int *)seg_off, segs, (const int *)goff, chk);
-        else
-            hipLaunchKernelGGL((k_compact_segs<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, (const RunDesc *)runs,
-                               (const int *)nruns, (const int *)seg_off, segs);
-        if (use_tiles) {
-            lmeta = (LRowMeta *)scratch(S_CG_LMETA, (size_t)(n_long + 1) * sizeof(LRowMeta));
-            if (!lmeta) return e.err_code;
-            hipLaunchKernelGGL(k_lrow_meta, dim3((n_long + 255) / 256), dim3(256), 0, st, n_long, long_rows, (const int *)lsr, (const int *)nsegs,
-                               (const int *)seg_off, (const int *)trange, (const int *)(trange + nK), (const int *)(trange + 2 * nK),
-                               sharded ? parts.lo[comm_rank()] : 0, sharded ? parts.lo[comm_rank() + 1] : n_long, lmeta);
-        }
-        e.stats.spmv_tiles = ntiles;
+        hipLaunchKernelGGL((k_compact_segs<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, (const RunDesc *)runs,
+                           (const int *)nruns, (const int *)seg_off, segs);
+        e.stats.spmv_tiles = 0; e.stats.spmv_tile_entries = 0;
     }
-    // blocks of k_spmv_segs: segments (a wave each; 16 lanes each in tile mode), tiles (a wave each), short rows (16 / 8 lanes each)
-    const int nsb = use_tiles ? (nseg_loc + SEGK_NT / 16 - 1) / (SEGK_NT / 16) : (nseg_loc + SEGK_NT / 64 - 1) / (SEGK_NT / 64);
-    const int ntb = (ntiles_loc + SEGK_NT / 64 - 1) / (SEGK_NT / 64);            // (this rank's share of the tiles)
-    const int hsA = (use_runs && n_short > 0) ? grid_for(n_short, use_tiles ? SEGK_NT / 8 : SEGK_NT / 16) : 0;
+    e.stats.xt_subblocks = 0; e.stats.xt_local_subblocks = 0; e.stats.xt_items = 0;
+    // blocks of k_spmv_segs: segments (a wave each), then the short rows (16 lanes each)
+    const int nsb = (nseg_loc + SEGK_NT / 64 - 1) / (SEGK_NT / 64);
+    const int hsA = (use_runs && n_short > 0) ? grid_for(n_short, SEGK_NT / 16) : 0;
     if (use_runs) np_ap = hsA + hl2;
     // ---- Jacobi scaling ----
     SPMV(M_DIAG, (const double *)nullptr, s, x, y, (double *)nullptr);
     SPMV(M_SCALE, (const double *)s, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr);
-    if (use_tiles) {
-        // packed copies of the scaled remainder entries and short rows (k_pack_rem / k_pack_short)
-        int h_tot[2] = {0, 0};
-        int *slen = (int *)scratch(S_MISC0, (size_t)(n_short + 4) * 4);
-        srp = (int *)scratch(S_CG_SRP, (size_t)(n_short + 4) * 4);
-        if (!slen || !srp) return e.err_code;
-        hipLaunchKernelGGL((k_short_len<RP>), dim3((n_short + 255) / 256), dim3(256), 0, st, n_short, short_rows, rp, slen);
-        int rc = dkmc_exclusive_scan_i32(slen, srp, n_short, srp + n_short); if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(&h_tot[0], srp + n_short, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(&h_tot[1], goff + n_long, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        sval = (double *)scratch(S_CG_SVAL, (size_t)(h_tot[0] + 2) * 8); scol = (int *)scratch(S_CG_SCOL, (size_t)(h_tot[0] + 2) * 4);
-        gval = (double *)scratch(S_CG_GVAL, (size_t)(h_tot[1] + 2) * 8); gcol = (int *)scratch(S_CG_GCOL, (size_t)(h_tot[1] + 2) * 4);
-        if (!sval || !scol || !gval || !gcol) return e.err_code;
-        if (n_short > 0) hipLaunchKernelGGL((k_pack_short<RP>), dim3((n_short + 15) / 16), dim3(256), 0, st, n_short, short_rows, rp, ci, (const double *)a,
-                                            (const int *)srp, sval, scol, srank, nW, (const int *)dense, (const int *)toff, tval, chk);
-        hipLaunchKernelGGL((k_pack_rem<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, ci, (const double *)a, (const int *)rem,
-                           (const int *)nrem, (const int *)goff, gval, gcol, srank, nW, (const int *)dense, (const int *)toff, tval, chk);
-        if (ntiles > 0) {
-            hipLaunchKernelGGL((k_tile_scatter<RP>), dim3((n_long + 3) / 4), dim3(256), 0, st, n_long, long_rows, rp, srank, (const RunDesc *)runs,
-                               (const int *)nruns, nW, (const int *)dense, (const int *)toff, (const double *)a, tval, chk);
-            // every upper entry placed in a tile must have had its mirror entry removed from the segment path, cell by cell
-            const long long ncand = (long long)nK * nW;
-            int *d_bad = (int *)scratch(S_MISC1, 16), h_bad = 0;
-            if (!d_bad) return e.err_code;
-            HIPCHK(hipMemsetAsync(d_bad, 0, 4, st));
-            hipLaunchKernelGGL(k_chk_max, dim3((unsigned)((ncand + 255) / 256)), dim3(256), 0, st, ncand, (const int *)chk, d_bad);
-            HIPCHK(hipMemcpyAsync(&h_bad, d_bad, 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            if (h_bad) return dkmc_fail(49, "CG: symmetric tiles: X is not structurally symmetric inside a tile (dkmc_set_symmetric_tiles(0) avoids the tiles)", __FILE__, __LINE__);
-        }
-    }
     // ---- r = A y - x, p = -r ----
     SPMV(M_INIT, (const double *)y, r, x, p, part_rr);
     hipLaunchKernelGGL(k_cg_check0, dim3(1), dim3(CG_NT), 0, st, part_rr, np_spmv, ctrl, tol2);
@@ -1215,11 +631,17 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
     int it = 0, launched = 0;
     int batch = 8;
     if (iter_hint && *iter_hint > 24) batch = *iter_hint - 8;
-    static const int spmv_var = getenv("DKMC_SPMV_VAR") ? atoi(getenv("DKMC_SPMV_VAR")) : 0;   // experiments only
+    // K solves (uniform rows), profiling on: one pair of events around the whole iteration loop
+    static hipEvent_t evk[2]; static bool evk_ready = false;
+    const bool prof_k = e.profiling && uniform_rows;
+    if (prof_k) {
+        if (!evk_ready) { HIPCHK(hipEventCreate(&evk[0])); HIPCHK(hipEventCreate(&evk[1])); evk_ready = true; }
+        HIPCHK(hipEventRecord(evk[0], st));
+    }
     // matrix stream: default cache policy while the values of one sweep fit the 256 MiB Infinity Cache (they are re-read
     // every iteration), non-temporal beyond that (measured: 45 vs 53 us at 240 MB, 478 vs 456 us at 1.86 GB); a rank of a
     // sharded solve streams only its share
-    const int seg_nt = (spmv_var == 3) ? 1 : (spmv_var == 2) ? 0 : (nnz * 8 / (sharded ? comm_nranks() : 1) > (300ll << 20));
+    const int seg_nt = nnz * 8 / (sharded ? comm_nranks() : 1) > (300ll << 20);
     CgCtrl h{};
     for (;;) {
         HIPCHK(hipMemcpyAsync(&h, ctrl, sizeof(CgCtrl), hipMemcpyDeviceToHost, st));
@@ -1244,34 +666,11 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
             hipEvent_t e0 = pb ? evs[4 * b] : nullptr, e1 = pb ? evs[4 * b + 1] : nullptr, e2 = pb ? evs[4 * b + 2] : nullptr, e3 = pb ? evs[4 * b + 3] : nullptr;
             if (use_runs) {
 #define SEG_ARGS nseg_loc, (const RunDesc *)segs + seg_lo, (const double *)a, (const double *)pS, seg_part + seg_lo, (const CgCtrl *)ctrl, (const int *)rem, ci, \
-                 (const double *)p, nsb, n_short, short_rows, rp, long_rows, t, part_pAp, ntb, ntiles_loc, nW, ns, (const TileDesc *)tiles + tile_lo, (const double *)tval + (size_t)tile_lo * TILE_R * TILE_C, rowpart, colpart, \
-                 (const double *)gval, (const int *)gcol, (const int *)srp, (const double *)sval, (const int *)scol
-                const dim3 sg(nsb + hsA + ntb);
-                if (use_tiles) {       // tile role compiled in; short rows and remainder entries from their packed copies
-                    if (seg_nt) hipExtLaunchKernelGGL((k_spmv_segs<1, RP, 1>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
-                    else hipExtLaunchKernelGGL((k_spmv_segs<0, RP, 1>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
-                }
-                else if (seg_nt) hipExtLaunchKernelGGL((k_spmv_segs<1, RP, 0>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
-                else hipExtLaunchKernelGGL((k_spmv_segs<0, RP, 0>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
+                 (const double *)p, nsb, n_short, short_rows, rp, long_rows, t, part_pAp
+                const dim3 sg(nsb + hsA);
+                if (seg_nt) hipExtLaunchKernelGGL((k_spmv_segs<1, RP>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
+                else hipExtLaunchKernelGGL((k_spmv_segs<0, RP>), sg, dim3(SEGK_NT), 0, st, e0, e1, 0, SEG_ARGS);
 #undef SEG_ARGS
-                if (use_tiles) {
-                    if (csum) hipLaunchKernelGGL(k_tile_colsum, dim3(nW * COLSUM_SLICES), dim3(TILE_C), 0, st, ns, nK, nW, (const int *)(trange + 2 * nK),
-                                                 (const double *)colpart, csum, csum_pitch, (const CgCtrl *)ctrl);
-                    if (sharded) {
-                        // this rank's share of every long row's sum -> one all-reduce -> t and the p.t partials on every rank.  All ranks
-                        // receive the same bits and enqueue exactly the same sequence of collectives.
-                        hipLaunchKernelGGL(k_rowsum_tiles, dim3(hl2), dim3(SPMV_NT), 0, st, n_long, (const LRowMeta *)lmeta, (const double *)seg_part, nW,
-                                           (const double *)rowpart, (const double *)colpart, (const double *)csum, csum_pitch, (const double *)p, t,
-                                           part_pAp + hsA, (const CgCtrl *)ctrl, xbuf);
-                        if (int rc = comm_allreduce_sum_f64(xbuf, (size_t)n_long)) return rc;
-                        if (pb) HIPCHK(hipEventRecord(evc[b / PROF_STRIDE], st));
-                        hipExtLaunchKernelGGL(k_xbuf_apply, dim3(hl2), dim3(SPMV_NT), 0, st, e2, e3, 0, n_long, (const LRowMeta *)lmeta, (const double *)xbuf,
-                                              (const double *)p, t, part_pAp + hsA, (const CgCtrl *)ctrl);
-                    } else
-                    hipExtLaunchKernelGGL(k_rowsum_tiles, dim3(hl2), dim3(SPMV_NT), 0, st, e2, e3, 0, n_long, (const LRowMeta *)lmeta,
-                                          (const double *)seg_part, nW, (const double *)rowpart, (const double *)colpart, (const double *)csum, csum_pitch,
-                                          (const double *)p, t, part_pAp + hsA, (const CgCtrl *)ctrl, (double *)nullptr);
-                } else
                 if (sharded) {
                     // row sums of the owned rows -> exchange step -> t and the p.t partials on every rank.  Every rank enqueues
                     // exactly the same sequence of collectives (the batch plan and the stop decisions depend only on values
@@ -1300,6 +699,13 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
         else if (batch < 64) batch *= 2;
     }
 #undef SPMV
+    if (prof_k) {
+        HIPCHK(hipEventRecord(evk[1], st));
+        HIPCHK(hipEventSynchronize(evk[1]));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, evk[0], evk[1]));
+        e.stats.kcg_ms = ms; e.stats.kcg_iters_timed = h.iters;
+    } else if (uniform_rows) { e.stats.kcg_ms = 0.0; e.stats.kcg_iters_timed = 0; }
     if (prof) {
         e.stats.spmv_long_ms = prof_long_ms; e.stats.spmv_short_ms = prof_short_ms;
         e.stats.spmv_long_launches = prof_long_n; e.stats.spmv_short_launches = prof_short_n;

@@ -104,7 +104,6 @@ struct Engine {
     int current_warm_start = 0;
     int profiling = 0;
     int x_format = 1;              // 1: tiled X (xt.hip, default); 0: CSR X as the reference stores it (current.hip + cg.hip)
-    int symmetric_tiles = 1;       // CSR X only: CG on X: read dense blocks of the (symmetric) tunnelling part once for both triangles (cg.hip)
     int x_iter_hint = 0;           // iteration count of the previous CG solve of X (sizes the first launch batch)
     dkmc_stats stats{};
     char err[512] = {0};
@@ -129,7 +128,7 @@ inline MetalSet load_metals(const int *d_metals, int num_metals) { MetalSet ms; 
 
 // scratch slots
 enum {
-    S_CG_S = 0, S_CG_R, S_CG_P, S_CG_T, S_CG_PART, S_CG_CTRL, S_CG_RUNS, S_CG_REM, S_CG_NRUNS, S_CG_PS, S_CG_SEGOFF, S_CG_SEGS, S_CG_SEGPART, S_CG_XCHG, S_CG_PARTS, S_CG_S2R, S_CG_TDENSE, S_CG_TOFF, S_CG_NSEGS, S_CG_TILES, S_CG_ROWPART, S_CG_COLPART, S_CG_CSUM, S_CG_LSR, S_CG_GOFF, S_CG_SRP, S_CG_SVAL, S_CG_SCOL, S_CG_GVAL, S_CG_GCOL, S_CG_LMETA, S_CG_TVAL, S_CG_CSUM2,
+    S_CG_S = 0, S_CG_R, S_CG_P, S_CG_T, S_CG_PART, S_CG_CTRL, S_CG_RUNS, S_CG_REM, S_CG_NRUNS, S_CG_PS, S_CG_SEGOFF, S_CG_SEGS, S_CG_SEGPART, S_CG_XCHG, S_CG_PARTS,
     S_K_DATA, S_K_RHS,
     S_PW_LIST, S_PW_CNT,
     S_EV_PROB, S_EV_ROWSUM, S_EV_G2, S_EV_G3, S_EV_CTRL, S_EV_UNI, S_EV_LOG,

@@ -319,7 +319,20 @@ extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, 
     hipLaunchKernelGGL(k_charge_flags, dim3(blocks), dim3(256), 0, st, N, charge, flag);
     int rc = dkmc_exclusive_scan_i32(flag, off, N, cnt); if (rc) return rc;
     hipLaunchKernelGGL(k_charge_scatter, dim3(blocks), dim3(256), 0, st, N, charge, off, x, y, z, list);
+    static hipEvent_t evp[2]; static bool evp_ready = false;
+    if (e.profiling) {
+        if (!evp_ready) { HIPCHK(hipEventCreate(&evp[0])); HIPCHK(hipEventCreate(&evp[1])); evp_ready = true; }
+        HIPCHK(hipEventRecord(evp[0], st));
+    }
     hipLaunchKernelGGL(k_pairwise, dim3((N + PW_NT - 1) / PW_NT), dim3(PW_NT), 0, st, N, x, y, z, lattice, pbc, sigma, k, list, cnt, out);
     KCHK();
+    e.stats.pair_ms = 0.0;
+    if (e.profiling) {
+        HIPCHK(hipEventRecord(evp[1], st));
+        HIPCHK(hipEventSynchronize(evp[1]));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, evp[0], evp[1]));
+        e.stats.pair_ms = ms;
+    }
     return 0;
 }

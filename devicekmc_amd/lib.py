@@ -39,7 +39,8 @@ class dkmc_stats(C.Structure):
                 ("comm_ms", C.c_double), ("comm_launches", C.c_int), ("comm_pad", C.c_int),
                 ("spmv_tiles", C.c_int), ("spmv_pad2", C.c_int), ("spmv_tile_entries", C.c_longlong),
                 ("xt_subblocks", C.c_longlong), ("xt_local_subblocks", C.c_longlong), ("xt_items", C.c_int), ("xt_kc", C.c_int),
-                ("xt_sparse_nnz", C.c_longlong), ("xt_ns", C.c_int), ("xt_pad", C.c_int)]
+                ("xt_sparse_nnz", C.c_longlong), ("xt_ns", C.c_int), ("xt_pad", C.c_int),
+                ("kcg_ms", C.c_double), ("kcg_iters_timed", C.c_int), ("kcg_pad", C.c_int), ("pair_ms", C.c_double)]
 
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
@@ -58,7 +59,6 @@ SYMBOLS = {
     "dkmc_set_cg_tolerance": (None, [_D]),
     "dkmc_set_current_warm_start": (None, [_I]),
     "dkmc_set_profiling": (None, [_I]),
-    "dkmc_set_symmetric_tiles": (None, [_I]),
     "dkmc_set_x_format": (None, [_I]),
     "dkmc_gpubuf_create": (_I, [C.POINTER(dkmc_gpubuf), _I, _I, _I, _I, vp, vp, vp, vp, vp, vp, _D, _D, _D, vp]),
     "dkmc_gpubuf_free": (_I, [C.POINTER(dkmc_gpubuf)]),

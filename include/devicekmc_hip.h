@@ -73,8 +73,8 @@ typedef struct dkmc_stats {
     long long comm_count_per_rank;
     double comm_ms;
     int comm_launches, comm_pad;
-    /* symmetric tiles of the last CG solve on X: 32 x 256 blocks of the tunnelling block read once for both triangles
-     * (same launch as the segments) */
+    /* tiled X: 32 x 256 tiles of the tunnelling block (read once per iteration for both triangles) and the entries of the
+     * upper triangle they hold */
     int spmv_tiles, spmv_pad2;
     long long spmv_tile_entries;
     /* tiled X (dkmc_set_x_format(1), the default): stored 32 x 32 sub-blocks of the tunnelling block (8 KiB each; all ranks /
@@ -84,6 +84,11 @@ typedef struct dkmc_stats {
     int xt_items, xt_kc;
     long long xt_sparse_nnz;
     int xt_ns, xt_pad;
+    /* profiling on: HIP-event time of the whole iteration loop of the last CG solve on K (and the iterations it covers), and
+     * of the last pair-sum kernel */
+    double kcg_ms;
+    int kcg_iters_timed, kcg_pad;
+    double pair_ms;
 } dkmc_stats;
 
 const char *dkmc_last_error(void);
@@ -105,11 +110,6 @@ void dkmc_set_current_warm_start(int mode);
 /* 1: bracket every SpMV launch of the CG solves with HIP events on the engine's stream and accumulate
  * their durations into dkmc_stats (measurement aid for bench.py; off by default) */
 void dkmc_set_profiling(int on);
-/* 1 (default): the CG on X reads the dense blocks of its symmetric tunnelling part once per iteration for both triangles
- * ("symmetric tiles") when at least 80 % of X sits in such blocks; 0: every stored entry is read, the
- * arithmetic of the sharded solve (which never uses tiles).  Both agree to rounding (a_ij s_i s_j is formed in a different
- * order for the two triangles). */
-void dkmc_set_symmetric_tiles(int on);
 /* layout of the current-solve matrix X (update_power_gpu_sparse).  1 (default): tiled X -- the neighbour part as a small CSR,
  * the tunnelling block generated straight into symmetric 32 x 256 tiles (upper triangle only, no column indices, one copy);
  * per-rank storage and assembly when a communicator is attached.  0: CSR X exactly as the reference stores it

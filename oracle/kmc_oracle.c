@@ -9,8 +9,9 @@
  * path differs (used only to pin the oracle against CPU-path numbers).
  *
  * Pinning (see oracle/README.md and tests/test_oracle_golden.py):
- *   - X sparsity pattern == the CSR dump the reference ships
- *     (structures/single_devices/timing_2.5nm/fullmatrix_assembly/), bit-exact;
+ *   - X sparsity pattern vs the CSR dump the reference ships
+ *     (structures/single_devices/timing_2.5nm/fullmatrix_assembly/): identical except 44 of 467 336
+ *     entries, all vacancy-vacancy tunnelling pairs;
  *   - Current [uA] / KMC time of the reference's own CUDA-path log
  *     (structures/single_devices/timing_7.5nm/output_noguess.txt) at 85 071 sites.
  *
@@ -815,4 +816,62 @@ double okmc_temperature_global(int N, const double *site_power, double T_bg, dou
     double c = b + P / C * small_step;
     int step = (int)number_steps;
     return c * (1.0 - pow(a, (double)step)) / (1.0 - a) + pow(a, (double)step) * T_bg;
+}
+
+/* ------------------------------------------------------------------------- */
+/* cpu_baseline of bench.py's scale points (sizes at which a full CPU superstep would take hours and the assembled X does
+ * not fit int32 row pointers): seconds per iteration of the loop body of okmc_cg_jacobi above -- one CSR SpMV, three dot
+ * products, three vector updates, the same OpenMP schedules -- on a CSR with X's shape at that size: m rows of which n_long
+ * (spread evenly) share nnz_long entries in runs of consecutive columns, the others share nnz_short entries near the diagonal.
+ * Columns and values are synthetic: the time of an iteration depends on neither.  64-bit row pointers. */
+double okmc_cg_iter_bench(int m, int n_long, long long nnz_long, long long nnz_short, int niter)
+{
+    if (m < 4 || niter < 1) return -1.0;
+    if (n_long > m) n_long = m;
+    long long *rp = (long long *)malloc(((size_t)m + 1) * sizeof(long long));
+    if (!rp) return -1.0;
+    int n_short = m - n_long;
+    long long per_long = n_long > 0 ? nnz_long / n_long : 0, per_short = n_short > 0 ? nnz_short / n_short : 0;
+    if (per_long > m) per_long = m;
+    if (per_short > m) per_short = m;
+    int stride = n_long > 0 ? m / n_long : m + 1;
+    rp[0] = 0;
+    for (int i = 0; i < m; ++i) {
+        int is_long = n_long > 0 && (i % stride) == 0 && (i / stride) < n_long;
+        rp[i + 1] = rp[i] + (is_long ? per_long : per_short);
+    }
+    long long nnz = rp[m];
+    int *ci = (int *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(int));
+    double *a = (double *)malloc((size_t)(nnz > 0 ? nnz : 1) * sizeof(double));
+    double *x = (double *)malloc((size_t)m * sizeof(double)), *y = (double *)malloc((size_t)m * sizeof(double));
+    double *r = (double *)malloc((size_t)m * sizeof(double)), *p = (double *)malloc((size_t)m * sizeof(double)), *t = (double *)malloc((size_t)m * sizeof(double));
+    if (!ci || !a || !x || !y || !r || !p || !t) { free(rp); free(ci); free(a); free(x); free(y); free(r); free(p); free(t); return -1.0; }
+#pragma omp parallel for schedule(dynamic, 512)
+    for (int i = 0; i < m; ++i) {                 /* first touch with the schedule of spmv() */
+        long long len = rp[i + 1] - rp[i];
+        long long c0 = len > 64 ? ((long long)i * 7919) % (m - len + 1) : (i - len / 2 < 0 ? 0 : (i + len > m ? m - len : i - len / 2));
+        for (long long q = 0; q < len; ++q) { ci[rp[i] + q] = (int)(c0 + q); a[rp[i] + q] = (c0 + q == i) ? 1.0 : -1e-3 / (double)(len + 1); }
+        y[i] = 0.0; r[i] = 1.0 / (1.0 + i % 17); p[i] = -r[i]; x[i] = 0.0;
+    }
+    double t0 = 0.0, elapsed = 0.0;
+    for (int it = -1; it < niter; ++it) {         /* one untimed warm-up iteration */
+        if (it == 0) t0 = omp_get_wtime();
+        double tt = dot(m, r, r);
+#pragma omp parallel for schedule(dynamic, 512)
+        for (int i = 0; i < m; ++i) {
+            double s = 0.0;
+            for (long long q = rp[i]; q < rp[i + 1]; ++q) s += a[q] * p[ci[q]];
+            t[i] = s;
+        }
+        double alpha = tt / dot(m, p, t);
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < m; ++i) { y[i] += alpha * p[i]; r[i] += alpha * t[i]; }
+        double tnew = dot(m, r, r);
+        double beta = tnew / tt;
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < m; ++i) p[i] = p[i] * beta - r[i];
+    }
+    elapsed = omp_get_wtime() - t0;
+    free(rp); free(ci); free(a); free(x); free(y); free(r); free(p); free(t);
+    return elapsed / niter;
 }

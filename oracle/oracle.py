@@ -43,6 +43,8 @@ def lib():
         L.okmc_imacro_row0.restype = C.c_double
         L.okmc_imacro_row0.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double]
         L.okmc_temperature_global.restype = C.c_double
+        L.okmc_cg_iter_bench.restype = C.c_double
+        L.okmc_cg_iter_bench.argtypes = [C.c_int, C.c_int, C.c_longlong, C.c_longlong, C.c_int]
         L.okmc_temperature_global.argtypes = [C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_double,
                                               C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]
         _LIB = L
@@ -88,6 +90,11 @@ def cg_jacobi(row_ptr, col, data, rhs, guess, tol=1e-6, max_iter=0):
     rr = C.c_double(0)
     it = lib().okmc_cg_jacobi(len(x), _p(row_ptr), _p(col), _p(a), _p(x), _p(y), C.c_double(tol), int(max_iter), C.byref(rr))
     return y, it, rr.value
+
+
+def cg_iter_bench(m, n_long, nnz_long, nnz_short, niter=3):
+    """Seconds per iteration of the oracle's CG loop body on a CSR of X's shape (see okmc_cg_iter_bench)."""
+    return lib().okmc_cg_iter_bench(int(m), int(n_long), int(nnz_long), int(nnz_short), int(niter))
 
 
 class OracleKMC:

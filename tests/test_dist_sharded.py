@@ -1,13 +1,15 @@
-"""The sharded current solve (csrc/comm.hip): N ranks advance one simulation in lockstep, the matrix stream of A*p is dealt to
-the ranks and completed by one collective per CG iteration.  Runs-only arithmetic (dkmc_set_symmetric_tiles(0)): all-gather of
-row sums, bit-identical to the single-GPU run.  Symmetric tiles (default): all-reduce of row sums, all ranks bit-identical to
-each other and equal to the single-GPU run to rounding.
+"""The sharded current solve (csrc/comm.hip + xt.hip / cg.hip): N ranks advance one simulation in lockstep.
 
-* two ranks sharing cuda:0 over the host-callback transport (gloo) -- RCCL refuses two ranks on one device, and the test
-  box has one GPU; this covers the partitioning, the lockstep launch plan and the exchange placement;
-* the RCCL transport itself with a communicator of one rank (dlopen, ncclCommInitRank, in-place ncclAllGather on the
-  engine's stream).
-(File name: sorts before the other GPU tests so that the ranks are spawned from a parent that has not touched the GPU.)
+* Tiled X (default, dkmc_set_x_format(1)): the work items (runs of tiles) are dealt to the ranks in contiguous, byte-balanced
+  shares; a rank generates, stores and streams only its tiles; one all-reduce of |S| doubles per matrix-vector product.  All ranks
+  hold the same bits; the result equals the single-GPU one to rounding.
+* CSR X (dkmc_set_x_format(0)): the long rows are dealt to the ranks, one all-gather of row sums per iteration, values and
+  summation orders of the single-GPU kernels: bit-identical to the single-GPU run.
+
+Covered here: two ranks sharing cuda:0 over the host-callback transport (gloo) -- RCCL refuses two ranks on one device and the
+test box has one GPU; this covers the partitioning, the per-rank storage, the lockstep launch plan and the exchange placement --
+and the RCCL transport itself with a communicator of one rank (dlopen, ncclCommInitRank, in-place collectives on the engine's
+stream).  (File name: sorts before the other GPU tests so that the ranks are spawned from a parent that has not touched the GPU.)
 """
 import os
 import socket
@@ -26,13 +28,12 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _supersteps(nsteps, seed=1, tiles=0, big=False):
-    """nsteps supersteps from a fresh state of the 2.5 nm device (big: the 85 071-site 7.5 nm device, whose tunnelling block is
-    large enough for symmetric tiles); returns everything a caller of the path can observe.
-    tiles=0: the single-GPU solve reads every stored entry (the arithmetic the sharded solve reproduces bit for bit)."""
+def _supersteps(nsteps, seed=1, fmt=0, big=False):
+    """nsteps supersteps from a fresh state of the 2.5 nm device (big: the 85 071-site 7.5 nm device); returns everything a
+    caller of the path can observe.  fmt: dkmc_set_x_format (0 = CSR X, the arithmetic the sharded solve reproduces bit for bit)."""
     import torch
     from devicekmc_amd import host, lib, params, structure
-    lib.load().dkmc_set_symmetric_tiles(tiles)
+    lib.load().dkmc_set_x_format(fmt)
     g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     if big:
         s = structure.load_structure(os.path.join(g, "device_7.5nm.npz"))
@@ -56,6 +57,7 @@ def _supersteps(nsteps, seed=1, tiles=0, big=False):
         trace.append((dt, dev.imacro, dev.T_bg)); iters.append(host.get_stats()["cg_iters_X"])
     fields = {n: gb.t[n].cpu().numpy().copy() for n in ("site_power", "site_potential_boundary", "site_potential_charge",
                                                         "site_charge", "site_element", "atom_virtual_potentials")}
+    lib.load().dkmc_set_x_format(1)
     return trace, iters, fields, dict(host.get_stats())
 
 
@@ -66,11 +68,11 @@ def _worker(rank, world, port, q):
     parallel.init("gloo")
     torch.cuda.set_device(0)
     ref = _supersteps(NSTEPS) if rank == 0 else None           # single-GPU path, no communicator
-    ref_tiles = _supersteps(2, tiles=1, big=True) if rank == 0 else None    # default single-GPU arithmetic (symmetric tiles), 85 k sites
+    ref_tiles = _supersteps(2, fmt=1, big=True) if rank == 0 else None      # default single-GPU arithmetic (tiled X), 85 k sites
     parallel.barrier()
     assert parallel.attach_solver_comm() == "host"
     got = _supersteps(NSTEPS)
-    got_tiles = _supersteps(2, tiles=1, big=True)               # tiles dealt to the ranks, one all-reduce per iteration
+    got_tiles = _supersteps(2, fmt=1, big=True)                 # tiles dealt to the ranks, one all-reduce per matrix-vector product
     parallel.detach_solver_comm()
     parallel.barrier()
     q.put((rank, ref, got, ref_tiles, got_tiles))
@@ -95,7 +97,7 @@ def test_two_ranks_lockstep_bit_identical():
         for n in rfields:
             assert np.array_equal(fields[n], rfields[n]), (rank, n)   # every field a caller can read back: bit-identical
         assert st["comm_ranks"] == 2 and st["comm_count_per_rank"] % 2 == 0
-    # sharded solve with symmetric tiles: the ranks agree bit for bit and match the single-GPU tile solve to rounding
+    # sharded solve on the tiled X: the ranks agree bit for bit and match the single-GPU solve to rounding
     assert gt0[0] == gt1[0] and gt0[1] == gt1[1]
     for n in gt0[2]:
         assert np.array_equal(gt0[2][n], gt1[2][n]), n
@@ -104,6 +106,11 @@ def test_two_ranks_lockstep_bit_identical():
         assert abs(dt - dt2) <= 1e-8 * dt and abs(im - im2) <= 1e-8 * abs(im) and abs(tb - tb2) <= 1e-8 * tb
     assert np.array_equal(gt0[2]["site_element"], ref_tiles[2]["site_element"])
     assert np.abs(gt0[2]["site_power"] - ref_tiles[2]["site_power"]).max() <= 1e-8 * np.abs(ref_tiles[2]["site_power"]).max()
+    # every rank generated, stored and streamed only its share of the tiles
+    tot = gt0[3]["xt_subblocks"]
+    assert tot == gt1[3]["xt_subblocks"] > 0 and gt0[3]["xt_local_subblocks"] + gt1[3]["xt_local_subblocks"] == tot
+    assert abs(gt0[3]["xt_local_subblocks"] - gt1[3]["xt_local_subblocks"]) <= 8 * 16          # balanced up to one work item
+    assert gt0[3]["comm_count_per_rank"] == gt0[3]["xt_ns"]                                     # |S| doubles per all-reduce
     nseg = got0[3]["spmv_segments"]
     assert got0[3]["comm_local_segments"] + got1[3]["comm_local_segments"] == nseg > 0      # the ranks split the segments
     assert abs(got0[3]["comm_local_segments"] - got1[3]["comm_local_segments"]) <= 64      # balanced up to one row
@@ -121,13 +128,12 @@ def test_rccl_transport_one_rank():
         lib.load().dkmc_comm_info(C.byref(n), C.byref(r), C.byref(t))
         assert (n.value, r.value, t.value) == (1, 0, 1)
         got = _supersteps(2)
-        got_t = _supersteps(1, tiles=1, big=True)             # all-reduce variant (ncclAllReduce in place), 85 k sites
+        got_t = _supersteps(1, fmt=1, big=True)               # all-reduce variant (ncclAllReduce in place), 85 k sites
     finally:
         parallel.detach_solver_comm()
-        lib.load().dkmc_set_symmetric_tiles(1)
-    ref_t = _supersteps(1, tiles=1, big=True)
-    lib.load().dkmc_set_symmetric_tiles(1)
+    ref_t = _supersteps(1, fmt=1, big=True)
     assert got_t[0] == ref_t[0] and got_t[3]["spmv_tiles"] > 0     # one rank: the all-reduce is the identity, same bits as without it
+    assert got_t[3]["xt_local_subblocks"] == got_t[3]["xt_subblocks"]
     assert got[0] == ref[0] and got[1] == ref[1]
     for name in ref[2]:
         assert np.array_equal(got[2][name], ref[2][name]), name

@@ -36,7 +36,11 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 
 struct __attribute__((aligned(16))) XTile { int k, w; unsigned mask; int soff; };   // cell (k, w); present sub-blocks; first sub-block slot
 struct __attribute__((aligned(32))) XItem { int t0, t1, w, c, k0; unsigned mask0; int soff0, pad; };   // tiles [t0, t1) of strip w; c = position of the run in its strip; descriptor of tile t0
-struct XCtrl { double rr[2]; double pad; int done; int iters; };
+struct XCtrl { double rr[2]; int done_local, sharded; int done; int iters; };
+// `done` gates every kernel of the loop.  Single GPU: set by the direction kernel.  Sharded solve: the direction kernel only sets
+// done_local; rank 0's done_local travels in the all-reduced buffer (slot ns) and k_xt_rows_apply turns it into `done` on every
+// rank in the same iteration -- all control flow derives from data every rank received from the same collective, so the ranks
+// cannot leave the loop at different iterations even if their arithmetic differed in a bit.
 
 struct SNodes {                      // S in rank order, padded to a multiple of XT_C (flag 0 = no entries)
     const double *x, *y, *z, *cb;
@@ -399,7 +403,7 @@ __global__ __launch_bounds__(XT_NT) void k_xt_rows(int ns, int nK, int nW, int n
                                                    const double *__restrict__ rowpart, const double *__restrict__ colpart,
                                                    const int *__restrict__ srow, const double *__restrict__ sS, const double *__restrict__ pvec,
                                                    double *__restrict__ t, double *__restrict__ part, const XCtrl *ctrl, double *__restrict__ xout,
-                                                   int m, const int *__restrict__ nsrank)
+                                                   int m, const int *__restrict__ nsrank, int flag_rank0)
 {
     __shared__ double red[XT_NT / 64];
     __shared__ double sl_sum[8][XT_R];
@@ -418,7 +422,10 @@ __global__ __launch_bounds__(XT_NT) void k_xt_rows(int ns, int nK, int nW, int n
             else { const int row = srow[s]; const double tv = sS[s] * (t[row] + sum); t[row] = tv; acc += pvec[row] * tv; }
         }
     }
-    if (MODE == 1) return;
+    if (MODE == 1) {
+        if (ctrl && blockIdx.x == 0 && threadIdx.x == 0) xout[ns] = (flag_rank0 && ctrl->done_local) ? 1.0 : 0.0;   // the stop decision rides in the all-reduce
+        return;
+    }
     // p.t over the non-S rows of this workgroup's share of the vector
     const int chunk = (m + (int)gridDim.x - 1) / (int)gridDim.x;
     const int i0 = blockIdx.x * chunk, i1 = min(m, i0 + chunk);
@@ -429,13 +436,13 @@ __global__ __launch_bounds__(XT_NT) void k_xt_rows(int ns, int nK, int nW, int n
 // sharded solve, after the all-reduce of xout: finish the S rows, then the same p.t partials as MODE 0
 __global__ __launch_bounds__(XT_NT) void k_xt_rows_apply(int ns, int nK, const double *__restrict__ xbuf, const int *__restrict__ srow,
                                                          const double *__restrict__ sS, const double *__restrict__ pvec, double *__restrict__ t,
-                                                         double *__restrict__ part, const XCtrl *ctrl, int m, const int *__restrict__ nsrank)
+                                                         double *__restrict__ part, XCtrl *ctrl, int m, const int *__restrict__ nsrank)
 {
     __shared__ double red[XT_NT / 64];
     __shared__ int sdone;
-    if (threadIdx.x == 0) sdone = ctrl->done;
+    if (threadIdx.x == 0) sdone = ctrl->done || xbuf[ns] != 0.0;     // xbuf[ns]: rank 0's stop decision, identical on every rank
     __syncthreads();
-    if (sdone) return;
+    if (sdone) { if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->done = 1; return; }
     double acc = 0.0;
     for (int k = blockIdx.x; k < nK; k += gridDim.x) {
         const int s = XT_R * k + (int)threadIdx.x;
@@ -502,7 +509,7 @@ __global__ __launch_bounds__(XT_NT) void k_xt_check0(const double *part, int npa
     double s = 0.0;
     for (int i = threadIdx.x; i < npart; i += XT_NT) s += part[i];
     const double rr = block_sum_all<XT_NT>(s, red);
-    if (threadIdx.x == 0) { ctrl->rr[0] = rr; ctrl->rr[1] = rr; ctrl->iters = 0; ctrl->done = !(sqrt(rr) > tol2); }
+    if (threadIdx.x == 0) { ctrl->rr[0] = rr; ctrl->rr[1] = rr; ctrl->iters = 0; const int d = !(sqrt(rr) > tol2); if (ctrl->sharded) ctrl->done_local = d; else ctrl->done = d; }
 }
 // alpha = rr / p.t ; y += alpha p ; r += alpha t ; partial r.r
 __global__ __launch_bounds__(XT_NT) void k_xt_update(int m, int it, const double *__restrict__ part_pt, int npart, const double *__restrict__ p,
@@ -545,7 +552,7 @@ __global__ __launch_bounds__(XT_NT) void k_xt_direction(int m, int it, const dou
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctrl->rr[(it + 1) & 1] = rr_new;
         ctrl->iters = it + 1;
-        if (!(rr_new > tol2)) ctrl->done = 1;
+        if (!(rr_new > tol2)) { if (ctrl->sharded) ctrl->done_local = 1; else ctrl->done = 1; }
     }
 }
 __global__ void k_xt_vec_mul(int m, double *__restrict__ y, const double *__restrict__ s)
@@ -634,7 +641,7 @@ static int xt_tile_sums(const double *vS, double *out, int vpos)
     hipLaunchKernelGGL((k_xt_rows<1>), dim3(xt_grid(X.nK, 1, 1024)), dim3(XT_NT), 0, st, X.ns, X.nK, X.nW, X.ns_pad, (const int2 *)g_xb.wrange,
                        (const int *)g_xb.nitem_w, (const double *)g_xb.rowpart, (const double *)g_xb.colpart, (const int *)nullptr,
                        (const double *)nullptr, (const double *)nullptr, (double *)nullptr, (double *)nullptr, (const XCtrl *)nullptr, out,
-                       0, (const int *)nullptr);
+                       0, (const int *)nullptr, 0);
     KCHK();
     if (comm_attached()) { int rc = comm_allreduce_sum_f64(out, (size_t)X.ns); if (rc) return rc; }
     return 0;
@@ -755,7 +762,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         } else { X.tile_lo = 0; X.tile_n = 0; X.sub_base = 0; X.sub_n = 0; }
     }
     e.stats.comm_ranks = sharded ? comm_nranks() : 0;
-    e.stats.comm_count_per_rank = sharded ? ns : 0;
+    e.stats.comm_count_per_rank = sharded ? ns + 1 : 0;
     e.stats.comm_local_segments = X.item_n;
 
     // ---- storage + fill ----
@@ -815,20 +822,20 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         if (sharded && ns > 0) {
             hipLaunchKernelGGL((k_xt_rows<1>), dim3(n2b), dim3(XT_NT), 0, st, ns, nK, nW, ns_pad, (const int2 *)wrange, (const int *)nitem_w, (const double *)rowpart,
                                (const double *)colpart, (const int *)srow, (const double *)sS, (const double *)p, t, part_pt, (const XCtrl *)ctrl, xbuf,
-                               m, (const int *)nsrank);
-            if (int rcx = comm_allreduce_sum_f64(xbuf, (size_t)ns)) return rcx;
+                               m, (const int *)nsrank, comm_rank() == 0 ? 1 : 0);
+            if (int rcx = comm_allreduce_sum_f64(xbuf, (size_t)ns + 1)) return rcx;          // |S| row sums + rank 0's stop decision
             if (ec) HIPCHK(hipEventRecord(ec, st));
             hipExtLaunchKernelGGL(k_xt_rows_apply, dim3(n2b), dim3(XT_NT), 0, st, e2, e3, 0, ns, nK, (const double *)xbuf, (const int *)srow, (const double *)sS,
-                                  (const double *)p, t, part_pt, (const XCtrl *)ctrl, m, (const int *)nsrank);
+                                  (const double *)p, t, part_pt, ctrl, m, (const int *)nsrank);
         } else
             hipExtLaunchKernelGGL((k_xt_rows<0>), dim3(n2b), dim3(XT_NT), 0, st, e2, e3, 0, ns, nK, nW, ns_pad, (const int2 *)wrange, (const int *)nitem_w,
                                   (const double *)rowpart, (const double *)colpart, (const int *)srow, (const double *)sS, (const double *)p, t,
-                                  part_pt, (const XCtrl *)ctrl, (double *)nullptr, m, (const int *)nsrank);
+                                  part_pt, (const XCtrl *)ctrl, (double *)nullptr, m, (const int *)nsrank, 0);
         return 0;
     };
 
     // ---- r = A y - b, p = -r ----
-    HIPCHK(hipMemsetAsync(ctrl, 0, sizeof(XCtrl), st));
+    { XCtrl c0{}; c0.sharded = (sharded && ns > 0) ? 1 : 0; HIPCHK(hipMemcpyAsync(ctrl, &c0, sizeof(XCtrl), hipMemcpyHostToDevice, st)); HIPCHK(hipStreamSynchronize(st)); }
     HIPCHK(hipMemsetAsync(p, 0, (size_t)m * 8, st));
     rc = matvec(nullptr, nullptr, nullptr, nullptr, nullptr); if (rc) return rc;
     hipLaunchKernelGGL(k_xt_resid_init, dim3(gv), dim3(XT_NT), 0, st, m, (const double *)t, (const double *)rhs, r, p, (const double *)sc, q, (const int *)nsrank, qS, part_rr);

@@ -676,6 +676,43 @@ long long okmc_x_pattern(int Na, int ann, const int *atom_neigh, const int *ael,
     return nnz;
 }
 
+/* off-diagonal entry between atoms a and b (populate_sparse_X_gpu2, iterative_solvers_gpu.cu:1616-1716): direct term for
+ * neighbours, WKB tunnelling term (window bound = N_full in the value kernel, :1630-1636) otherwise */
+static double x_offdiag_atom(int a, int b, const double *ax, const double *ay, const double *az, const int *ael, const int *aq,
+                             const double *acb, const double *lat, int pbc, double nn_dist, const int *metals, int nm, double tol,
+                             double high_G, double low_G, double m_e, double V0, int n_src, int n_gnd, int nlc, int N_full)
+{
+    double v = 0.0;
+    double dA = site_dist(ax[a], ay[a], az[a], ax[b], ay[b], az[b], lat, pbc);
+    int neighbor = dA < nn_dist;
+    if (!neighbor) {
+        int kind = tunnel_kind(a, b, ael, acb, metals, nm, nlc, n_src, n_gnd, N_full, tol);
+        if (kind) {
+            double drop = fabs(acb[a] - acb[b]);
+            double prefac = -(sqrt(2 * m_e) / H_BAR) * (2.0 / 3.0);
+            double dist = 1e-10 * dA;
+            if (kind == 1) {
+                double dE = Q_E * 0.01, T = 0.0;
+                for (double iv = 0; iv < drop; iv += dE) {
+                    double E1 = Q_E * V0 + iv, E2 = E1 - drop;
+                    if (E2 > 0) T += exp(prefac * (dist / drop) * (pow(E1, 1.5) - pow(E2, 1.5)));
+                    if (E2 < 0) T += exp(prefac * (dist / drop) * (pow(E1, 1.5)));
+                }
+                v = -T;
+            } else {
+                double E1 = Q_E * V0, E2 = E1 - drop;
+                if (E2 > 0) v = -exp(prefac * (dist / fabs(E1 - E2)) * (pow(E1, 1.5) - pow(E2, 1.5)));
+                if (E2 < 0) v = -exp(prefac * (dist / fabs(E1 - E2)) * (pow(E1, 1.5)));
+            }
+        }
+    } else {
+        int m1 = is_metal(ael[a], metals, nm), m2 = is_metal(ael[b], metals, nm);
+        int cv1 = (ael[a] == VACANCY) && (aq[a] == 0), cv2 = (ael[b] == VACANCY) && (aq[b] == 0);
+        v = ((m1 && m2) || (cv1 && cv2)) ? -high_G : -low_G;
+    }
+    return v;
+}
+
 /* X values: populate_sparse_X_gpu2 (iterative_solvers_gpu.cu:1525-1721) + calc_diagonal_X_gpu
  * (:2053-2076).  Positions are atom positions; data must hold nnz doubles. */
 void okmc_x_values(int Na, const double *ax, const double *ay, const double *az, const int *ael,
@@ -707,36 +744,8 @@ void okmc_x_values(int Na, const double *ax, const double *ay, const double *az,
                 }
                 if (c == 0 && i > N_full - n_gnd) v = -high_G;
                 if (c == 1 && i < n_src + 2) v = -high_G;
-                if (c >= 2 && c != i) {
-                    int b = c - 2;
-                    double dA = site_dist(ax[a], ay[a], az[a], ax[b], ay[b], az[b], lat, pbc);
-                    int neighbor = dA < nn_dist;
-                    if (!neighbor) {
-                        int kind = tunnel_kind(a, b, ael, acb, metals, nm, nlc, n_src, n_gnd, N_full, tol);
-                        if (kind) {
-                            double drop = fabs(acb[a] - acb[b]);
-                            double prefac = -(sqrt(2 * m_e) / H_BAR) * (2.0 / 3.0);
-                            double dist = 1e-10 * dA;
-                            if (kind == 1) {
-                                double dE = Q_E * 0.01, T = 0.0;
-                                for (double iv = 0; iv < drop; iv += dE) {
-                                    double E1 = Q_E * V0 + iv, E2 = E1 - drop;
-                                    if (E2 > 0) T += exp(prefac * (dist / drop) * (pow(E1, 1.5) - pow(E2, 1.5)));
-                                    if (E2 < 0) T += exp(prefac * (dist / drop) * (pow(E1, 1.5)));
-                                }
-                                v = -T;
-                            } else {
-                                double E1 = Q_E * V0, E2 = E1 - drop;
-                                if (E2 > 0) v = -exp(prefac * (dist / fabs(E1 - E2)) * (pow(E1, 1.5) - pow(E2, 1.5)));
-                                if (E2 < 0) v = -exp(prefac * (dist / fabs(E1 - E2)) * (pow(E1, 1.5)));
-                            }
-                        }
-                    } else {
-                        int m1 = is_metal(ael[a], metals, nm), m2 = is_metal(ael[b], metals, nm);
-                        int cv1 = (ael[a] == VACANCY) && (aq[a] == 0), cv2 = (ael[b] == VACANCY) && (aq[b] == 0);
-                        v = ((m1 && m2) || (cv1 && cv2)) ? -high_G : -low_G;
-                    }
-                }
+                if (c >= 2 && c != i)
+                    v = x_offdiag_atom(a, c - 2, ax, ay, az, ael, aq, acb, lat, pbc, nn_dist, metals, nm, tol, high_G, low_G, m_e, V0, n_src, n_gnd, nlc, N_full);
             }
             data[p] = v;
         }
@@ -816,6 +825,55 @@ double okmc_temperature_global(int N, const double *site_power, double T_bg, dou
     double c = b + P / C * small_step;
     int step = (int)number_steps;
     return c * (1.0 - pow(a, (double)step)) / (1.0 - a) + pow(a, (double)step) * T_bg;
+}
+
+/* Rows of X on the fly, no assembled matrix: for each listed ATOM row i (node index >= 2) out_diag[k] = X[i,i] and
+ * out_ax[k] = sum_c X[i,c] m[c], with the pattern rule of okmc_x_pattern (window bound = Na) and the entry values of
+ * okmc_x_values (x_offdiag_atom).  Lets a test check a solution of the full-size system -- where the assembled CSR does not fit
+ * int32 and the WKB integrals of every entry would take hours on the CPU -- on sampled rows. */
+void okmc_x_rows_apply(int Na, int ann, const int *atom_neigh, const double *ax, const double *ay, const double *az, const int *ael,
+                       const int *aq, const double *acb, const double *lat, int pbc, double nn_dist,
+                       const int *metals, int nm, double tol, double high_G, double low_G, double m_e, double V0,
+                       int n_src, int n_gnd, int nlc, int nrows, const int *rows, const double *m, double *out_diag, double *out_ax)
+{
+    int N_full = Na + 2;
+    int *S = (int *)malloc((size_t)Na * sizeof(int)); int ns = 0;
+    char *inS = (char *)calloc((size_t)Na, 1);
+    for (int a = 0; a < Na - 1; ++a) {
+        int mp = is_metal(ael[a], metals, nm) && (a > (nlc - 1) * n_src) && (a < Na - (nlc - 1) * n_gnd);
+        if (ael[a] == VACANCY || mp) { S[ns++] = a; inS[a] = 1; }
+    }
+    for (int k = 0; k < nrows; ++k) {
+        int i = rows[k], a = i - 2;
+        double off = 0.0, acc = 0.0;
+        if (i > N_full - n_gnd) { off += -high_G; acc += -high_G * m[0]; }
+        if (i < n_src + 2) { off += -high_G; acc += -high_G * m[1]; }
+        const int *nb = atom_neigh + (size_t)a * ann;
+        for (int s = 0; s < ann && nb[s] >= 0; ++s) {
+            int b = nb[s];
+            if (b >= Na - 1) continue;                               /* the ground atom is not a node */
+            double v = x_offdiag_atom(a, b, ax, ay, az, ael, aq, acb, lat, pbc, nn_dist, metals, nm, tol, high_G, low_G, m_e, V0, n_src, n_gnd, nlc, N_full);
+            off += v; acc += v * m[b + 2];
+        }
+        if (inS[a]) {
+            double off_t = 0.0, acc_t = 0.0;
+#pragma omp parallel for schedule(dynamic, 256) reduction(+ : off_t, acc_t)
+            for (int q = 0; q < ns; ++q) {
+                int b = S[q];
+                if (b == a) continue;
+                int is_nb = 0;
+                for (int s = 0; s < ann && nb[s] >= 0; ++s) if (nb[s] == b) { is_nb = 1; break; }
+                if (is_nb || !tunnel_kind(a, b, ael, acb, metals, nm, nlc, n_src, n_gnd, Na, tol)) continue;
+                double v = x_offdiag_atom(a, b, ax, ay, az, ael, aq, acb, lat, pbc, nn_dist, metals, nm, tol, high_G, low_G, m_e, V0, n_src, n_gnd, nlc, N_full);
+                off_t += v; acc_t += v * m[b + 2];
+            }
+            off += off_t; acc += acc_t;
+        }
+        double d = site_dist(ax[a], ay[a], az[a], ax[Na - 1], ay[Na - 1], az[Na - 1], lat, pbc) < nn_dist ? high_G : 0.0;
+        d += -off;
+        out_diag[k] = d; out_ax[k] = acc + d * m[i];
+    }
+    free(S); free(inS);
 }
 
 /* ------------------------------------------------------------------------- */

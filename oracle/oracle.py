@@ -262,6 +262,27 @@ class OracleKMC:
                         _p(rp), _p(ci), _p(data))
         return dict(Na=Na, atom_site=atom_site, ael=ael, row_ptr=rp[:Na + 2], col=ci, data=data)
 
+    def x_rows_apply(self, rows, m):
+        """(diag_i, (X m)_i) of the listed atom rows (node index >= 2) computed on the fly from the current state, without
+        assembling X (okmc_x_rows_apply): a full-size check of a solution on sampled rows."""
+        L = lib(); p = self.p
+        atom_site = np.empty(self.N, dtype=np.int32)
+        Na = L.okmc_compact_atoms(self.N, _p(self.element), _p(atom_site))
+        atom_site = atom_site[:Na].copy()
+        ax, ay, az = self.x[atom_site].copy(), self.y[atom_site].copy(), self.z[atom_site].copy()
+        ael = self.element[atom_site].copy(); aq = self.charge[atom_site].copy(); acb = self.CB_edge[atom_site].copy()
+        an = np.empty((Na, self.nn), dtype=np.int32)
+        L.okmc_atom_neighbors(self.N, self.nn, _p(self.neigh), Na, _p(atom_site), _p(an))
+        rows = _i32(rows); m = _f64(m)
+        assert rows.min() >= 2 and rows.max() <= Na
+        diag = np.empty(len(rows)); axm = np.empty(len(rows))
+        n = p.num_atoms_first_layer
+        L.okmc_x_rows_apply(Na, self.nn, _p(an), _p(ax), _p(ay), _p(az), _p(ael), _p(aq), _p(acb), _p(self.lattice), int(p.pbc),
+                            C.c_double(p.nn_dist), _p(self.metals), len(self.metals), C.c_double(p.X_tol), C.c_double(p.X_high_G),
+                            C.c_double(p.X_low_G), C.c_double(p.m_e), C.c_double(p.V0), n, n, p.num_layers_contact,
+                            len(rows), _p(rows), _p(m), _p(diag), _p(axm))
+        return diag, axm
+
     def update_power(self, Vd, tol=None, heating=None):
         L = lib(); p = self.p
         tol = p.cg_tol if tol is None else tol

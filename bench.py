@@ -261,6 +261,52 @@ def cpu_superstep_baseline(s, p, ncores):
             "ms_per_step": round(tc * 1e3, 1), "split_ms": {k: round(v * 1e3, 2) for k, v in o.timing.items()}}
 
 
+def pmc_traffic(workload, kernel_prefix, x_format):
+    """HBM bytes per launch of the dominant kernel from the PMC counters, measured in this run: two rocprofv3 child runs of this
+    script on the same workload (one step), `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes with the kernel trace only
+    (MI355X_MICROARCH.md, HBM / rocprofv3 sections); median over the kernel's working launches (the no-op launches behind the
+    last iteration of a batch fetch next to nothing); gfx950 correction: FETCH_SIZE counts half of a wide coalesced streaming
+    read, so bytes = (2 FETCH_SIZE + WRITE_SIZE) x 1024.  Returns (bytes or None, detail)."""
+    import csv
+    import glob
+    import shutil
+    import statistics
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, {"error": "rocprofv3 not found"}
+    med = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="dkmc_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
+               sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+               "--scale-points", "none", "--no-alt", "--no-pmc", "--x-format", str(x_format)]
+        try:
+            subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True,
+                           cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for r in csv.DictReader(fh):
+                        if r["Counter_Name"] == counter and kernel_prefix in r["Kernel_Name"]:
+                            vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, {"error": "no %s samples of %s" % (counter, kernel_prefix)}
+            top = max(vals)
+            work = [v for v in vals if v > 0.5 * top] if counter == "FETCH_SIZE" else vals
+            med[counter] = (statistics.median(work), len(work))
+        except Exception as exc:
+            return None, {"error": repr(exc)[:200]}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    if med["WRITE_SIZE"][1] != med["FETCH_SIZE"][1]:      # same launches in both passes: take the working ones of the write pass by rank
+        pass
+    b = (2.0 * med["FETCH_SIZE"][0] + med["WRITE_SIZE"][0]) * 1024.0
+    return b, {"FETCH_SIZE_KB_median": med["FETCH_SIZE"][0], "WRITE_SIZE_KB_median": med["WRITE_SIZE"][0], "launches": med["FETCH_SIZE"][1],
+               "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024, separate --pmc passes"}
+
+
 def arm_watchdog(seconds, rank, what):
     """A rank stuck in a collective cannot be unwound: report and leave with a non-zero exit code."""
     def fire():
@@ -287,6 +333,7 @@ def main():
     ap.add_argument("--scale-points", default=None, help="N = 1: comma list of extra workloads measured in the same run (default tile:5,tile:10; 'none')")
     ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the replicas block")
     ap.add_argument("--no-alt", action="store_true", help="skip the alt_warm_start block")
+    ap.add_argument("--no-pmc", action="store_true", help="N = 1: do not measure roofline.traffic (two rocprofv3 --pmc child runs)")
     ap.add_argument("--budget", type=float, default=420.0, help="time budget [s] for the timed steps of seconds-per-step workloads")
     ap.add_argument("--timeout", type=float, default=900.0, help="watchdog [s]: exit 3 if the run has not finished")
     args = ap.parse_args()
@@ -338,6 +385,13 @@ def main():
             out["steps_requested"] = args.steps
         out.update(roofs)
         sim.close()
+        # ---- roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC counters, measured now ----
+        if not args.no_pmc and "roofline" in out:
+            tb, detail = pmc_traffic(name, out["roofline"]["kernel"], args.x_format)
+            out["roofline"]["traffic"] = tb
+            out["roofline"]["traffic_detail"] = detail
+            if tb:
+                out["roofline"]["traffic_over_algorithmic"] = round(tb / out["roofline"]["algorithmic_bytes_per_launch"], 3)
         # ---- scale points: the larger stacks of BASELINE.json's configs, measured in the same run ----
         sp_names = (args.scale_points if args.scale_points is not None else ("tile:5,tile:10" if args.workload is None else "none"))
         points = {}

@@ -631,13 +631,6 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
     int it = 0, launched = 0;
     int batch = 8;
     if (iter_hint && *iter_hint > 24) batch = *iter_hint - 8;
-    // K solves (uniform rows), profiling on: one pair of events around the whole iteration loop
-    static hipEvent_t evk[2]; static bool evk_ready = false;
-    const bool prof_k = e.profiling && uniform_rows;
-    if (prof_k) {
-        if (!evk_ready) { HIPCHK(hipEventCreate(&evk[0])); HIPCHK(hipEventCreate(&evk[1])); evk_ready = true; }
-        HIPCHK(hipEventRecord(evk[0], st));
-    }
     // matrix stream: default cache policy while the values of one sweep fit the 256 MiB Infinity Cache (they are re-read
     // every iteration), non-temporal beyond that (measured: 45 vs 53 us at 240 MB, 478 vs 456 us at 1.86 GB); a rank of a
     // sharded solve streams only its share
@@ -699,13 +692,6 @@ static int cg_solve_jacobi_t(double *a, const RP *rp, const int *ci, long long n
         else if (batch < 64) batch *= 2;
     }
 #undef SPMV
-    if (prof_k) {
-        HIPCHK(hipEventRecord(evk[1], st));
-        HIPCHK(hipEventSynchronize(evk[1]));
-        float ms = 0.f;
-        HIPCHK(hipEventElapsedTime(&ms, evk[0], evk[1]));
-        e.stats.kcg_ms = ms; e.stats.kcg_iters_timed = h.iters;
-    } else if (uniform_rows) { e.stats.kcg_ms = 0.0; e.stats.kcg_iters_timed = 0; }
     if (prof) {
         e.stats.spmv_long_ms = prof_long_ms; e.stats.spmv_short_ms = prof_short_ms;
         e.stats.spmv_long_launches = prof_long_n; e.stats.spmv_short_launches = prof_short_n;

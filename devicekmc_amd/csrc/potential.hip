@@ -3,8 +3,9 @@
 // builders of iterative_solvers_gpu.cu.
 #include "common.h"
 
-int cg_solve_jacobi(double *a, const int *rp, const int *ci, int nnz, int m, double *x, double *y,
-                    int uniform_rows, const int *srank, int ns, int *iters_out, double *rr_out);
+int kcg_assemble_and_solve(int cb, int m, int N_left, const int *element, const int *charge, MetalSet ms, double high_G, double low_G,
+                           const int *rp, const int *ci, int nnz, const int *lrp, const int *lci, const int *rrp, const int *rci,
+                           double VL, double VR, double *y, int *iters_out, double *rr_out);
 void tcache_invalidate();
 
 // ------------------------------------------------------------------------------------------------
@@ -137,56 +138,7 @@ extern "C" int dkmc_initialize_sparsity(dkmc_gpubuf *buf, int pbc, double nn_dis
     return 0;
 }
 
-// ------------------------------------------------------------------------------------------------
-// K values + rhs in one pass (Assemble_A / Assemble_A_CB + calc_rhs_for_A,
-// potential_solver_gpu.cu:187-593).  16 lanes per row; the 6 reference kernels (off-diagonals,
-// reduce_rows_into_diag, 2x contact row reductions, 2x add_vector_to_diagonal) and the rhs kernel
-// collapse into this one.
-template <int CB>
-__device__ __forceinline__ double k_cond(int ei, int ej, int qi, int qj, const MetalSet &ms, double high_G, double low_G)
-{
-    const bool m1 = is_metal(ei, ms), m2 = is_metal(ej, ms);
-    if (CB) return (m1 || m2) ? high_G : low_G;                         // :239-249
-    const bool cv1 = (ei == VACANCY) && (qi == 0), cv2 = (ej == VACANCY) && (qj == 0);
-    return ((m1 && m2) || (cv1 && cv2)) ? high_G : low_G;               // :202-217
-}
-
-template <int CB>
-__global__ __launch_bounds__(256) void k_assemble_K(int m, int N_left, const int *__restrict__ element, const int *__restrict__ charge,
-                                                    MetalSet ms, double high_G, double low_G,
-                                                    const int *__restrict__ rp, const int *__restrict__ ci,
-                                                    const int *__restrict__ lrp, const int *__restrict__ lci,
-                                                    const int *__restrict__ rrp, const int *__restrict__ rci,
-                                                    double VL, double VR,
-                                                    double *__restrict__ data, double *__restrict__ rhs)
-{
-    const int LPR = 16;
-    const int g = threadIdx.x / LPR, l = threadIdx.x % LPR;
-    const int r = blockIdx.x * (256 / LPR) + g;
-    if (r >= m) return;
-    const int i = N_left + r;
-    const int ei = element[i], qi = charge[i];
-    double off = 0.0, kl = 0.0, kr = 0.0;
-    int dpos = -1;                                   // position of the diagonal entry (exactly one lane meets it)
-    for (int p = rp[r] + l; p < rp[r + 1]; p += LPR) {
-        const int c = ci[p];
-        if (c == r) { dpos = p; continue; }
-        const int j = N_left + c;
-        const double gg = k_cond<CB>(ei, element[j], qi, charge[j], ms, high_G, low_G);
-        data[p] = -gg;
-        off += gg;
-    }
-    for (int p = lrp[r] + l; p < lrp[r + 1]; p += LPR) { const int j = lci[p]; kl += k_cond<CB>(ei, element[j], qi, charge[j], ms, high_G, low_G); }
-    for (int p = rrp[r] + l; p < rrp[r + 1]; p += LPR) { const int j = N_left + m + rci[p]; kr += k_cond<CB>(ei, element[j], qi, charge[j], ms, high_G, low_G); }
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) { off += __shfl_xor(off, o, LPR); kl += __shfl_xor(kl, o, LPR); kr += __shfl_xor(kr, o, LPR); }
-    double d = off;          // reduce_rows_into_diag: -(sum of off-diagonals)
-    d += kl;                 // add_vector_to_diagonal (left)
-    d += kr;                 // add_vector_to_diagonal (right)
-    if (dpos >= 0) data[dpos] = d;
-    if (l == 0) rhs[r] = kl * VL + kr * VR;
-}
-
+// K values, rhs and the solve: kcg.hip (the off-diagonals of K take two values: the matrix is kept as class bits)
 __global__ void k_fill_contacts(double *field, int N, int N_left, int N_right, double vl, double vr, double scale_all)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -205,21 +157,11 @@ static int solve_K(dkmc_gpubuf *buf, int N, int N_left, int N_right, double VL, 
         return dkmc_fail(6, "K sparsity not initialised (call initialize_sparsity)", __FILE__, __LINE__);
     if (N_left != N_right || !kpat_matches(buf->Device_row_ptr_d, m, N_left))
         return dkmc_fail(6, "K sparsity was built for other contact sizes than this solve asks for", __FILE__, __LINE__);
-    double *data = (double *)scratch(S_K_DATA, (size_t)buf->Device_nnz * 8);
-    double *rhs = (double *)scratch(S_K_RHS, (size_t)m * 8);
-    if (!data || !rhs) return e.err_code;
     MetalSet ms = load_metals(buf->metal_types, num_metals);
-    const int blocks = (m + 15) / 16;
-    if (cb) hipLaunchKernelGGL((k_assemble_K<1>), dim3(blocks), dim3(256), 0, st, m, N_left, buf->site_element, buf->site_charge, ms,
-                               high_G, low_G, buf->Device_row_ptr_d, buf->Device_col_indices_d, buf->contact_left_row_ptr,
-                               buf->contact_left_col_indices, buf->contact_right_row_ptr, buf->contact_right_col_indices,
-                               VL, VR, data, rhs);
-    else hipLaunchKernelGGL((k_assemble_K<0>), dim3(blocks), dim3(256), 0, st, m, N_left, buf->site_element, buf->site_charge, ms,
-                            high_G, low_G, buf->Device_row_ptr_d, buf->Device_col_indices_d, buf->contact_left_row_ptr,
-                            buf->contact_left_col_indices, buf->contact_right_row_ptr, buf->contact_right_col_indices,
-                            VL, VR, data, rhs);
-    KCHK();
-    return cg_solve_jacobi(data, buf->Device_row_ptr_d, buf->Device_col_indices_d, buf->Device_nnz, m, rhs, field + N_left, 1, nullptr, 0, iters, rr);
+    (void)e; (void)st;
+    return kcg_assemble_and_solve(cb, m, N_left, buf->site_element, buf->site_charge, ms, high_G, low_G, buf->Device_row_ptr_d, buf->Device_col_indices_d,
+                                  buf->Device_nnz, buf->contact_left_row_ptr, buf->contact_left_col_indices, buf->contact_right_row_ptr,
+                                  buf->contact_right_col_indices, VL, VR, field + N_left, iters, rr);
 }
 
 // background_potential_gpu_sparse (potential_solver_gpu.cu:696-781)

@@ -277,11 +277,12 @@ def test_pbc_fields(cell_2p5, hip):
 
 
 def test_kmc_time_vs_reference_cuda_log_7p5(dev_7p5, hip, ref_logs):
-    """configs[1]: 85 071 sites.  KMC time of the first supersteps against the reference's own CUDA-path log, and the
-    same event sequence as the oracle."""
+    """configs[1]: 85 071 sites.  KMC time of all 19 logged supersteps against the reference's own CUDA-path log, and the same
+    event sequence as the oracle.  CG tolerance 1e-12 = the tolerance the log was produced with ("used to be 1e-12",
+    iterative_solvers_gpu.cu:322; tests/test_oracle_golden.py::test_cuda_path_log_7p5nm): the log's 6 printed digits are met."""
     host, L = hip
     gold = ref_logs["timing_7.5nm/output_noguess.txt"]["steps"]
-    p = params_7p5(); p.cg_tol = 1e-9; p.solve_current = False
+    p = params_7p5(); p.cg_tol = 1e-12; p.solve_current = False
     dev, sim, gb, o = make_pair(dev_7p5, p, hip)
     t = 0.0
     for k in range(3):
@@ -289,19 +290,20 @@ def test_kmc_time_vs_reference_cuda_log_7p5(dev_7p5, hip, ref_logs):
         _, dt = sim.executeKMCStep(gb, dev, want_log=True); t += dt
         out = o.superstep(Vd)
         assert np.array_equal(sim.last_event_log, o.last_events["log"]), k
-        assert abs(t / gold[k]["KMC time"] - 1) < 3e-4, (k, t, gold[k])
+        assert abs(t / gold[k]["KMC time"] - 1) < 1e-5, (k, t, gold[k])
         pb = get(gb, "site_potential_boundary")
         assert np.abs(pb - o.pot_boundary).max() <= 1e-6 * Vd
     # the remaining 16 logged supersteps, HIP path alone against the reference's log
     for k in range(3, len(gold)):
         dev.updateCharge(gb); dev.updatePotential(gb, p, Vd, k)
         _, dt = sim.executeKMCStep(gb, dev); t += dt
-        assert abs(t / gold[k]["KMC time"] - 1) < 3e-4, (k, t, gold[k])
+        assert abs(t / gold[k]["KMC time"] - 1) < 1e-5, (k, t, gold[k])
 
 
 def test_current_7p5_properties(dev_7p5, hip):
-    """Full-size current solve: pattern identical to the oracle's, X symmetric, I_macro close to the oracle's and
-    within 1 % of the reference CUDA log (11.8834 uA; unexplained 0.8 % offset of the logged revision)."""
+    """Full-size current solve: pattern identical to the oracle's, X symmetric, I_macro equal to the oracle's, and 0.83 % below the
+    one current value the reference's CUDA log holds (11.8834 uA): the gap of the logged revision, independent of the CG tolerance
+    and not explained by the 0.01 eV threshold (tests/test_oracle_golden.py::test_current_7p5nm_vs_log, DESIGN.md section 2)."""
     host, L = hip
     p = params_7p5(); p.cg_tol = 1e-8
     dev, sim, gb, o = make_pair(dev_7p5, p, hip)
@@ -314,7 +316,7 @@ def test_current_7p5_properties(dev_7p5, hip):
     rp, ci, data = host.get_last_X()
     assert np.array_equal(rp, o.last_X["row_ptr"]) and np.array_equal(ci, o.last_X["col"])
     assert abs(dev.imacro / oi - 1) <= 1e-5
-    assert abs(dev.imacro * 1e6 / 11.8834 - 1) < 0.01
+    assert -8.5e-3 < dev.imacro * 1e6 / 11.8834 - 1 < -8.1e-3
     import scipy.sparse as sp
     A = sp.csr_matrix((data, ci, rp))
     assert abs(A - A.T).max() <= 1e-12 * np.abs(data).max()
@@ -674,12 +676,14 @@ def test_supersteps_tiled_structure(cell_2p5, hip):
     """37 596 sites (the 2.5 nm cell tiled 2 x 2 laterally): a tunnelling block of a few hundred tiles, small enough for the CPU
     oracle.  Three full supersteps with global heating: the tile layout is rebuilt every step as the vacancies
     move; events identical to the oracle's, KMC time / current / temperature within the tolerances of the other superstep tests
-    (both solves converged to a scaled residual of 1e-9)."""
+    (both solves converged to a scaled residual of 1e-12)."""
     from devicekmc_amd import params as pm
     from devicekmc_amd import structure
     host, L = hip
     s = structure.tile_structure(cell_2p5, 2, 25.575, 25.575, 1440)
-    p = pm.KMCParameters().for_tiling(2); p.solve_heating_global = True; p.cg_tol = 1e-9
+    # converged solves (1e-12): at a looser tolerance the comparison would measure whether two implementations stop on the same
+    # iterate (cond(K) ~ 1e8: at 1e-9 the KMC time of neighbouring iterates still differs by 1e-3), not whether they solve the same system
+    p = pm.KMCParameters().for_tiling(2); p.solve_heating_global = True; p.cg_tol = 1e-12
     dev, sim, gb, o = make_pair(s, p, hip)
     for k in range(3):
         dev.updateCharge(gb); dev.updatePotential(gb, p, Vd, k)

@@ -74,17 +74,35 @@ def test_x_pattern_vs_reference_dump(cell_2p5, golden_dir):
 
 
 def test_cuda_path_log_7p5nm(dev_7p5, ref_logs):
-    """KMC time of the reference's CUDA-path log (85 071 sites).  The log itself carries the error of a CG stopped
-    at 1e-6, so agreement is ~1e-4 relative with a converged solve."""
+    """KMC time of the reference's CUDA-path log (85 071 sites), potential + event path.  With the CG tolerance the reference
+    used before it was relaxed to 1e-6 ("used to be 1e-12", iterative_solvers_gpu.cu:322) the oracle reproduces every printed
+    digit of the log; at 1e-9 it agrees to 1e-4, at 1e-6 to 4.5 % (tools/pin_current.py): the log was produced at 1e-12."""
     gold = ref_logs["timing_7.5nm/output_noguess.txt"]["steps"]
-    p = params_7p5(); p.cg_tol = 1e-9; p.solve_current = False
+    p = params_7p5(); p.cg_tol = 1e-12; p.solve_current = False
     o = oc.OracleKMC(dev_7p5.element, dev_7p5.x, dev_7p5.y, dev_7p5.z, p)
     assert o.N == 85071 and o.nn == 52 and int((o.element == pm.VACANCY).sum()) == 900
     t = 0.0
-    for k in range(3):
+    for k in range(4):
         t += o.superstep(5.0)["step_time"]
-        assert abs(t / gold[k]["KMC time"] - 1) < 3e-4, (k, t, gold[k])
+        assert abs(t / gold[k]["KMC time"] - 1) < 5e-6, (k, t, gold[k])      # 6 printed digits
         assert o.last_events["margin"].min() > 1e-9      # no draw within rounding distance of a bucket edge
+
+
+def test_current_7p5nm_vs_log(dev_7p5, ref_logs):
+    """The one current value the reference holds for its CUDA path (timing_7.5nm/output_noguess.txt: 11.8834 uA at step 0) against
+    the oracle at the reference's current tolerance 1e-6.  The oracle's current is 0.83 % LOWER, and stays there at 1e-9 and 1e-12
+    (11.78455 / 11.78485 / 11.78485 uA, tools/pin_current.py), while the potential/event path matches the log to 6 digits.  The
+    0.01 eV threshold of the tunnelling rule (iterative_solvers_gpu.cu:903-908) is not the cause: between 1e-6 and 1e-12 the CB edge
+    moves by <= 5.6e-4 eV, 16 of 3.06e7 entries flip and the current moves by 3e-5 relative.  The gap is a property of the code
+    revision that wrote the log; this test pins the oracle's value and the size of the gap."""
+    gold = ref_logs["timing_7.5nm/output_noguess.txt"]["steps"][0]
+    p = params_7p5(); p.cg_tol = 1e-6
+    o = oc.OracleKMC(dev_7p5.element, dev_7p5.x, dev_7p5.y, dev_7p5.z, p)
+    o.set_laplace_potential(5.0); o.update_charge(); o.update_potential(5.0); o.execute_kmc_step()
+    im = o.update_power(5.0, heating=False) * 1e6
+    assert o.stats["X_nnz"] == 30605018
+    assert abs(im / 11.78455 - 1) < 2e-6
+    assert -8.5e-3 < im / gold["Current [uA]"] - 1 < -8.1e-3
 
 
 def test_cuda_path_log_crossbar(ref_logs, golden_dir):

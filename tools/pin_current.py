@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""CPU experiment behind DESIGN.md section 2 (pin of the current solve): the oracle on the reference's 85 071-site device at several
+CG tolerances, against the reference's own CUDA-path log (timing_7.5nm/output_noguess.txt: KMC time 2.05754e-14 s, Current 11.8834 uA
+at step 0).  Also: how many tunnelling pairs sit within the CB-edge solve's error band of the 0.01 eV threshold
+(iterative_solvers_gpu.cu:903-908), and what the current becomes when those pairs flip.
+usage: OMP_NUM_THREADS=8 python tools/pin_current.py [tol ...]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from devicekmc_amd import params, structure  # noqa: E402
+from oracle import oracle as oc  # noqa: E402
+
+g = os.path.join(ROOT, "tests", "golden")
+s = structure.load_structure(os.path.join(g, "device_7.5nm.npz"))
+gold = json.load(open(os.path.join(g, "reference_logs.json")))["timing_7.5nm/output_noguess.txt"]["steps"][0]
+tols = [float(t) for t in sys.argv[1:]] or [1e-6, 1e-9, 1e-12]
+cb = {}
+for tol in tols:
+    p = params.KMCParameters(rnd_seed=5, lattice=tuple(s.meta["lattice"]), num_atoms_first_layer=1296, num_atoms_contact=12960,
+                             A=76.725e-10 * 76.725e-10)
+    p.cg_tol = tol
+    o = oc.OracleKMC(s.element, s.x, s.y, s.z, p)
+    t0 = time.time()
+    itcb = o.set_laplace_potential(5.0)
+    cb[tol] = o.CB_edge.copy()
+    o.update_charge(); itk = o.update_potential(5.0)
+    dt = o.execute_kmc_step()
+    im = o.update_power(5.0, heating=False)
+    print("tol %.0e: CB iters %d, K iters %d, X iters %d | KMC time %.6e (log %.6e, rel %+.2e) | Current %.5f uA (log %.4f, rel %+.2e) | X nnz %d  [%.0f s]"
+          % (tol, itcb, itk, o.stats["cg_iters_X"], dt, gold["KMC time"], dt / gold["KMC time"] - 1, im * 1e6, gold["Current [uA]"],
+             im * 1e6 / gold["Current [uA]"] - 1, o.stats["X_nnz"], time.time() - t0), flush=True)
+if len(cb) > 1:
+    ref = cb[min(cb)]
+    for tol in sorted(cb, reverse=True)[:-1]:
+        d = np.abs(cb[tol] - ref) / 1.60217663e-19
+        print("CB edge at tol %.0e vs %.0e: max |diff| %.3e eV (threshold 0.01 eV)" % (tol, min(cb), d.max()))

@@ -199,9 +199,9 @@ extern "C" int dkmc_update_CB_edge_gpu_sparse(dkmc_gpubuf *buf, int N, int N_lef
 // poisson_gridless (potential_solver_gpu.cu:908-978).  The reference launches N x ceil(N/512)
 // blocks (N^2 threads), though only columns with a non-zero charge contribute, and combines block
 // sums with atomicAdd in arrival order.  Here: (1) the charged sites are compacted, in ascending
-// site order, into a packed {x,y,z,q,idx} list; (2) each thread owns one site and sweeps the list
-// through an LDS tile, accumulating in list order -- the sequential order of the host twin
-// (potential_solver.cpp:412-432), no atomics, no memset.
+// site order, into a packed {x,y,z,q,idx} list; (2) a workgroup owns 64 sites and sweeps the list
+// through LDS tiles, its four waves taking every fourth list entry; fixed summation order (eight
+// interleaved partial sums per site, combined in a fixed tree), no atomics, no memset.
 struct __attribute__((aligned(32))) ChargedSite { double x, y, z; int q, idx; };
 
 __global__ void k_charge_flags(int N, const int *charge, int *flag)
@@ -218,6 +218,11 @@ __global__ void k_charge_scatter(int N, const int *__restrict__ charge, const in
 }
 
 #define PW_NT 256
+#define PW_SITES 64             // sites per workgroup: one per lane; the four waves split the charged list
+// Each workgroup owns 64 sites; wave w adds the charged sites c = w, w + 4, ... of every LDS tile (all lanes of a wave read the
+// same list entry: an LDS broadcast), two independent accumulators per lane; the four partial sums of a site are combined in a
+// fixed order.  Four times the waves of a thread-per-site launch (85 k sites: 21 waves per CU instead of 5) and twice the
+// independent erfc / sqrt / divide chains per lane.
 __global__ __launch_bounds__(PW_NT) void k_pairwise(int N, const double *__restrict__ x, const double *__restrict__ y,
                                                     const double *__restrict__ z, const double *__restrict__ lattice, int pbc,
                                                     const double *__restrict__ sigma_p, const double *__restrict__ k_p,
@@ -225,26 +230,35 @@ __global__ __launch_bounds__(PW_NT) void k_pairwise(int N, const double *__restr
                                                     double *__restrict__ out)
 {
     __shared__ ChargedSite tile[PW_NT];
-    const int i = blockIdx.x * PW_NT + threadIdx.x;
+    __shared__ double partial[PW_NT / 64][PW_SITES];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = blockIdx.x * PW_SITES + lane;
     const int nc = *ncharged;
     const double sigma = *sigma_p, kk = *k_p, laty = lattice[1], latz = lattice[2];
     const double xi = i < N ? x[i] : 0.0, yi = i < N ? y[i] : 0.0, zi = i < N ? z[i] : 0.0;
-    double v = 0.0;
+    double v0 = 0.0, v1 = 0.0;
     for (int base = 0; base < nc; base += PW_NT) {
         const int n = min(PW_NT, nc - base);
         __syncthreads();
         if (threadIdx.x < n) tile[threadIdx.x] = list[base + threadIdx.x];
         __syncthreads();
-        if (i < N) {
-            for (int c = 0; c < n; ++c) {
-                const ChargedSite cs = tile[c];
-                if (cs.idx == i) continue;
-                const double r = 1e-10 * site_dist(xi, yi, zi, cs.x, cs.y, cs.z, laty, latz, pbc);
-                v += v_solve(r, cs.q, sigma, kk);
-            }
+        int c = w;
+        for (; c + 4 < n; c += 8) {
+            const ChargedSite a = tile[c], b = tile[c + 4];
+            const double ra = 1e-10 * site_dist(xi, yi, zi, a.x, a.y, a.z, laty, latz, pbc);
+            const double rb = 1e-10 * site_dist(xi, yi, zi, b.x, b.y, b.z, laty, latz, pbc);
+            if (a.idx != i) v0 += v_solve(ra, a.q, sigma, kk);
+            if (b.idx != i) v1 += v_solve(rb, b.q, sigma, kk);
+        }
+        if (c < n) {
+            const ChargedSite a = tile[c];
+            const double ra = 1e-10 * site_dist(xi, yi, zi, a.x, a.y, a.z, laty, latz, pbc);
+            if (a.idx != i) v0 += v_solve(ra, a.q, sigma, kk);
         }
     }
-    if (i < N) out[i] = v;
+    partial[w][lane] = v0 + v1;
+    __syncthreads();
+    if (w == 0 && i < N) out[i] = (partial[0][lane] + partial[1][lane]) + (partial[2][lane] + partial[3][lane]);
 }
 
 extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, const double *lattice, const double *sigma,
@@ -266,7 +280,7 @@ extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, 
         if (!evp_ready) { HIPCHK(hipEventCreate(&evp[0])); HIPCHK(hipEventCreate(&evp[1])); evp_ready = true; }
         HIPCHK(hipEventRecord(evp[0], st));
     }
-    hipLaunchKernelGGL(k_pairwise, dim3((N + PW_NT - 1) / PW_NT), dim3(PW_NT), 0, st, N, x, y, z, lattice, pbc, sigma, k, list, cnt, out);
+    hipLaunchKernelGGL(k_pairwise, dim3((N + PW_SITES - 1) / PW_SITES), dim3(PW_NT), 0, st, N, x, y, z, lattice, pbc, sigma, k, list, cnt, out);
     KCHK();
     e.stats.pair_ms = 0.0;
     if (e.profiling) {

@@ -298,6 +298,46 @@ class KMCProcess:
         return {"Z - calculation time - kmc events [s]": time.perf_counter() - t0}, et.value
 
 
+def save_restart(path, device: Device, sim: KMCProcess, gpubuf: GPUBuffers, kmc_time=0.0, kmc_step_count=0):
+    """Device::writeSnapshot (Device.cpp:236-252) + the state it drops (io.write_restart): after load_restart the run continues with
+    the same event sequence, bit for bit."""
+    from . import io
+    gpubuf.sync_GPUToHost(device)
+    state = dict(site_charge=device.site_charge, site_potential_boundary=device.site_potential_boundary,
+                 site_potential_charge=device.site_potential_charge, site_power=device.site_power,
+                 site_temperature=device.site_temperature, site_CB_edge=device.site_CB_edge,
+                 atom_virtual_potentials=gpubuf.atom_virtual_potentials.cpu().numpy(),
+                 T_bg=float(device.T_bg), kmc_time=float(kmc_time), kmc_step_count=int(kmc_step_count),
+                 rnd_seed_kmc=int(sim.random_generator.seed), kmc_rng_raw_draws=int(sim.random_generator.n_raw))
+    io.write_restart(path, device.site_element, device.site_x, device.site_y, device.site_z, state)
+
+
+def load_restart(path, p: KMCParameters, device="cuda:0", gpu_neighbors=None):
+    """kmc_main.cpp:65-80 (restart = 1: the snapshot is the site list, no substoichiometry pass) + the sidecar state.
+    Returns (Device, KMCProcess, GPUBuffers, state)."""
+    import copy as _copy
+    from . import io
+    s, state = io.read_restart(path)
+    p = _copy.copy(p); p.pristine = False
+    dev = Device(s, p, gpu_neighbors=gpu_neighbors)
+    sim = KMCProcess(dev, p.freq)
+    gb = dev.make_gpubuf(device)
+    if state is not None:
+        dev.site_charge = np.asarray(state["site_charge"], dtype=np.int32)
+        dev.site_potential_boundary = np.asarray(state["site_potential_boundary"], dtype=np.float64)
+        dev.site_potential_charge = np.asarray(state["site_potential_charge"], dtype=np.float64)
+        dev.site_power = np.asarray(state["site_power"], dtype=np.float64)
+        dev.site_temperature = np.asarray(state["site_temperature"], dtype=np.float64)
+        dev.site_CB_edge = np.asarray(state["site_CB_edge"], dtype=np.float64)
+        dev.T_bg = float(state["T_bg"])
+        gb.sync_HostToGPU(dev)
+        m = np.asarray(state["atom_virtual_potentials"], dtype=np.float64)
+        n = min(len(m), gb.atom_virtual_potentials.numel())
+        gb.atom_virtual_potentials[:n].copy_(torch.as_tensor(m[:n]))
+        sim.random_generator = StdMT19937.at_position(int(state["rnd_seed_kmc"]), int(state["kmc_rng_raw_draws"]))
+    return dev, sim, gb, state
+
+
 def get_stats():
     s = _lib.load().dkmc_get_stats().contents
     return {f[0]: getattr(s, f[0]) for f in s._fields_}

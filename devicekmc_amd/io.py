@@ -4,6 +4,10 @@
   ``element   x   y   z   potential   power`` with iostream's default 6 significant digits; ``restart = 1`` reloads such a
   file as the site list through ``read_xyz`` (utils.cpp:72-98, kmc_main.cpp:65-80: only element and xyz are read back).
   ``write_snapshot(..., full_precision=True)`` keeps 17 digits so that a restart reproduces the coordinates bit for bit.
+* Restart state: the reference's restart drops everything but element and position, so a restarted run
+  cannot continue the same event sequence.  ``write_restart`` / ``read_restart`` keep the snapshot in the reference's own xyz
+  format (17 digits) and put what it drops into a sidecar ``<snapshot>.state.npz``: site_charge, both potentials, power,
+  temperature, the warm-start vector of the current solve, T_bg, the KMC time and the position of the KMC random stream.
 * Step log: the ``output.txt`` block per superstep (kmc_main.cpp:177-278): ``KMC step count``, ``V_vcm``, ``KMC time is``,
   then the result map in key order (std::map), so the reference's timing_boxplot.py / plotting scripts can read it.
 """
@@ -42,6 +46,30 @@ def read_xyz(path) -> Structure:
             el[i] = _NAME_TO_ELEMENT[t[0]]
             xyz[i] = (float(t[1]), float(t[2]), float(t[3]))
     return Structure(el, xyz[:, 0].copy(), xyz[:, 1].copy(), xyz[:, 2].copy(), {})
+
+
+def write_restart(path, element, x, y, z, state):
+    """Snapshot in the reference's xyz format (full precision) + sidecar with the state the format drops.
+    state: dict with site_charge, site_potential_boundary, site_potential_charge, site_power, site_temperature (arrays of N),
+    atom_virtual_potentials (array), T_bg, kmc_time, kmc_step_count, rnd_seed_kmc, kmc_rng_raw_draws (scalars)."""
+    pot = np.asarray(state["site_potential_boundary"]) + np.asarray(state["site_potential_charge"])
+    write_snapshot(path, element, x, y, z, pot, state["site_power"], full_precision=True)
+    np.savez(path + ".state.npz", **{k: np.asarray(v) for k, v in state.items()})
+
+
+def read_restart(path):
+    """(Structure, state dict).  The Structure is what read_xyz gives (kmc_main.cpp:65-80); state is None when the sidecar is missing
+    (a snapshot written by the reference itself)."""
+    import os
+    s = read_xyz(path)
+    side = path + ".state.npz"
+    if not os.path.exists(side):
+        return s, None
+    with np.load(side) as f:
+        state = {k: (f[k].item() if f[k].ndim == 0 else f[k].copy()) for k in f.files}
+    if len(state["site_charge"]) != s.N:
+        raise ValueError("restart sidecar %s does not belong to %s" % (side, path))
+    return s, state
 
 
 class StepLog:

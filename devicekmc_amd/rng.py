@@ -13,16 +13,30 @@ import numpy as np
 
 class StdMT19937:
     def __init__(self, seed: int = 0):
+        self.seed = int(seed)
+        self.n_raw = 0                            # 32-bit outputs drawn so far: the stream position a restart file carries
         self._bg = np.random.MT19937()
         self._bg._legacy_seeding(int(seed))       # init_genrand == std::mt19937::seed(value)
 
     def copy(self) -> "StdMT19937":
         c = StdMT19937.__new__(StdMT19937)
+        c.seed, c.n_raw = self.seed, self.n_raw
         c._bg = np.random.MT19937()
         c._bg.state = copy.deepcopy(self._bg.state)
         return c
 
+    @classmethod
+    def at_position(cls, seed: int, n_raw: int) -> "StdMT19937":
+        """The generator after n_raw 32-bit outputs of std::mt19937(seed) (restart)."""
+        g = cls(seed)
+        left = int(n_raw)
+        while left > 0:
+            k = min(left, 1 << 20)
+            g.raw(k); left -= k
+        return g
+
     def raw(self, n: int) -> np.ndarray:
+        self.n_raw += int(n)
         return self._bg.random_raw(n).astype(np.uint64)
 
     def uniform_batch(self, n: int) -> np.ndarray:
@@ -38,4 +52,5 @@ class StdMT19937:
 
     def skip(self, n_uniform: int) -> None:
         if n_uniform > 0:
+            self.n_raw += 2 * int(n_uniform)
             self._bg.random_raw(2 * n_uniform)

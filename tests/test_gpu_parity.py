@@ -456,29 +456,29 @@ def test_current_solve_randomised_negative_bias(cell_2p5, hip):
 
 def test_crossbar_log(hip, ref_logs, golden_dir):
     """structures/crossbars/timing_10nm_5pitch (110 813 sites, V = 1, solve_current = 0): a second geometry.  Same events as
-    the oracle; KMC time of the first logged supersteps of the reference's CUDA run within 5e-3 (its CG stops at 1e-6 and the
-    rates at V = 1 amplify that; beyond step 10 the logged trajectory and a converged one part at a single event)."""
+    the oracle; KMC time of ALL 13 logged supersteps of the reference's CUDA run to its 6 printed digits, at the CG tolerance the
+    log was made with (1e-12, tests/test_oracle_golden.py)."""
     from devicekmc_amd import params as pm, structure
     from oracle import oracle as oc
     host, L = hip
     gold = ref_logs["crossbars/timing_10nm_5pitch/output_initial.txt"]["steps"]
     s = structure.load_structure(os.path.join(golden_dir, "crossbar_10nm_5pitch.npz"))
     p = pm.KMCParameters(rnd_seed=5, lattice=tuple(s.meta["lattice"]), num_atoms_first_layer=144, num_atoms_contact=11520)
-    p.cg_tol = 1e-9; p.solve_current = False
+    p.cg_tol = 1e-12; p.solve_current = False
     V = 1.0
     dev = host.Device(s, p, gpu_neighbors="cuda:0"); sim = host.KMCProcess(dev, p.freq)
     gb = dev.make_gpubuf("cuda:0")
     o = oc.OracleKMC(s.element, s.x, s.y, s.z, p)
     assert dev.N == 110813 and np.array_equal(dev.neigh_idx, o.neigh) and np.array_equal(dev.site_element, o.element)
     t = 0.0
-    for k in range(8):
+    for k in range(len(gold)):
         dev.updateCharge(gb); dev.updatePotential(gb, p, V, k)
         _, dt = sim.executeKMCStep(gb, dev, want_log=True); t += dt
         if k < 3:
             o.superstep(V)
             assert np.array_equal(sim.last_event_log, o.last_events["log"]), k
             assert np.array_equal(get(gb, "site_charge"), o.charge)
-        assert abs(t / gold[k]["KMC time"] - 1) < 5e-3, (k, t, gold[k])
+        assert abs(t / gold[k]["KMC time"] - 1) < 1e-5, (k, t, gold[k])
 
 
 def test_error_paths(cell_2p5, hip):
@@ -699,3 +699,90 @@ def test_supersteps_tiled_structure(cell_2p5, hip):
         assert abs(dev.T_bg - out["T_bg"]) <= 1e-7
     rp, ci, data = host.get_last_X()
     assert np.array_equal(rp, o.last_X["row_ptr"]) and np.array_equal(ci, o.last_X["col"])
+
+
+def test_crossbar_with_current_solve(hip, golden_dir):
+    """configs[4] geometry (crossbar, 110 813 sites) with the current solve switched ON (every shipped crossbar parameter set has
+    solve_current = 0, so the reference holds no number for it), V = 1, two supersteps.  The oracle follows the potential / event
+    path (same events); the current solve is checked the way the ~1e6-site test does it: the solved node potentials satisfy
+    X m = b on sampled rows that the oracle generates on the fly (assembling this X and its WKB integrals on the CPU takes minutes)."""
+    from devicekmc_amd import params as pm, structure
+    from oracle import oracle as oc
+    host, L = hip
+    s = structure.load_structure(os.path.join(golden_dir, "crossbar_10nm_5pitch.npz"))
+    p = pm.KMCParameters(rnd_seed=5, lattice=tuple(s.meta["lattice"]), num_atoms_first_layer=144, num_atoms_contact=11520)
+    p.cg_tol = 1e-12
+    V = 1.0
+    dev = host.Device(s, p, gpu_neighbors="cuda:0"); sim = host.KMCProcess(dev, p.freq)
+    gb = dev.make_gpubuf("cuda:0")
+    L.dkmc_set_current_warm_start(0)
+    dev.setLaplacePotential(gb, p, V); gb.sync_HostToGPU(dev)
+    po = pm.KMCParameters(rnd_seed=5, lattice=tuple(s.meta["lattice"]), num_atoms_first_layer=144, num_atoms_contact=11520)
+    po.cg_tol = 1e-12; po.solve_current = False
+    o = oc.OracleKMC(s.element, s.x, s.y, s.z, po, neigh=dev.neigh_idx)
+    o.set_laplace_potential(V)
+    # the CB-edge system couples the oxide through conductances of 1e-8 (cond ~ 1e8 and more in this geometry): two converged
+    # solves agree to ~1e-6 there; the row check below uses the CB edge the GPU solve used
+    assert np.abs(get(gb, "site_CB_edge") - o.CB_edge).max() <= 1e-5 * np.abs(o.CB_edge).max()
+    o.CB_edge[:] = get(gb, "site_CB_edge")
+    rng = np.random.default_rng(11)
+    for k in range(2):
+        dev.updateCharge(gb); dev.updatePotential(gb, p, V, k)
+        _, dt = sim.executeKMCStep(gb, dev, want_log=True)
+        dev.updatePower(gb, p, V)
+        out = o.superstep(V)
+        st = host.get_stats()
+        assert np.array_equal(sim.last_event_log, o.last_events["log"]), k
+        assert abs(dt / out["step_time"] - 1) <= 1e-5
+        assert st["spmv_tiles"] > 0 and st["cg_rr_X"] <= p.cg_tol ** 2 and dev.imacro > 0
+        gb.sync_GPUToHost(dev)
+        assert np.array_equal(dev.site_element, o.element) and np.array_equal(dev.site_charge, o.charge)
+        m = get(gb, "atom_virtual_potentials")                 # G0-scaled, not shifted (no heating)
+        el = o.element
+        atom_site = np.flatnonzero((el != 0) & (el != 1))
+        Na = len(atom_site); a = np.arange(Na); ael = el[atom_site]
+        n1, nlc = p.num_atoms_first_layer, p.num_layers_contact
+        inner = np.isin(ael, list(p.metals)) & (a > (nlc - 1) * n1) & (a < Na - (nlc - 1) * n1) & (a < Na - 1)
+        vac = (ael == 2) & (a < Na - 1)
+        plain = ~inner & ~vac & (a < Na - 1)
+        rows = np.concatenate([rng.choice(np.flatnonzero(vac), 8, replace=False), rng.choice(np.flatnonzero(inner), 8, replace=False),
+                               rng.choice(np.flatnonzero(plain), 16, replace=False)]).astype(np.int32) + 2
+        diag, xm = o.x_rows_apply(rows, m)
+        assert (np.abs(xm) / p.G0 / np.sqrt(diag)).max() <= 1e-9          # scaled residual of the sampled rows (b = 0 on atom rows)
+
+
+def test_restart_continues_the_same_event_sequence(cell_2p5, hip, tmp_path):
+    """f2: three supersteps, snapshot + sidecar (host.save_restart), fresh objects from the files (host.load_restart), three more
+    supersteps: same (slot, i, j, type) event log, KMC time, I_macro and T_bg -- bit for bit -- as the uninterrupted run."""
+    from devicekmc_amd import params as pm
+    host, L = hip
+    p = pm.KMCParameters(); p.solve_heating_global = True
+
+    def steps(dev, sim, gb, k0, n):
+        out = []
+        for k in range(k0, k0 + n):
+            dev.updateCharge(gb); dev.updatePotential(gb, p, Vd, k)
+            _, dt = sim.executeKMCStep(gb, dev, want_log=True)
+            dev.updatePower(gb, p, Vd); dev.updateTemperature(gb, p, dt)
+            out.append((sim.last_event_log.copy(), dt, dev.imacro, dev.T_bg))
+        return out
+
+    L.dkmc_set_current_warm_start(0)
+    dev = host.Device(cell_2p5, p); sim = host.KMCProcess(dev, p.freq); gb = dev.make_gpubuf("cuda:0")
+    dev.setLaplacePotential(gb, p, Vd); gb.sync_HostToGPU(dev)
+    full = steps(dev, sim, gb, 0, 6)
+    del gb, sim, dev
+    dev = host.Device(cell_2p5, p); sim = host.KMCProcess(dev, p.freq); gb = dev.make_gpubuf("cuda:0")
+    dev.setLaplacePotential(gb, p, Vd); gb.sync_HostToGPU(dev)
+    first = steps(dev, sim, gb, 0, 3)
+    path = str(tmp_path / "snapshot_3.xyz")
+    host.save_restart(path, dev, sim, gb, kmc_time=sum(f[1] for f in first), kmc_step_count=3)
+    del gb, sim, dev
+    dev2, sim2, gb2, state = host.load_restart(path, p, "cuda:0")
+    assert state["kmc_step_count"] == 3 and state["kmc_rng_raw_draws"] > 0
+    rest = steps(dev2, sim2, gb2, 3, 3)
+    for a, b in zip(full[:3], first):
+        assert np.array_equal(a[0], b[0]) and a[1:] == b[1:]
+    for a, b in zip(full[3:], rest):
+        assert np.array_equal(a[0], b[0])
+        assert a[1:] == b[1:], (a[1:], b[1:])

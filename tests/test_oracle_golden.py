@@ -106,18 +106,20 @@ def test_current_7p5nm_vs_log(dev_7p5, ref_logs):
 
 
 def test_cuda_path_log_crossbar(ref_logs, golden_dir):
-    """Second geometry: crossbars/timing_10nm_5pitch (110 813 sites, V = 1, solve_current = 0), first logged supersteps."""
+    """Second geometry: crossbars/timing_10nm_5pitch (110 813 sites, V = 1, solve_current = 0).  At the tolerance the reference's
+    logs were made with (1e-12, see test_cuda_path_log_7p5nm) ALL 13 logged supersteps agree to the 6 printed digits; at 1e-9 the
+    first 11 agree to 5e-3 and the trajectories then part at one event."""
     from devicekmc_amd import structure
     gold = ref_logs["crossbars/timing_10nm_5pitch/output_initial.txt"]["steps"]
     s = structure.load_structure(os.path.join(golden_dir, "crossbar_10nm_5pitch.npz"))
     p = pm.KMCParameters(rnd_seed=5, lattice=tuple(s.meta["lattice"]), num_atoms_first_layer=144, num_atoms_contact=11520)
-    p.cg_tol = 1e-9; p.solve_current = False
+    p.cg_tol = 1e-12; p.solve_current = False
     o = oc.OracleKMC(s.element, s.x, s.y, s.z, p)
     assert o.N == 110813 and int((o.element == pm.VACANCY).sum()) == 1600
     t = 0.0
-    for k in range(3):
+    for k in range(len(gold)):
         t += o.superstep(1.0)["step_time"]
-        assert abs(t / gold[k]["KMC time"] - 1) < 5e-3, (k, t, gold[k])
+        assert abs(t / gold[k]["KMC time"] - 1) < 5e-6, (k, t, gold[k])
 
 
 def test_x_rows_on_the_fly_match_assembled_X(cell_2p5):

@@ -261,6 +261,34 @@ def cpu_superstep_baseline(s, p, ncores):
             "ms_per_step": round(tc * 1e3, 1), "split_ms": {k: round(v * 1e3, 2) for k, v in o.timing.items()}}
 
 
+def cpp_host_crosscheck(sim, steps, warmup):
+    """The same timed loop driven by the C++ host (devicekmc_amd/host/kmc_superstep: the reference's call sequence and argument lists
+    through include/gpu_solvers.h -> C ABI) instead of the Python mirror: steps/s of a child process on the same workload."""
+    import subprocess
+    import tempfile
+    from devicekmc_amd import io as kio, structure
+    exe = os.path.join(ROOT, "devicekmc_amd", "host", "kmc_superstep")
+    if not os.path.exists(exe):
+        return {"error": "kmc_superstep not built"}
+    d = tempfile.mkdtemp(prefix="dkmc_cpp_", dir="/tmp")
+    try:
+        element, neigh, nn, layer = structure.prepare_device(sim.s, sim.p, (sim.dev.neigh_idx, sim.dev.max_num_neighbors))
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        kio.write_host_bundle(fin, sim.s, sim.p, VD, element, neigh, nn, layer)
+        r = subprocess.run([exe, fin, fout, str(steps), str(warmup)], capture_output=True, text=True, timeout=300)
+        line = [l for l in r.stdout.splitlines() if l.startswith("TIMING")]
+        if r.returncode != 0 or not line:
+            return {"error": (r.stderr or r.stdout)[-300:]}
+        sec = float(line[0].split("seconds=")[1])
+        return {"host": "C++ driver over the drop-in shim (child process)", "steps": steps, "warmup": warmup,
+                "value": round(steps / sec, 4), "ms_per_step": round(sec / steps * 1e3, 3)}
+    except Exception as exc:
+        return {"error": repr(exc)[:300]}
+    finally:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def pmc_traffic(workload, kernel_prefix, x_format):
     """HBM bytes per launch of the dominant kernel from the PMC counters, measured in this run: two rocprofv3 child runs of this
     script on the same workload (one step), `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes with the kernel trace only
@@ -333,6 +361,7 @@ def main():
     ap.add_argument("--scale-points", default=None, help="N = 1: comma list of extra workloads measured in the same run (default tile:5,tile:10; 'none')")
     ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the replicas block")
     ap.add_argument("--no-alt", action="store_true", help="skip the alt_warm_start block")
+    ap.add_argument("--no-cpp-host", action="store_true", help="N = 1: skip the cross-check line through the C++ host driver")
     ap.add_argument("--no-pmc", action="store_true", help="N = 1: do not measure roofline.traffic (two rocprofv3 --pmc child runs)")
     ap.add_argument("--budget", type=float, default=420.0, help="time budget [s] for the timed steps of seconds-per-step workloads")
     ap.add_argument("--timeout", type=float, default=900.0, help="watchdog [s]: exit 3 if the run has not finished")
@@ -370,6 +399,9 @@ def main():
             ta = time.perf_counter() - t0
             alt = {"current_warm_start": 1, "value": round(na / ta, 4), "ms_per_step": round(ta / na * 1e3, 3), "cg_iters_X": it0 / na}
             sim.L.dkmc_set_current_warm_start(0)
+        cpp = None
+        if not args.no_cpp_host and sim.s.N <= 150000:
+            cpp = cpp_host_crosscheck(sim, min(n, 10), 2)
         cpu = None
         if not args.no_cpu_baseline:
             cpu = cpu_superstep_baseline(sim.s, sim.p, ncores) if sim.s.N <= 150000 else cpu_cg_baseline(sim, ncores)
@@ -379,7 +411,7 @@ def main():
             "config": {"workload": name, "sites": res["sites"], "nn": res["nn"], "atoms": res["atoms"], "Vd": VD,
                        "phases": "charge+potential+rates+current+heat", "parallelism": "single GPU", "x_format": "tiled" if args.x_format else "csr",
                        "current_warm_start": args.warm_start, "cg_tol": sim.p.cg_tol},
-            "split_ms": res["split_ms"], "per_step": res["per_step"], "cpu_baseline": cpu, "alt_warm_start": alt,
+            "split_ms": res["split_ms"], "per_step": res["per_step"], "cpu_baseline": cpu, "alt_warm_start": alt, "cpp_host_crosscheck": cpp,
         }
         if n != args.steps:
             out["steps_requested"] = args.steps

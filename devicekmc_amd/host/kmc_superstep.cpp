@@ -7,7 +7,8 @@
 // Input / output are raw binary bundles written / read by tests/test_cpp_host.py (no reference parser here:
 // input_parser / xyz reading are out of scope).
 //
-//   kmc_superstep <bundle.in> <bundle.out> <steps>
+//   kmc_superstep <bundle.in> <bundle.out> <steps> [warmup]     (warmup given: `warmup` untimed steps first, then a TIMING line on stdout)
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -30,6 +31,7 @@ int main(int argc, char **argv)
 {
     if (argc < 4) { fprintf(stderr, "usage: %s bundle.in bundle.out steps\n", argv[0]); return 1; }
     const int steps = atoi(argv[3]);
+    const int warmup = argc > 4 ? atoi(argv[4]) : 0;
     FILE *f = fopen(argv[1], "rb");
     if (!f) { perror(argv[1]); return 1; }
     int hdr[8]; rd(f, hdr, 8);
@@ -68,23 +70,33 @@ int main(int argc, char **argv)
     std::vector<double> out_dt, out_I, out_T;
     // current_solver.cpp:8-17
     const double X_loop_G = high_G * 10000000, X_high_G = high_G * 100000, X_low_G = low_G, G0 = 2 * 3.8612e-5 * 1e-5, tol = 1.60217663e-19 * 0.01;
-    for (int step = 0; step < steps; ++step) {
-        update_charge_gpu(reinterpret_cast<ELEMENT *>(gpubuf.site_element), gpubuf.site_charge, gpubuf.neigh_idx, gpubuf.N_, gpubuf.nn_,
-                          reinterpret_cast<const ELEMENT *>(gpubuf.metal_types), gpubuf.num_metal_types_);
-        background_potential_gpu_sparse(h, h, gpubuf, N, n_first, n_first, Vd, pbc, high_G, low_G, nn_dist, (int)metals.size(), step);
+    std::chrono::steady_clock::time_point t_start;
+    for (int step = -warmup; step < steps; ++step) {
+        if (step == 0 && argc > 4) { dkmc_synchronize(); t_start = std::chrono::steady_clock::now(); }
+        update_charge_gpu(gpubuf.site_element, gpubuf.site_charge, gpubuf.neigh_idx, gpubuf.N_, gpubuf.nn_,
+                          gpubuf.metal_types, gpubuf.num_metal_types_);                   // potential_solver.cpp:152, verbatim
+        background_potential_gpu_sparse(h, h, gpubuf, N, n_first, n_first, Vd, pbc, high_G, low_G, nn_dist, (int)metals.size(), step + warmup);
         poisson_gridless_gpu(n_first, pbc, gpubuf.N_, gpubuf.lattice, gpubuf.sigma, gpubuf.k, gpubuf.site_x, gpubuf.site_y, gpubuf.site_z,
                              gpubuf.site_charge, gpubuf.site_potential_charge);
         const double dt = execute_kmc_step_gpu(N, nn, gpubuf.neigh_idx, gpubuf.site_layer, gpubuf.lattice, pbc, gpubuf.T_bg, gpubuf.freq,
                                                gpubuf.sigma, gpubuf.k, gpubuf.site_x, gpubuf.site_y, gpubuf.site_z,
                                                gpubuf.site_potential_boundary, gpubuf.site_potential_charge, gpubuf.site_temperature,
-                                               reinterpret_cast<ELEMENT *>(gpubuf.site_element), gpubuf.site_charge, rng, dev.neigh_idx.data());
+                                               gpubuf.site_element, gpubuf.site_charge, rng, dev.neigh_idx.data());   // KMCProcess.cpp:269-274, verbatim
         update_power_gpu_sparse(h, h, gpubuf, n_first, n_first, n_lay_contact, Vd, pbc, X_high_G, X_low_G, X_loop_G, G0, tol, nn_dist, m_e, V0,
                                 (int)metals.size(), &dev.imacro, false, true, 1.0);
         double P = 0.0;                                                                   // heat_solver.cpp:316-350, on the device
         GPUBuffers::report(dkmc_update_temperature_global_analytic(gpubuf.site_power, gpubuf.T_bg, N, dt, diss, t_ox, A, c_p, &P));
+        if (step < 0) continue;
+        if (argc > 4) { out_dt.push_back(dt); out_I.push_back(dev.imacro); out_T.push_back(0.0); continue; }      // timed run: no host copies inside the loop
         out_dt.push_back(dt); out_I.push_back(dev.imacro);
         gpubuf.sync_GPUToHost(dev); out_T.push_back(dev.T_bg);
         fprintf(stderr, "step %d: KMC step time %.6e  Current [uA] %.6f  T_bg %.6f\n", step, dt, dev.imacro * 1e6, dev.T_bg);
+    }
+    if (argc > 4) {
+        dkmc_synchronize();
+        const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+        printf("TIMING steps=%d seconds=%.6f\n", steps, sec);
+        gpubuf.sync_GPUToHost(dev);
     }
     const double next_u = rng.getRandomNumber();       // proves the stream position
     f = fopen(argv[2], "wb");

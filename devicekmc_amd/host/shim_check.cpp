@@ -15,15 +15,15 @@ double kmc_superstep(HostDevice &device, GPUBuffers &gpubuf, RandomNumberGenerat
                      double nn_dist, int step)
 {
     dkmc_handle_t h = nullptr;
-    update_charge_gpu(reinterpret_cast<ELEMENT *>(gpubuf.site_element), gpubuf.site_charge, gpubuf.neigh_idx, gpubuf.N_, gpubuf.nn_,
-                      reinterpret_cast<const ELEMENT *>(gpubuf.metal_types), gpubuf.num_metal_types_);
+    update_charge_gpu(gpubuf.site_element, gpubuf.site_charge, gpubuf.neigh_idx, gpubuf.N_, gpubuf.nn_,
+                      gpubuf.metal_types, gpubuf.num_metal_types_);              // potential_solver.cpp:152 as it stands
     background_potential_gpu_sparse(h, h, gpubuf, device.N, n_first_layer, n_first_layer, Vd, pbc, 1.0, 1e-8, nn_dist, gpubuf.num_metal_types_, step);
     poisson_gridless_gpu(n_first_layer, pbc, gpubuf.N_, gpubuf.lattice, gpubuf.sigma, gpubuf.k, gpubuf.site_x, gpubuf.site_y, gpubuf.site_z,
                          gpubuf.site_charge, gpubuf.site_potential_charge);
     double dt = execute_kmc_step_gpu(device.N, device.max_num_neighbors, gpubuf.neigh_idx, gpubuf.site_layer, gpubuf.lattice, pbc, gpubuf.T_bg,
                                      gpubuf.freq, gpubuf.sigma, gpubuf.k, gpubuf.site_x, gpubuf.site_y, gpubuf.site_z,
                                      gpubuf.site_potential_boundary, gpubuf.site_potential_charge, gpubuf.site_temperature,
-                                     reinterpret_cast<ELEMENT *>(gpubuf.site_element), gpubuf.site_charge, rng, device.neigh_idx.data());
+                                     gpubuf.site_element, gpubuf.site_charge, rng, device.neigh_idx.data());   // KMCProcess.cpp:269-274 as it stands
     double imacro = 0.0;
     update_power_gpu_sparse(h, h, gpubuf, n_first_layer, n_first_layer, 10, Vd, pbc, 1e5, 1e-8, 1e7, 2 * 3.8612e-5 * 1e-5, 1.60217663e-19 * 0.01,
                             nn_dist, 0.85 * 9.11e-31, 1.6, gpubuf.num_metal_types_, &imacro, false, true, 1.0);

@@ -23,6 +23,12 @@ extern "C" {
 #endif
 
 /* Mirror of the public members of class GPUBuffers (gpu_buffers.h:16-52). */
+/* Element arrays hold the 4-byte ELEMENT enum (utils.h:37-44).  A C++ host that has the enum type defines DKMC_ELEMENT_T to it before
+ * including this header (include/gpu_buffers.h does): the members then have the reference's own type, `ELEMENT *`, and the
+ * reference's call sites (potential_solver.cpp:152, KMCProcess.cpp:269-274) compile unchanged.  Same layout either way. */
+#ifndef DKMC_ELEMENT_T
+#define DKMC_ELEMENT_T int
+#endif
 typedef struct dkmc_gpubuf {
     int *site_charge;
     double *site_power, *site_potential_boundary, *site_potential_charge, *site_temperature;
@@ -32,11 +38,11 @@ typedef struct dkmc_gpubuf {
     double *atom_CB_edge;
     double *atom_virtual_potentials;
     int *atom_charge;
-    int *site_element;
-    int *atom_element;
+    DKMC_ELEMENT_T *site_element;
+    DKMC_ELEMENT_T *atom_element;
     double *site_x, *site_y, *site_z;
     double *atom_x, *atom_y, *atom_z;
-    int *metal_types;
+    DKMC_ELEMENT_T *metal_types;
     double *sigma, *k, *lattice, *freq;
     int *neigh_idx, *site_layer;
     int *Device_row_ptr_d, *Device_col_indices_d;

@@ -10,8 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include "devicekmc_types.h"            // ELEMENT (or, with DKMC_HAVE_REFERENCE_TYPES, the reference's own utils.h has defined it)
+#define DKMC_ELEMENT_T ELEMENT          // gpubuf.site_element / atom_element / metal_types are ELEMENT *, as in the reference
 #include "devicekmc_hip.h"
-#include "devicekmc_types.h"
 
 class GPUBuffers : public dkmc_gpubuf {
 public:

@@ -14,34 +14,42 @@
 #include <vector>
 #include "gpu_buffers.h"
 
-inline void get_gpu_info(char *gpu_string, int dev) { GPUBuffers::report(dkmc_get_gpu_info(gpu_string, 1000, dev)); }   // kmc_events.cu:15
-inline void set_gpu(int dev) { GPUBuffers::report(dkmc_set_gpu(dev)); }                                                 // kmc_events.cu:30
+/* Linkage of the functions below.  Default: inline forwards (header-only shim; the host is recompiled against this header).
+ * devicekmc_amd/host/shim_exports.cpp compiles the same bodies with DKMC_SHIM_API = extern "C" + default visibility into
+ * libdevicekmc_shim.so, which then EXPORTS the reference's unmangled names (gpu_solvers.h:36-208 declares them extern "C") for
+ * host objects that were compiled against a declaration-only copy of this header (DKMC_SHIM_DECLARATIONS_ONLY). */
+#ifndef DKMC_SHIM_API
+#define DKMC_SHIM_API inline
+#endif
 
-inline void copytoConstMemory(std::vector<double> E_gen, std::vector<double> E_rec, std::vector<double> E_Vdiff, std::vector<double> E_Odiff)
+DKMC_SHIM_API void get_gpu_info(char *gpu_string, int dev) { GPUBuffers::report(dkmc_get_gpu_info(gpu_string, 1000, dev)); }   // kmc_events.cu:15
+DKMC_SHIM_API void set_gpu(int dev) { GPUBuffers::report(dkmc_set_gpu(dev)); }                                                 // kmc_events.cu:30
+
+DKMC_SHIM_API void copytoConstMemory(std::vector<double> E_gen, std::vector<double> E_rec, std::vector<double> E_Vdiff, std::vector<double> E_Odiff)
 {
     GPUBuffers::report(dkmc_copy_to_const_memory(E_gen.data(), E_rec.data(), E_Vdiff.data(), E_Odiff.data(), (int)E_gen.size()));
 }
 
-inline void initialize_sparsity(GPUBuffers &gpubuf, int pbc, const double nn_dist, int num_atoms_contact)
+DKMC_SHIM_API void initialize_sparsity(GPUBuffers &gpubuf, int pbc, const double nn_dist, int num_atoms_contact)
 {
     GPUBuffers::report(dkmc_initialize_sparsity(&gpubuf, pbc, nn_dist, num_atoms_contact));
 }
 
-inline void update_CB_edge_gpu_sparse(dkmc_handle_t, dkmc_handle_t, GPUBuffers &gpubuf, const int N, const int N_left_tot,
+DKMC_SHIM_API void update_CB_edge_gpu_sparse(dkmc_handle_t, dkmc_handle_t, GPUBuffers &gpubuf, const int N, const int N_left_tot,
                                       const int N_right_tot, const double d_Vd, const int pbc, const double d_high_G,
                                       const double d_low_G, const double nn_dist, const int num_metals)
 {
     GPUBuffers::report(dkmc_update_CB_edge_gpu_sparse(&gpubuf, N, N_left_tot, N_right_tot, d_Vd, pbc, d_high_G, d_low_G, nn_dist, num_metals));
 }
 
-inline void update_charge_gpu(ELEMENT *gpu_site_element, int *gpu_site_charge, int *gpu_neigh_idx, int N, int nn,
+DKMC_SHIM_API void update_charge_gpu(ELEMENT *gpu_site_element, int *gpu_site_charge, int *gpu_neigh_idx, int N, int nn,
                               const ELEMENT *metals, const int num_metals)
 {
     GPUBuffers::report(dkmc_update_charge_gpu(reinterpret_cast<int *>(gpu_site_element), gpu_site_charge, gpu_neigh_idx, N, nn,
                                               reinterpret_cast<const int *>(metals), num_metals));
 }
 
-inline void background_potential_gpu_sparse(dkmc_handle_t, dkmc_handle_t, GPUBuffers &gpubuf, const int N, const int N_left_tot,
+DKMC_SHIM_API void background_potential_gpu_sparse(dkmc_handle_t, dkmc_handle_t, GPUBuffers &gpubuf, const int N, const int N_left_tot,
                                             const int N_right_tot, const double d_Vd, const int pbc, const double d_high_G,
                                             const double d_low_G, const double nn_dist, const int num_metals, int kmc_step_count)
 {
@@ -49,20 +57,20 @@ inline void background_potential_gpu_sparse(dkmc_handle_t, dkmc_handle_t, GPUBuf
                                                             num_metals, kmc_step_count));
 }
 
-inline void poisson_gridless_gpu(const int num_atoms_contact, const int pbc, const int N, const double *lattice, const double *sigma,
+DKMC_SHIM_API void poisson_gridless_gpu(const int num_atoms_contact, const int pbc, const int N, const double *lattice, const double *sigma,
                                  const double *k, const double *posx, const double *posy, const double *posz, const int *site_charge,
                                  double *site_potential_charge)
 {
     GPUBuffers::report(dkmc_poisson_gridless_gpu(num_atoms_contact, pbc, N, lattice, sigma, k, posx, posy, posz, site_charge, site_potential_charge));
 }
 
-inline void solve_sparse_CG_Jacobi(dkmc_handle_t, dkmc_handle_t, double *A_data, int *A_row_ptr, int *A_col_indices, const int A_nnz,
+DKMC_SHIM_API void solve_sparse_CG_Jacobi(dkmc_handle_t, dkmc_handle_t, double *A_data, int *A_row_ptr, int *A_col_indices, const int A_nnz,
                                    int m, double *d_x, double *d_y)
 {
     GPUBuffers::report(dkmc_solve_sparse_CG_Jacobi(A_data, A_row_ptr, A_col_indices, A_nnz, m, d_x, d_y, nullptr, nullptr));
 }
 
-inline double execute_kmc_step_gpu(const int N, const int nn, const int *neigh_idx, const int *site_layer, const double *lattice,
+DKMC_SHIM_API double execute_kmc_step_gpu(const int N, const int nn, const int *neigh_idx, const int *site_layer, const double *lattice,
                                    const int pbc, const double *T_bg, const double *freq, const double *sigma, const double *k,
                                    const double *posx, const double *posy, const double *posz, const double *site_potential_boundary,
                                    const double *site_potential_charge, const double *site_temperature, ELEMENT *site_element,
@@ -87,7 +95,7 @@ inline double execute_kmc_step_gpu(const int N, const int nn, const int *neigh_i
     return event_time;
 }
 
-inline void update_power_gpu_sparse(dkmc_handle_t, dkmc_handle_t, GPUBuffers &gpubuf, const int num_source_inj, const int num_ground_ext,
+DKMC_SHIM_API void update_power_gpu_sparse(dkmc_handle_t, dkmc_handle_t, GPUBuffers &gpubuf, const int num_source_inj, const int num_ground_ext,
                                     const int num_layers_contact, const double Vd, const int pbc, const double high_G, const double low_G,
                                     const double loop_G, const double G0, const double tol, const double nn_dist, const double m_e,
                                     const double V0, int num_metals, double *imacro, const bool solve_heating_local,
@@ -97,7 +105,7 @@ inline void update_power_gpu_sparse(dkmc_handle_t, dkmc_handle_t, GPUBuffers &gp
                                                     G0, tol, nn_dist, m_e, V0, num_metals, imacro, solve_heating_local, solve_heating_global, alpha_disp));
 }
 
-inline void update_temperatureglobal_gpu(const double *site_power, double *T_bg, const int N, const double a_coeff, const double b_coeff,
+DKMC_SHIM_API void update_temperatureglobal_gpu(const double *site_power, double *T_bg, const int N, const double a_coeff, const double b_coeff,
                                          const double number_steps, const double C_thermal, const double small_step)
 {
     GPUBuffers::report(dkmc_update_temperatureglobal_gpu(site_power, T_bg, N, a_coeff, b_coeff, number_steps, C_thermal, small_step));
@@ -107,12 +115,12 @@ inline void update_temperatureglobal_gpu(const double *site_power, double *T_bg,
 // Local temperature model: the reference keeps it on the host with dense inverses (heat_solver.cpp:40-246, 286-308, 354-513).
 // Device::constructLaplacian would call the first (N_left_tot / N_right_tot from get_num_in_contacts, gamma from :86), the
 // local branch of Device::updateTemperature the second; both work on the GPUBuffers arrays.
-inline void construct_laplacian_gpu(GPUBuffers &gpubuf, const int N_left_tot, const int N_right_tot, const double gamma)
+DKMC_SHIM_API void construct_laplacian_gpu(GPUBuffers &gpubuf, const int N_left_tot, const int N_right_tot, const double gamma)
 {
     GPUBuffers::report(dkmc_construct_laplacian(&gpubuf, N_left_tot, N_right_tot, gamma));
 }
 
-inline double update_temperature_local_gpu(GPUBuffers &gpubuf, const double step_time, const double delta_t, const double tau,
+DKMC_SHIM_API double update_temperature_local_gpu(GPUBuffers &gpubuf, const double step_time, const double delta_t, const double tau,
                                            const double background_temp, const double k_th_interface, const double k_th_vacancies,
                                            const double nn_dist, const int num_atoms_contact)
 {

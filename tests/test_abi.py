@@ -48,3 +48,17 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError):
         lib.load()
+
+
+def test_shim_library_exports_the_reference_names():
+    """libdevicekmc_shim.so exports the reference's own unmangled entry points (gpu_solvers.h:36-208) on top of the C ABI."""
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    shim = os.path.join(ROOT, "devicekmc_amd", "libdevicekmc_shim.so")
+    out = subprocess.run(["nm", "-D", "--defined-only", shim], capture_output=True, text=True, check=True).stdout
+    names = {l.split()[-1] for l in out.splitlines() if l.strip()}
+    for n in ("get_gpu_info", "set_gpu", "copytoConstMemory", "initialize_sparsity", "update_CB_edge_gpu_sparse", "update_charge_gpu",
+              "background_potential_gpu_sparse", "poisson_gridless_gpu", "solve_sparse_CG_Jacobi", "execute_kmc_step_gpu",
+              "update_power_gpu_sparse", "update_temperatureglobal_gpu"):
+        assert n in names, n

@@ -1,7 +1,6 @@
 """The reference's host language is C++: run the C++ driver that goes through the drop-in shim
 (include/gpu_buffers.h + include/gpu_solvers.h -> C ABI) and compare it with the oracle."""
 import os
-import struct
 import subprocess
 
 import numpy as np
@@ -20,20 +19,9 @@ def test_cpp_driver_matches_oracle(cell_2p5, tmp_path):
     Vd, steps = 5.0, 3
     element, neigh, nn, layer = structure.prepare_device(cell_2p5, p)
     N = cell_2p5.N
-    N_atom = int(((element != 0) & (element != 1)).sum())
     fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
-    with open(fin, "wb") as f:
-        f.write(struct.pack("8i", N, nn, N_atom, len(p.layers), len(p.metals), p.num_atoms_first_layer, p.num_layers_contact, int(p.pbc)))
-        f.write(struct.pack("16d", Vd, p.freq, p.sigma, p.k, p.nn_dist, p.high_G, p.low_G, p.m_e, p.V0, p.background_temp,
-                            p.dissipation_constant, p.t_ox, p.A, p.c_p, float(p.rnd_seed_kmc), 0.0))
-        f.write(np.asarray(p.lattice, dtype=np.float64).tobytes())
-        for l in p.layers:
-            f.write(struct.pack("4d", l.E_gen_0, l.E_rec_1, l.E_diff_2, l.E_diff_3))
-        f.write(np.asarray(p.metals, dtype=np.int32).tobytes())
-        f.write(element.astype(np.int32).tobytes()); f.write(layer.astype(np.int32).tobytes())
-        for a in (cell_2p5.x, cell_2p5.y, cell_2p5.z):
-            f.write(np.ascontiguousarray(a, dtype=np.float64).tobytes())
-        f.write(np.ascontiguousarray(neigh, dtype=np.int32).tobytes())
+    from devicekmc_amd import io as kio
+    kio.write_host_bundle(fin, cell_2p5, p, Vd, element, neigh, nn, layer)
     exe = os.path.join(ROOT, "devicekmc_amd", "host", "kmc_superstep")
     r = subprocess.run([exe, fin, fout, str(steps)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr

@@ -360,6 +360,7 @@ def main():
                     help="N > 1: ONE simulation, X sharded over the ranks (strong scaling, default) or independent replicas (weak scaling)")
     ap.add_argument("--scale-points", default=None, help="N = 1: comma list of extra workloads measured in the same run (default tile:5,tile:10; 'none')")
     ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the replicas block")
+    ap.add_argument("--no-single-ref", action="store_true", help="N > 1: skip the single-GPU run of the same simulation (reference point of the speed-up)")
     ap.add_argument("--no-alt", action="store_true", help="skip the alt_warm_start block")
     ap.add_argument("--no-cpp-host", action="store_true", help="N = 1: skip the cross-check line through the C++ host driver")
     ap.add_argument("--no-pmc", action="store_true", help="N = 1: do not measure roofline.traffic (two rocprofv3 --pmc child runs)")
@@ -459,6 +460,17 @@ def main():
             replicas = {"workload": "7.5nm", "steps_per_rank": n, "value": round(parallel.aggregate_rate(n, world, el), 4),
                         "unit": "KMC steps/s (aggregate over %d independent replicas)" % world, "scaling": "weak", "ms_per_step": round(el / n * 1e3, 3)}
             rs.close()
+        single = None
+        if args.mode == "sharded" and not args.no_single_ref:
+            # the same simulation on ONE GPU of this node (rank 0; the other ranks wait): the reference point of the strong scaling
+            if rank == 0:
+                s1 = Sim(name, devname, x_format=1)
+                big1 = s1.s.N > 150000
+                el1, n1 = s1.run(2 if big1 else 5, 0 if big1 else 1, budget_s=90.0)
+                single = {"workload": name, "n_gpus": 1, "steps": n1, "value": round(n1 / el1, 5), "ms_per_step": round(el1 / n1 * 1e3, 3),
+                          "cg_iters_X": s1.cnt["cg_iters_X"] / max(s1.cnt["steps"], 1), "trace": [list(t) for t in s1.trace[:n1]]}
+                s1.close()
+            parallel.barrier()
         if args.mode == "sharded":
             transport = parallel.attach_solver_comm()          # every rank advances the same simulation (same seeds); X is sharded
             sim = Sim(name, devname, x_format=1)
@@ -499,8 +511,19 @@ def main():
                              "exchange_us": round(sim.prof["comm_ms"] / max(sim.prof["comm_n"], 1) * 1e3, 2),
                              "exchanged_doubles": int(st["comm_count_per_rank"]),
                              "replicated_phases": "charge, K-CG, pair sum, event loop, neighbour part of X (all < 5 % of a step at this size)"},
-                "replicas": replicas,
+                "replicas": replicas, "single_gpu_reference": None,
             }
+            if single is not None:
+                # same seeds, same steps: the sharded run must reproduce the single-GPU trajectory (to rounding)
+                ref_tr = single.pop("trace")           # steps 0, 1, ... of the single-GPU run; sim.trace holds steps warm, warm + 1, ... of the sharded one
+                k = min(len(ref_tr) - warm, len(sim.trace))
+                dev_rel = None
+                if k > 0:
+                    dev_rel = max(abs(a - b) / max(abs(b), 1e-300) for jj in range(k) for a, b in zip(sim.trace[jj], ref_tr[warm + jj]))
+                single["common_steps"] = max(k, 0)
+                single["max_rel_deviation_of_dt_I_T_over_common_steps"] = dev_rel
+                out["single_gpu_reference"] = single
+                out["strong_scaling_speedup"] = round(out["value"] / single["value"], 3)
             if n != args.steps:
                 out["steps_requested"] = args.steps
             out.update(roofs)

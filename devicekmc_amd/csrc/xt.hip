@@ -369,8 +369,9 @@ __global__ __launch_bounds__(XT_NT) void k_xt_tiles_only(int nitems, const XItem
 
 // ---- row kernel: per S-row, row partials (ascending window) + column partials (ascending run) ------------------------------
 // One workgroup per row block: 8 slices x 32 S-rows, slice sl adds every 8th window and every 8th run, the slices are combined
-// in a fixed order through LDS.  MODE 0: t = s_i (sparse sum + tile sums) for the S rows, then the workgroup adds p.t over its
-// share of ALL rows (the non-S rows were finished by the apply kernel) and writes one partial.  MODE 1: xout[s] = tile sums
+// in a fixed order through LDS.  MODE 0: t = s_i (sparse sum + tile sums) for the S rows, then the workgroup adds p.t, r.t and t.t
+// over its share of ALL rows (the non-S rows were finished by the apply kernel) and writes one partial of each (XT_PSTRIDE
+// apart).  MODE 1: xout[s] = tile sums
 // only (this rank's share in the sharded solve; the diagonal and power passes).
 __device__ __forceinline__ double xt_row_block_sum(int k, int nW, int ns_pad, const int2 *__restrict__ wrange, const int *__restrict__ nitem_w,
                                                    const double *__restrict__ rowpart, const double *__restrict__ colpart, double (*sl_sum)[XT_R])
@@ -378,18 +379,19 @@ __device__ __forceinline__ double xt_row_block_sum(int k, int nW, int ns_pad, co
     const int r = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int s = XT_R * k + r;
     const int2 wr = wrange[k];
-    double a0 = 0.0, a1 = 0.0;
-    const double *rpp = rowpart + (size_t)k * nW * XT_R + r;
-    int w = wr.x + sl;
-    for (; w + 8 < wr.y; w += 16) { a0 += rpp[(size_t)w * XT_R]; a1 += rpp[(size_t)(w + 8) * XT_R]; }
-    if (w < wr.y) a0 += rpp[(size_t)w * XT_R];
     const int nc = nitem_w[k / (XT_C / XT_R)];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    const double *rpp = rowpart + (size_t)k * nW * XT_R + r;
     const double *cpp = colpart + s;
-    int c = sl;
-    for (; c + 8 < nc; c += 16) { a0 += cpp[(size_t)c * ns_pad]; a1 += cpp[(size_t)(c + 8) * ns_pad]; }
-    if (c < nc) a0 += cpp[(size_t)c * ns_pad];
+    int w = wr.x + sl, c = sl;
+    // four independent loads in flight per list (the lists hold up to nK / 8 terms per slice)
+    for (; c + 24 < nc; c += 32) { a0 += cpp[(size_t)c * ns_pad]; a1 += cpp[(size_t)(c + 8) * ns_pad]; a2 += cpp[(size_t)(c + 16) * ns_pad]; a3 += cpp[(size_t)(c + 24) * ns_pad]; }
+    for (; c < nc; c += 8) a0 += cpp[(size_t)c * ns_pad];
+    for (; w + 24 < wr.y; w += 32) { a0 += rpp[(size_t)w * XT_R]; a1 += rpp[(size_t)(w + 8) * XT_R]; a2 += rpp[(size_t)(w + 16) * XT_R]; a3 += rpp[(size_t)(w + 24) * XT_R]; }
+    for (; w < wr.y; w += 8) a1 += rpp[(size_t)w * XT_R];
+    const double mine = (a0 + a1) + (a2 + a3);
     __syncthreads();                                                 // previous round's readers are done with sl_sum
-    sl_sum[sl][r] = a0 + a1;
+    sl_sum[sl][r] = mine;
     __syncthreads();
     double tot = 0.0;
     if (sl == 0) {
@@ -398,74 +400,102 @@ __device__ __forceinline__ double xt_row_block_sum(int k, int nW, int ns_pad, co
     }
     return tot;                                                      // valid in threads 0..31
 }
+#define XT_PSTRIDE 1024          // distance between the p.t, r.t and t.t partial arrays
+// the three dot products of an iteration from one pass over p, r, t: p.t gives alpha; r.t and t.t give r'.r' = r.r + 2 alpha r.t +
+// alpha^2 t.t for r' = r + alpha t WITHOUT a second global reduction, so that the vector update and the new direction fit in
+// one kernel (k_xt_step).  The identity is exact for the r' actually formed (it does not assume conjugacy).
+// block sums of NV values with one LDS round (two barriers), fixed order; red4: [XT_NT / 64][4] doubles
+template <int NV>
+__device__ __forceinline__ void xt_block_sums(double (&v)[NV], double (*red4)[4])
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) v[u] = wave_sum(v[u]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int u = 0; u < NV; ++u) red4[w][u] = v[u];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < NV; ++u) { double s = 0.0; for (int i = 0; i < XT_NT / 64; ++i) s += red4[i][u]; v[u] = s; }
+}
+__device__ __forceinline__ void xt_dots_write(double a_pt, double a_rt, double a_tt, double (*red4)[4], double *part)
+{
+    double v[3] = {a_pt, a_rt, a_tt};
+    xt_block_sums<3>(v, red4);
+    if (threadIdx.x == 0) { part[blockIdx.x] = v[0]; part[XT_PSTRIDE + blockIdx.x] = v[1]; part[2 * XT_PSTRIDE + blockIdx.x] = v[2]; }
+}
 template <int MODE>
 __global__ __launch_bounds__(XT_NT) void k_xt_rows(int ns, int nK, int nW, int ns_pad, const int2 *__restrict__ wrange, const int *__restrict__ nitem_w,
                                                    const double *__restrict__ rowpart, const double *__restrict__ colpart,
                                                    const int *__restrict__ srow, const double *__restrict__ sS, const double *__restrict__ pvec,
                                                    double *__restrict__ t, double *__restrict__ part, const XCtrl *ctrl, double *__restrict__ xout,
-                                                   int m, const int *__restrict__ nsrank, int flag_rank0)
+                                                   int m, const int *__restrict__ nsrank, int flag_rank0, const double *__restrict__ rvec)
 {
-    __shared__ double red[XT_NT / 64];
+    __shared__ double red[XT_NT / 64][4];
     __shared__ double sl_sum[8][XT_R];
     __shared__ int sdone;
+    double acc = 0.0, arr = 0.0, att = 0.0;
+    // Everything that does not depend on the partial sums is fetched first -- the S rows' own entries (row index, scale, sparse
+    // sum, p, r) and this workgroup's share of the non-S rows for the dot products -- so that the dependent chain of the launch is
+    // flag -> partial sums -> store instead of flag -> partial sums -> row index -> vectors -> store.
+    const int chunk = (m + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int i0 = blockIdx.x * chunk, i1 = min(m, i0 + chunk);
+    const int ifirst = i0 + (int)threadIdx.x;
+    double fp = 0.0, ft = 0.0, fr = 0.0; int fs = 0;
+    if (MODE == 0 && ifirst < i1) { fs = nsrank[ifirst]; fp = pvec[ifirst]; ft = t[ifirst]; fr = rvec[ifirst]; }
+    int row0 = -1; double s0 = 0.0, t0 = 0.0, p0 = 0.0, r0 = 0.0;
+    {
+        const int s = XT_R * (int)blockIdx.x + (int)threadIdx.x;
+        if (MODE == 0 && (int)blockIdx.x < nK && threadIdx.x < XT_R && s < ns) { row0 = srow[s]; s0 = sS[s]; t0 = t[row0]; p0 = pvec[row0]; r0 = rvec[row0]; }
+    }
     if (ctrl) {
         if (threadIdx.x == 0) sdone = ctrl->done;
         __syncthreads();
         if (sdone) return;
     }
-    double acc = 0.0;
     for (int k = blockIdx.x; k < nK; k += gridDim.x) {
         const double sum = xt_row_block_sum(k, nW, ns_pad, wrange, nitem_w, rowpart, colpart, sl_sum);
         const int s = XT_R * k + (int)threadIdx.x;
         if (threadIdx.x < XT_R && s < ns) {
             if (MODE == 1) xout[s] = sum;
-            else { const int row = srow[s]; const double tv = sS[s] * (t[row] + sum); t[row] = tv; acc += pvec[row] * tv; }
+            else if (k == (int)blockIdx.x) { const double tv = s0 * (t0 + sum); t[row0] = tv; acc += p0 * tv; arr += r0 * tv; att += tv * tv; }
+            else { const int row = srow[s]; const double tv = sS[s] * (t[row] + sum); t[row] = tv; acc += pvec[row] * tv; arr += rvec[row] * tv; att += tv * tv; }
         }
     }
     if (MODE == 1) {
         if (ctrl && blockIdx.x == 0 && threadIdx.x == 0) xout[ns] = (flag_rank0 && ctrl->done_local) ? 1.0 : 0.0;   // the stop decision rides in the all-reduce
         return;
     }
-    // p.t over the non-S rows of this workgroup's share of the vector
-    const int chunk = (m + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int i0 = blockIdx.x * chunk, i1 = min(m, i0 + chunk);
-    for (int i = i0 + threadIdx.x; i < i1; i += XT_NT) if (nsrank[i] < 0) acc += pvec[i] * t[i];
-    const double tot = block_sum_all<XT_NT>(acc, red);
-    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+    // the non-S rows of this workgroup's share of the vector
+    if (ifirst < i1 && fs < 0) { acc += fp * ft; arr += fr * ft; att += ft * ft; }
+    for (int i = ifirst + XT_NT; i < i1; i += XT_NT) if (nsrank[i] < 0) { const double tv = t[i]; acc += pvec[i] * tv; arr += rvec[i] * tv; att += tv * tv; }
+    xt_dots_write(acc, arr, att, red, part);
 }
-// sharded solve, after the all-reduce of xout: finish the S rows, then the same p.t partials as MODE 0
+// sharded solve, after the all-reduce of xout: finish the S rows, then the same partials as MODE 0
 __global__ __launch_bounds__(XT_NT) void k_xt_rows_apply(int ns, int nK, const double *__restrict__ xbuf, const int *__restrict__ srow,
                                                          const double *__restrict__ sS, const double *__restrict__ pvec, double *__restrict__ t,
-                                                         double *__restrict__ part, XCtrl *ctrl, int m, const int *__restrict__ nsrank)
+                                                         double *__restrict__ part, XCtrl *ctrl, int m, const int *__restrict__ nsrank,
+                                                         const double *__restrict__ rvec)
 {
-    __shared__ double red[XT_NT / 64];
+    __shared__ double red[XT_NT / 64][4];
     __shared__ int sdone;
     if (threadIdx.x == 0) sdone = ctrl->done || xbuf[ns] != 0.0;     // xbuf[ns]: rank 0's stop decision, identical on every rank
     __syncthreads();
     if (sdone) { if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->done = 1; return; }
-    double acc = 0.0;
+    double acc = 0.0, arr = 0.0, att = 0.0;
     for (int k = blockIdx.x; k < nK; k += gridDim.x) {
         const int s = XT_R * k + (int)threadIdx.x;
-        if (threadIdx.x < XT_R && s < ns) { const int row = srow[s]; const double tv = sS[s] * (t[row] + xbuf[s]); t[row] = tv; acc += pvec[row] * tv; }
+        if (threadIdx.x < XT_R && s < ns) { const int row = srow[s]; const double tv = sS[s] * (t[row] + xbuf[s]); t[row] = tv; acc += pvec[row] * tv; arr += rvec[row] * tv; att += tv * tv; }
     }
     const int chunk = (m + (int)gridDim.x - 1) / (int)gridDim.x;
     const int i0 = blockIdx.x * chunk, i1 = min(m, i0 + chunk);
-    for (int i = i0 + threadIdx.x; i < i1; i += XT_NT) if (nsrank[i] < 0) acc += pvec[i] * t[i];
-    const double tot = block_sum_all<XT_NT>(acc, red);
-    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+    for (int i = i0 + threadIdx.x; i < i1; i += XT_NT) if (nsrank[i] < 0) { const double tv = t[i]; acc += pvec[i] * tv; arr += rvec[i] * tv; att += tv * tv; }
+    xt_dots_write(acc, arr, att, red, part);
 }
 
 // ---- vector kernels of the CG (sign convention and stop tests of solve_sparse_CG_Jacobi, iterative_solvers_gpu.cu:349-459) ----
-__device__ __forceinline__ double xt_reduce(const double *part, int n, double *red, const XCtrl *ctrl, bool *done)
-{
-    __shared__ int sdone;
-    if (threadIdx.x == 0) sdone = ctrl->done;
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += XT_NT) s += part[i];
-    s = block_sum_all<XT_NT>(s, red);
-    *done = sdone != 0;
-    return s;
-}
 // diag -= tile row sums (S rows); s = 1/sqrt(diag); b *= s; y /= s; q = s * y (= the caller's y); compact copies over S
 __global__ void k_xt_scale_init(int Nsub, const xrp_t *__restrict__ diag_pos, double *__restrict__ val, const int *__restrict__ nsrank,
                                 const double *__restrict__ tsum, double *__restrict__ sc, double *__restrict__ b, double *__restrict__ y,
@@ -511,44 +541,73 @@ __global__ __launch_bounds__(XT_NT) void k_xt_check0(const double *part, int npa
     const double rr = block_sum_all<XT_NT>(s, red);
     if (threadIdx.x == 0) { ctrl->rr[0] = rr; ctrl->rr[1] = rr; ctrl->iters = 0; const int d = !(sqrt(rr) > tol2); if (ctrl->sharded) ctrl->done_local = d; else ctrl->done = d; }
 }
-// alpha = rr / p.t ; y += alpha p ; r += alpha t ; partial r.r
-__global__ __launch_bounds__(XT_NT) void k_xt_update(int m, int it, const double *__restrict__ part_pt, int npart, const double *__restrict__ p,
-                                                     const double *__restrict__ t, double *__restrict__ y, double *__restrict__ r,
-                                                     double *__restrict__ part_rr, const XCtrl *ctrl)
+// One kernel per iteration for everything after the matrix-vector product:
+//   alpha = r.r / p.t ; y += alpha p ; r' = r + alpha t ; beta = r'.r' / r.r ; p = beta p - r' ; q = s p ; stop test on r'.r'
+// (solve_sparse_CG_Jacobi, iterative_solvers_gpu.cu:424-455).  r.r is the DIRECT sum of squares of the current r (partials of the
+// previous launch of this kernel, double-buffered); r'.r' -- needed for beta before r' exists everywhere -- is formed as
+// r.r + 2 alpha r.t + alpha^2 t.t from the partials of the row kernel (exact for the r' formed here; rounding ~1e-16 r.r, the
+// same order as regrouping a sum).  The reference's separate update / direction passes need two global reductions for this.
+__global__ __launch_bounds__(XT_NT) void k_xt_step(int m, int it, const double *__restrict__ part3, int npart, const double *__restrict__ part_rr_in,
+                                                   int npart_rr, double *__restrict__ part_rr_out, double *__restrict__ p,
+                                                   const double *__restrict__ t, double *__restrict__ y, double *__restrict__ r,
+                                                   const double *__restrict__ sc, double *__restrict__ q, const int *__restrict__ nsrank,
+                                                   double *__restrict__ qS, XCtrl *ctrl, double tol2)
 {
-    __shared__ double red[XT_NT / 64];
-    bool done;
-    const double pAp = xt_reduce(part_pt, npart, red, ctrl, &done);
-    if (done) return;
-    const double alpha = ctrl->rr[it & 1] / pAp;
+    __shared__ double red[XT_NT / 64][4];
+    __shared__ int sdone;
+    if (threadIdx.x == 0) sdone = ctrl->done;
+    // the first four elements of this thread are fetched before the partial sums are reduced: their latency hides behind the
+    // reduction chain (one element batch covers the whole vector unless the grid is capped)
+    const int stride = gridDim.x * XT_NT, i0 = blockIdx.x * XT_NT + threadIdx.x;
+    double pv[4], tv[4], yv[4], rv[4], sv[4]; int srk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * stride;
+        const bool ok = i < m;
+        pv[u] = ok ? p[i] : 0.0; tv[u] = ok ? t[i] : 0.0; yv[u] = ok ? y[i] : 0.0; rv[u] = ok ? r[i] : 0.0; sv[u] = ok ? sc[i] : 0.0;
+        srk[u] = ok ? nsrank[i] : -1;
+    }
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < npart; i += XT_NT) { a[0] += part3[i]; a[1] += part3[XT_PSTRIDE + i]; a[2] += part3[2 * XT_PSTRIDE + i]; }
+    for (int i = threadIdx.x; i < npart_rr; i += XT_NT) a[3] += part_rr_in[i];
+    xt_block_sums<4>(a, red);
+    if (sdone) return;
+    const double pAp = a[0], rt = a[1], tt = a[2], rr = a[3];
+    const double alpha = rr / pAp;
+    const double rr_new = rr + 2.0 * alpha * rt + alpha * alpha * tt;
+    const double beta = rr_new / rr;
     double acc = 0.0;
-    for (int i = blockIdx.x * XT_NT + threadIdx.x; i < m; i += gridDim.x * XT_NT) {
-        y[i] += alpha * p[i];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * stride;
+        if (i < m) {
+            y[i] = yv[u] + alpha * pv[u];
+            const double rn = rv[u] + alpha * tv[u];
+            r[i] = rn;
+            acc += rn * rn;
+            const double pn = pv[u] * beta - rn;
+            p[i] = pn;
+            const double qv = sv[u] * pn;
+            q[i] = qv;
+            if (srk[u] >= 0) qS[srk[u]] = qv;
+        }
+    }
+    for (int i = i0 + 4 * stride; i < m; i += stride) {
+        const double pw = p[i];
+        y[i] += alpha * pw;
         const double rn = r[i] + alpha * t[i];
         r[i] = rn;
         acc += rn * rn;
-    }
-    const double tot = block_sum_all<XT_NT>(acc, red);
-    if (threadIdx.x == 0) part_rr[blockIdx.x] = tot;
-}
-// beta = rr' / rr ; p = beta p - r ; q = s p ; stop test on rr'
-__global__ __launch_bounds__(XT_NT) void k_xt_direction(int m, int it, const double *__restrict__ part_rr, int npart, const double *__restrict__ r,
-                                                        double *__restrict__ p, const double *__restrict__ sc, double *__restrict__ q,
-                                                        const int *__restrict__ nsrank, double *__restrict__ qS, XCtrl *ctrl, double tol2)
-{
-    __shared__ double red[XT_NT / 64];
-    bool done;
-    const double rr_new = xt_reduce(part_rr, npart, red, ctrl, &done);
-    if (done) return;
-    const double beta = rr_new / ctrl->rr[it & 1];
-    for (int i = blockIdx.x * XT_NT + threadIdx.x; i < m; i += gridDim.x * XT_NT) {
-        const double pn = p[i] * beta - r[i];
+        const double pn = pw * beta - rn;
         p[i] = pn;
         const double qv = sc[i] * pn;
         q[i] = qv;
         const int sr = nsrank[i];
         if (sr >= 0) qS[sr] = qv;
     }
+    double av[1] = {acc};
+    xt_block_sums<1>(av, red);
+    if (threadIdx.x == 0) part_rr_out[blockIdx.x] = av[0];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctrl->rr[(it + 1) & 1] = rr_new;
         ctrl->iters = it + 1;
@@ -641,7 +700,7 @@ static int xt_tile_sums(const double *vS, double *out, int vpos)
     hipLaunchKernelGGL((k_xt_rows<1>), dim3(xt_grid(X.nK, 1, 1024)), dim3(XT_NT), 0, st, X.ns, X.nK, X.nW, X.ns_pad, (const int2 *)g_xb.wrange,
                        (const int *)g_xb.nitem_w, (const double *)g_xb.rowpart, (const double *)g_xb.colpart, (const int *)nullptr,
                        (const double *)nullptr, (const double *)nullptr, (double *)nullptr, (double *)nullptr, (const XCtrl *)nullptr, out,
-                       0, (const int *)nullptr, 0);
+                       0, (const int *)nullptr, 0, (const double *)nullptr);
     KCHK();
     if (comm_attached()) { int rc = comm_allreduce_sum_f64(out, (size_t)X.ns); if (rc) return rc; }
     return 0;
@@ -791,7 +850,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
     if (!sc || !r || !p || !t || !q || !vS || !part || !ctrl) return e.err_code;
     double *qS = vS, *sS = vS + ns_pad, *xS = vS + 2 * (size_t)ns_pad;
     HIPCHK(hipMemsetAsync(vS, 0, (size_t)ns_pad * 3 * 8, st));
-    double *part_pt = part, *part_rr = part + 4096;
+    double *part_pt = part, *part_rr = part + 4096;          // p.t | r.t | t.t partials (XT_PSTRIDE apart); r.r partials, double-buffered (512 apart)
     const double tol2 = e.cg_tol * e.cg_tol;
 
     // ---- diagonal: -(row sums of T), one pass with the vector of ones ----
@@ -822,15 +881,15 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         if (sharded && ns > 0) {
             hipLaunchKernelGGL((k_xt_rows<1>), dim3(n2b), dim3(XT_NT), 0, st, ns, nK, nW, ns_pad, (const int2 *)wrange, (const int *)nitem_w, (const double *)rowpart,
                                (const double *)colpart, (const int *)srow, (const double *)sS, (const double *)p, t, part_pt, (const XCtrl *)ctrl, xbuf,
-                               m, (const int *)nsrank, comm_rank() == 0 ? 1 : 0);
+                               m, (const int *)nsrank, comm_rank() == 0 ? 1 : 0, (const double *)r);
             if (int rcx = comm_allreduce_sum_f64(xbuf, (size_t)ns + 1)) return rcx;          // |S| row sums + rank 0's stop decision
             if (ec) HIPCHK(hipEventRecord(ec, st));
             hipExtLaunchKernelGGL(k_xt_rows_apply, dim3(n2b), dim3(XT_NT), 0, st, e2, e3, 0, ns, nK, (const double *)xbuf, (const int *)srow, (const double *)sS,
-                                  (const double *)p, t, part_pt, ctrl, m, (const int *)nsrank);
+                                  (const double *)p, t, part_pt, ctrl, m, (const int *)nsrank, (const double *)r);
         } else
             hipExtLaunchKernelGGL((k_xt_rows<0>), dim3(n2b), dim3(XT_NT), 0, st, e2, e3, 0, ns, nK, nW, ns_pad, (const int2 *)wrange, (const int *)nitem_w,
                                   (const double *)rowpart, (const double *)colpart, (const int *)srow, (const double *)sS, (const double *)p, t,
-                                  part_pt, (const XCtrl *)ctrl, (double *)nullptr, m, (const int *)nsrank, 0);
+                                  part_pt, (const XCtrl *)ctrl, (double *)nullptr, m, (const int *)nsrank, 0, (const double *)r);
         return 0;
     };
 
@@ -872,9 +931,8 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
             loop_rc = matvec(pb ? evs[4 * b] : nullptr, pb ? evs[4 * b + 1] : nullptr, pb ? evs[4 * b + 2] : nullptr, pb ? evs[4 * b + 3] : nullptr,
                              pb ? evc[b / XT_PROF_STRIDE] : nullptr);
             if (loop_rc) break;
-            hipLaunchKernelGGL(k_xt_update, dim3(gv), dim3(XT_NT), 0, st, m, it, (const double *)part_pt, np_pt, (const double *)p, (const double *)t, y, r, part_rr, (const XCtrl *)ctrl);
-            hipLaunchKernelGGL(k_xt_direction, dim3(gv), dim3(XT_NT), 0, st, m, it, (const double *)part_rr, gv, (const double *)r, p, (const double *)sc, q,
-                               (const int *)nsrank, qS, ctrl, tol2);
+            hipLaunchKernelGGL(k_xt_step, dim3(gv), dim3(XT_NT), 0, st, m, it, (const double *)part_pt, np_pt, (const double *)(part_rr + 512 * (it & 1)), gv,
+                               part_rr + 512 * ((it + 1) & 1), p, (const double *)t, y, r, (const double *)sc, q, (const int *)nsrank, qS, ctrl, tol2);
         }
         launched = batch;
         KCHK();

@@ -89,11 +89,46 @@ struct TCacheState {
     double *metal_cb = nullptr, *slot_cb = nullptr, *vals = nullptr;
     int2 *queue = nullptr;
 };
-static TCacheState g_tc;
+// Solver state that outlives a call -- the coefficient cache and the private warm-start copy -- is kept PER GPUBuffers (keyed by
+// its site_x array), so that several devices in one process (e.g. one per crossbar cell) do not share or thrash it.  Up to 8
+// buffers, least recently used one evicted.  The engine's scratch buffers are shared: they carry nothing across calls.
+struct XBufState { const void *key = nullptr; TCacheState tc; double *warm = nullptr; int warm_n = 0; unsigned long long stamp = 0; };
+static XBufState g_states[8];
+static XBufState *g_cur = &g_states[0];
+static unsigned long long g_stamp = 0;
+#define g_tc (g_cur->tc)
+#define g_warm (g_cur->warm)
+#define g_warm_n (g_cur->warm_n)
 static const int g_tc_enabled = getenv("DKMC_NO_TCACHE") ? 0 : 1;
 
-void tcache_invalidate() { g_tc.valid = 0; }     // new structure / new bias point (potential.hip)
+static XBufState *xstate_find(const void *key) { for (auto &st : g_states) if (st.key == key && key) return &st; return nullptr; }
+void tcache_invalidate(const void *key) { if (XBufState *st = xstate_find(key)) st->tc.valid = 0; }     // new bias point (potential.hip)
 
+static void tc_release();
+// new structure behind the same buffer (initialize_sparsity) or buffer freed: drop everything kept for it
+void xstate_reset(const void *key)
+{
+    XBufState *st = xstate_find(key);
+    if (!st) return;
+    XBufState *save = g_cur; g_cur = st;
+    (void)hipStreamSynchronize(eng().stream);
+    tc_release();
+    if (st->warm) (void)hipFree(st->warm);
+    *st = XBufState();
+    g_cur = save;
+}
+static void xstate_select(const void *key)
+{
+    XBufState *st = xstate_find(key);
+    if (!st) {
+        st = &g_states[0];
+        for (auto &c : g_states) { if (!c.key) { st = &c; break; } if (c.stamp < st->stamp) st = &c; }
+        if (st->key) xstate_reset(st->key);
+        st->key = key;
+    }
+    st->stamp = ++g_stamp;
+    g_cur = st;
+}
 static void tc_release()
 {
     void *ptrs[] = { g_tc.slot_of_site, g_tc.mrank_atom, g_tc.metal_atom, g_tc.ctr, g_tc.metal_cb, g_tc.slot_cb, g_tc.vals, g_tc.queue };
@@ -247,7 +282,6 @@ __global__ void k_iota_rows(int n, int *rows)
 
 // state of the last call (for dkmc_get_last_X and the private warm start)
 static int g_last_rows = 0; static long long g_last_nnz = 0; static bool g_last_tiled = false;
-static double *g_warm = nullptr; static int g_warm_n = 0;
 
 extern "C" int dkmc_update_power_gpu_sparse(dkmc_gpubuf *buf, int n_src, int n_gnd, int nlc, double Vd, int pbc,
                                             double high_G, double low_G, double loop_G, double G0, double tol, double nn_dist,
@@ -256,6 +290,7 @@ extern "C" int dkmc_update_power_gpu_sparse(dkmc_gpubuf *buf, int n_src, int n_g
 {
     Engine &e = eng(); hipStream_t st = e.stream;
     const int N = buf->N_, nn = buf->nn_;
+    xstate_select(buf->site_x);
     if (nn > 64) return dkmc_fail(11, "update_power: more than 64 neighbours per site is not supported", __FILE__, __LINE__);
     MetalSet ms = load_metals(buf->metal_types, num_metals);
     // ---- 1. atoms ----

@@ -3,6 +3,7 @@
 #include <stdlib.h>
 
 int events_upload_layers();      // events.hip
+void xstate_reset(const void *key);   // current.hip
 
 static Engine g_engine;
 Engine &eng() { return g_engine; }
@@ -101,6 +102,7 @@ int dkmc_gpubuf_create(dkmc_gpubuf *buf, int N, int N_atom, int nn, int nmt,
 
 int dkmc_gpubuf_free(dkmc_gpubuf *b)
 {
+    xstate_reset(b->site_x);
     void *ptrs[] = { b->site_charge, b->site_power, b->site_potential_boundary, b->site_potential_charge, b->site_temperature,
                      b->site_CB_edge, b->T_bg, b->atom_power, b->atom_CB_edge, b->atom_virtual_potentials, b->atom_charge,
                      b->site_element, b->atom_element, b->site_x, b->site_y, b->site_z, b->atom_x, b->atom_y, b->atom_z,

@@ -6,7 +6,8 @@
 int kcg_assemble_and_solve(int cb, int m, int N_left, const int *element, const int *charge, MetalSet ms, double high_G, double low_G,
                            const int *rp, const int *ci, int nnz, const int *lrp, const int *lci, const int *rrp, const int *rci,
                            double VL, double VR, double *y, int *iters_out, double *rr_out);
-void tcache_invalidate();
+void tcache_invalidate(const void *key);
+void xstate_reset(const void *key);
 
 // ------------------------------------------------------------------------------------------------
 // update_charge (potential_solver_gpu.cu:10-52).  One thread per site; only vacancies and oxygen
@@ -104,7 +105,7 @@ __global__ void k_set_last(int *rp, int m, const int *total) { if (threadIdx.x =
 extern "C" int dkmc_initialize_sparsity(dkmc_gpubuf *buf, int pbc, double nn_dist, int num_atoms_contact)
 {
     (void)pbc; (void)nn_dist;
-    tcache_invalidate();
+    xstate_reset(buf->site_x);
     Engine &e = eng(); hipStream_t st = e.stream;
     const int N = buf->N_, nn = buf->nn_, N_left = num_atoms_contact, m = N - 2 * num_atoms_contact;
     if (m <= 0) return dkmc_fail(5, "initialize_sparsity: no device rows", __FILE__, __LINE__);
@@ -184,7 +185,7 @@ extern "C" int dkmc_update_CB_edge_gpu_sparse(dkmc_gpubuf *buf, int N, int N_lef
                                               double high_G, double low_G, double nn_dist, int num_metals)
 {
     (void)pbc; (void)nn_dist;
-    tcache_invalidate();
+    tcache_invalidate(buf->site_x);
     Engine &e = eng();
     int rc = solve_K(buf, N, N_left, N_right, Vd / 2, -Vd / 2, 1, high_G, low_G, num_metals, buf->site_CB_edge,
                      &e.stats.cg_iters_CB, &e.stats.cg_rr_CB);

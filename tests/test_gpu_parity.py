@@ -786,3 +786,41 @@ def test_restart_continues_the_same_event_sequence(cell_2p5, hip, tmp_path):
     for a, b in zip(full[3:], rest):
         assert np.array_equal(a[0], b[0])
         assert a[1:] == b[1:], (a[1:], b[1:])
+
+
+def test_two_devices_in_one_process_keep_their_own_solver_state(cell_2p5, hip):
+    """Two GPUBuffers of the same size alive in one process, stepped alternately (the "one device per crossbar cell" use): the
+    coefficient cache and the private warm-start copy are kept per GPUBuffers, so each trajectory equals the one of a process
+    that runs that device alone -- bit for bit, also with dkmc_set_current_warm_start(1)."""
+    from devicekmc_amd import params as pm
+    host, L = hip
+    pa = pm.KMCParameters(); pa.solve_heating_global = True
+    pb = pm.KMCParameters(); pb.solve_heating_global = True; pb.rnd_seed = 7; pb.rnd_seed_kmc = 3
+    VA, VB = 5.0, 3.0
+
+    def make(p, V):
+        dev = host.Device(cell_2p5, p); sim = host.KMCProcess(dev, p.freq); gb = dev.make_gpubuf("cuda:0")
+        dev.setLaplacePotential(gb, p, V); gb.sync_HostToGPU(dev)
+        return dev, sim, gb
+
+    def step(dev, sim, gb, p, V, k):
+        dev.updateCharge(gb); dev.updatePotential(gb, p, V, k)
+        _, dt = sim.executeKMCStep(gb, dev)
+        dev.updatePower(gb, p, V); dev.updateTemperature(gb, p, dt)
+        return (dt, dev.imacro, dev.T_bg)
+
+    try:
+        L.dkmc_set_current_warm_start(1)
+        alone = {}
+        for name, p, V in (("a", pa, VA), ("b", pb, VB)):
+            d = make(p, V)
+            alone[name] = [step(*d, p, V, k) for k in range(3)]
+            del d
+        da, db = make(pa, VA), make(pb, VB)
+        both = {"a": [], "b": []}
+        for k in range(3):
+            both["a"].append(step(*da, pa, VA, k))
+            both["b"].append(step(*db, pb, VB, k))
+        assert both["a"] == alone["a"] and both["b"] == alone["b"]
+    finally:
+        L.dkmc_set_current_warm_start(0)

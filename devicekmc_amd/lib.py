@@ -75,6 +75,7 @@ SYMBOLS = {
     "dkmc_background_potential_gpu_sparse": (_I, [C.POINTER(dkmc_gpubuf), _I, _I, _I, _D, _I, _D, _D, _D, _I, _I]),
     "dkmc_poisson_gridless_gpu": (_I, [_I, _I, _I, vp, vp, vp, vp, vp, vp, vp, vp]),
     "dkmc_solve_sparse_CG_Jacobi": (_I, [vp, vp, vp, _I, _I, vp, vp, c_int_p, c_dbl_p]),
+    "dkmc_solve_sparse_CG_splitmatrix": (_I, [vp, _I, vp, vp, vp, _I, _I, vp, _I, vp, vp, _D, c_int_p, c_dbl_p]),
     "dkmc_execute_kmc_step_gpu": (_I, [_I, _I, vp, vp, vp, _I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                        vp, _I, _I, c_int_p, c_int_p, vp, c_dbl_p]),
     "dkmc_build_event_list": (_I, [_I, _I, vp, vp, vp, _I, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

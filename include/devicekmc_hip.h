@@ -180,6 +180,15 @@ int dkmc_solve_sparse_CG_Jacobi(double *d_A_data, const int *d_A_row_ptr, const 
                                 int A_nnz, int m, double *d_x, double *d_y, int *iters_out, double *rr_out);
 
 /* ---- KMC events: execute_kmc_step_gpu (kmc_events.cu:146-365) ------------------------------- */
+/* solve_sparse_CG_splitmatrix (iterative_solvers_gpu.cu:656-821; unfinished in the reference: it prints the solution and calls
+ * exit(1)) with add_submatrix_product (:634-652): UNPRECONDITIONED CG on (A + P^T M P) y = x, A in CSR (m rows), M dense msub x msub
+ * (row-major, device), (P v)_k = v[insertion_indices[k] + index_offset] (the reference hard-codes + 2: node = atom + 2).  Loop while
+ * ||r||_2 > tol (1e-5 in the source).  A and M are read only; y: start vector in, solution out.  The product's own current solve
+ * keeps the dense block as symmetric tiles instead (dkmc_set_x_format(1)); this entry point completes the reference's split API. */
+int dkmc_solve_sparse_CG_splitmatrix(const double *d_M, int msub, const double *d_A_data, const int *d_A_row_ptr, const int *d_A_col_indices,
+                                     int A_nnz, int m, const int *d_insertion_indices, int index_offset, const double *d_x, double *d_y,
+                                     double tol, int *iters_out, double *rnorm_out);
+
 /* The reference draws two numbers per executed event from the host RandomNumberGenerator
  * (kmc_events.cu:221,348).  Here the caller passes the next n_uniform numbers of that stream
  * (h_uniform[2e] selects event e, h_uniform[2e+1] draws its waiting time); *n_events_out tells how

@@ -70,6 +70,14 @@ DKMC_SHIM_API void solve_sparse_CG_Jacobi(dkmc_handle_t, dkmc_handle_t, double *
     GPUBuffers::report(dkmc_solve_sparse_CG_Jacobi(A_data, A_row_ptr, A_col_indices, A_nnz, m, d_x, d_y, nullptr, nullptr));
 }
 
+// declared at gpu_solvers.h:66 of the reference; there the body ends in exit(1) and the caller (update_power_gpu_split) is never reached
+DKMC_SHIM_API void solve_sparse_CG_splitmatrix(dkmc_handle_t, dkmc_handle_t, double *M, int msub, double *A_data, int *A_row_ptr, int *A_col_indices,
+                                               const int A_nnz, int m, int *insertion_indices, double *d_x, double *d_y)
+{
+    GPUBuffers::report(dkmc_solve_sparse_CG_splitmatrix(M, msub, A_data, A_row_ptr, A_col_indices, A_nnz, m, insertion_indices, 2, d_x, d_y, 1e-5,
+                                                        nullptr, nullptr));
+}
+
 DKMC_SHIM_API double execute_kmc_step_gpu(const int N, const int nn, const int *neigh_idx, const int *site_layer, const double *lattice,
                                    const int pbc, const double *T_bg, const double *freq, const double *sigma, const double *k,
                                    const double *posx, const double *posy, const double *posz, const double *site_potential_boundary,

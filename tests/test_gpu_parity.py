@@ -824,3 +824,46 @@ def test_two_devices_in_one_process_keep_their_own_solver_state(cell_2p5, hip):
         assert both["a"] == alone["a"] and both["b"] == alone["b"]
     finally:
         L.dkmc_set_current_warm_start(0)
+
+
+@pytest.mark.parametrize("offset", [0, 2])
+def test_split_matrix_cg(hip, offset):
+    """solve_sparse_CG_splitmatrix (iterative_solvers_gpu.cu:656-821, unfinished in the reference): unpreconditioned CG on
+    (A + P^T M P) y = x with A in CSR and M dense on an index subset, against a direct solve of the assembled system.  Ragged CSR
+    rows, an odd dense-block size (unaligned rows of M), a warm start; offset 2 = the reference's node = atom + 2 convention."""
+    import ctypes as C
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    import torch
+    host, L = hip
+    rng = np.random.default_rng(5 + offset)
+    m, msub = 4000, 777
+    B = sp.random(m, m, density=3e-3, random_state=3, data_rvs=rng.standard_normal).tocsr()
+    A = (B + B.T) * 0.1
+    A = (A + sp.diags(np.abs(A).sum(axis=1).A1 + 1.0)).tocsr()           # symmetric, diagonally dominant
+    A.sort_indices()
+    G = rng.standard_normal((msub, 40))
+    M = G @ G.T / 40.0 + 0.05 * rng.standard_normal((msub, msub)); M = 0.5 * (M + M.T) + 2.0 * np.eye(msub)      # symmetric positive definite
+    idx = np.sort(rng.choice(m - offset, msub, replace=False)).astype(np.int32)
+    P = sp.csr_matrix((np.ones(msub), (np.arange(msub), idx + offset)), shape=(msub, m))
+    full = (A + P.T @ sp.csr_matrix(M) @ P).tocsc()
+    x = rng.standard_normal(m)
+    want = spl.spsolve(full, x)
+    dev = torch.device("cuda:0")
+    tt = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a, dtype=dt)).to(dev)
+    dA, drp, dci, dM, didx, dx = tt(A.data, np.float64), tt(A.indptr, np.int32), tt(A.indices, np.int32), tt(M, np.float64), tt(idx, np.int32), tt(x, np.float64)
+    dy = tt(0.5 * want + 0.1 * rng.standard_normal(m), np.float64)      # some start vector
+    it, rn = C.c_int(0), C.c_double(0.0)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    tol = 1e-9
+    from devicekmc_amd.lib import check
+    check(L.dkmc_set_stream(C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
+    check(L.dkmc_solve_sparse_CG_splitmatrix(ptr(dM), msub, ptr(dA), ptr(drp), ptr(dci), A.nnz, m, ptr(didx), offset, ptr(dx), ptr(dy), tol,
+                                              C.byref(it), C.byref(rn)))
+    torch.cuda.synchronize()
+    got = dy.cpu().numpy()
+    assert 0 < it.value < 2000 and rn.value <= tol
+    assert np.linalg.norm(full @ got - x) <= 10 * tol                   # the true residual meets the stop test
+    assert np.abs(got - want).max() <= 1e-8 * np.abs(want).max()
+    # inputs are read only
+    assert np.array_equal(dM.cpu().numpy(), M) and np.array_equal(dA.cpu().numpy(), A.data) and np.array_equal(dx.cpu().numpy(), x)

@@ -1,17 +1,18 @@
-// comm.hip -- the one exchange step of the multi-GPU current solve (SURVEY 8e, row "X-CG").
+// comm.hip -- the exchange step of the multi-GPU current solve (SURVEY 8e, row "X-CG").
 //
 // The reference is single-GPU.  Here N processes (one per GPU) advance the SAME simulation in lockstep; every phase is
-// computed redundantly and identically on every rank except the dominant one, the matrix stream of A*p in the CG solve of
-// X (cg.hip, k_spmv_segs).  Two variants, one collective per CG iteration each:
-//   * symmetric tiles (default): the tiles are dealt to the ranks in equal contiguous shares, the leftover segments by rows;
-//     every rank forms the partial sum of every long row from what it owns and ONE in-place all-reduce (8 B per long row)
-//     completes them.  All ranks receive the same bits (lockstep-safe); the result equals the single-GPU one to rounding.
-//   * runs only (dkmc_set_symmetric_tiles(0)): the long rows are dealt to the ranks at row boundaries, balanced by segment
-//     count; a rank multiplies the segments of its rows and adds them per row; one in-place all-gather hands every rank
-//     every row sum.  Values and summation orders are those of the single-GPU kernels: bit-identical to the single-GPU run.
-// Everything downstream (dot products, vector updates, stop test) is again computed identically everywhere.  Consequences: the result is bit-identical to the single-GPU result, all ranks take the same control
-// decisions (no rank can leave the iteration loop while another waits in the collective), and no dot-product all-reduce
-// is needed.
+// computed redundantly and identically on every rank except the dominant one, the matrix stream of A*p in the CG solve of X.
+// Two variants, one collective per matrix-vector product each:
+//   * tiled X (xt.hip, default): the work items (runs of tiles of the tunnelling block) are dealt to the ranks in contiguous,
+//     byte-balanced shares; a rank generates, stores and streams only its tiles, forms its partial sum of every S-row and ONE
+//     in-place all-reduce (|S| + 1 doubles: the row sums and rank 0's stop decision) completes them.  Every rank receives the
+//     same bits and takes its control decisions from that buffer alone, so no rank can leave the iteration loop while another
+//     waits in the collective.  The result equals the single-GPU one to rounding (the all-reduce regroups the sums).
+//   * CSR X (cg.hip, dkmc_set_x_format(0)): the long rows are dealt to the ranks at row boundaries, balanced by segment count; a
+//     rank multiplies the segments of its rows and adds them per row; one in-place all-gather hands every rank every row sum.
+//     Values and summation orders are those of the single-GPU kernels: bit-identical to the single-GPU run.  (This variant
+//     relies on every rank computing identical dot products from identical data; it carries no flag in the exchange.)
+// Everything downstream (dot products, vector updates) is computed identically everywhere: no dot-product all-reduce is needed.
 //
 // Two transports behind the same call:
 //   * RCCL over xGMI (production): ncclAllGather on the engine's stream.  librccl is opened at run time (dlopen) so that

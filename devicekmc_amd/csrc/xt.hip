@@ -780,7 +780,9 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         if (h2[1] < 0) return dkmc_fail(47, "update_power: more than 2^31 sub-blocks", __FILE__, __LINE__);
     }
     const int ntiles = X.ntiles;
-    X.kc = std::max(1, std::min(XT_MAXKC, ntiles / 4096));
+    // tiles per work item: ~4 k items per GPU.  Measured at 234 975 sites (19 372 tiles): 2 / 4 / 8 / 16 tiles per item -> 198 / 188 / 206 /
+    // 222 us per launch (more items: ~2 us of start-up chain per wave round; fewer: the last waves stream alone, latency-bound)
+    X.kc = std::max(1, std::min(XT_MAXKC, ntiles / (comm_attached() ? comm_nranks() : 1) / 4096));
     X.maxchunk = std::max(1, (nK + X.kc - 1) / X.kc);
     XTile *tiles = (XTile *)scratch(S_XT_TILES, (size_t)(ntiles + 1) * sizeof(XTile));
     int *nitem_w = (int *)scratch(S_XT_NITEMW, (size_t)(nW + 4) * 4 * 2);

@@ -246,12 +246,13 @@ int dkmc_update_temperature_local(dkmc_gpubuf *buf, double step_time, double del
                                   int *n_solves_out, int *steady_out, int *cg_iters_out, double *T_bg_out);
 
 /* ---- multi-GPU: one simulation advanced in lockstep by N processes, one GPU each (no reference counterpart) ----
- * While a communicator is attached, update_power_gpu_sparse deals the matrix stream of A*p of its CG solve to the ranks and
- * completes the long rows' sums with ONE in-place collective per iteration: an all-reduce in the default arithmetic (symmetric
- * tiles; all ranks receive the same bits, the result equals the single-GPU one to rounding), an all-gather with
- * dkmc_set_symmetric_tiles(0) (bit-identical to the single-GPU result).  Every other phase is computed redundantly and identically
- * on every rank, so all ranks hold the same state after every call.  Every rank must make the same sequence of calls with the
- * same inputs.
+ * While a communicator is attached, update_power_gpu_sparse generates, stores and streams the tunnelling block of X in per-rank
+ * shares (tiled X, the default) and completes the S-rows' sums with ONE in-place all-reduce of |S| + 1 doubles per matrix-vector
+ * product; all ranks receive the same bits -- including rank 0's stop decision, from which every rank takes its control flow --
+ * and the result equals the single-GPU one to rounding.  With dkmc_set_x_format(0) (CSR X) the long rows are dealt to the ranks
+ * and an all-gather of row sums keeps the result bit-identical to the single-GPU one.  Every other phase is computed redundantly
+ * and identically on every rank, so all ranks hold the same state after every call.  Every rank must make the same sequence of
+ * calls with the same inputs.
  * Transports: RCCL over xGMI (unique id from rank 0, distributed by the caller), or a host callback that all-gathers a
  * pinned host buffer in place (rehearsal on machines where the ranks share a GPU, which RCCL refuses). */
 enum { DKMC_COMM_NONE = 0, DKMC_COMM_RCCL = 1, DKMC_COMM_HOST = 2 };

@@ -99,7 +99,6 @@ static unsigned long long g_stamp = 0;
 #define g_tc (g_cur->tc)
 #define g_warm (g_cur->warm)
 #define g_warm_n (g_cur->warm_n)
-static const int g_tc_enabled = getenv("DKMC_NO_TCACHE") ? 0 : 1;
 
 static XBufState *xstate_find(const void *key) { for (auto &st : g_states) if (st.key == key && key) return &st; return nullptr; }
 void tcache_invalidate(const void *key) { if (XBufState *st = xstate_find(key)) st->tc.valid = 0; }     // new bias point (potential.hip)
@@ -179,7 +178,6 @@ static int tc_update(const XParams &P, int N, int ns, const SEntry *S, const int
                      const double *ax, const double *ay, const double *az, const double *acb, int n_vac_hint)
 {
     Engine &e = eng(); hipStream_t st = e.stream;
-    if (!g_tc_enabled) { g_tc.valid = 0; return 0; }
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (!g_tc.valid || g_tc.N != N || g_tc.Na != P.Na) { int rc = tc_reset(P, N, aflag, acb, n_vac_hint); if (rc) return rc; if (!g_tc.valid) return 0; }
         int h[4] = {0, 0, 0, 0};

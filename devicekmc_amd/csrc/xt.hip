@@ -213,6 +213,16 @@ __device__ __forceinline__ void xt_tile_role(const XItem it, const XTile *__rest
                                              double *__restrict__ colpart, bool vpos, double *lcol, double *lq)
 {
     const int lane = threadIdx.x & 63, cc = lane & 15, rr = lane >> 4;
+    XTile td; td.k = it.k0; td.w = it.w; td.mask = it.mask0; td.soff = it.soff0;
+#define XT_LD(dst, slot) _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) dst[j_] = NTL ? __builtin_nontemporal_load(base + (size_t)(8 * (slot) + j_) * 64) : base[(size_t)(8 * (slot) + j_) * 64];
+    // the first 8 KiB of the first tile are requested before anything else: the set-up below (LDS, vector entries) runs behind them
+    dbl2 va[8];
+    bool have_first = false;
+    if (td.mask == 0xffu) {
+        const dbl2 *base = reinterpret_cast<const dbl2 *>(tval + (size_t)(td.soff - sub_base) * XT_SUB) + lane;
+        XT_LD(va, 0)
+        have_first = true;
+    }
     // the window's 256 vector entries and the 256 column accumulators live in wave-private LDS: their reads are counted by
     // lgkmcnt, so waiting for them never drains the tile stream (vmcnt)
     {
@@ -225,8 +235,6 @@ __device__ __forceinline__ void xt_tile_role(const XItem it, const XTile *__rest
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    XTile td; td.k = it.k0; td.w = it.w; td.mask = it.mask0; td.soff = it.soff0;
-#define XT_LD(dst, slot) _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) dst[j_] = NTL ? __builtin_nontemporal_load(base + (size_t)(8 * (slot) + j_) * 64) : base[(size_t)(8 * (slot) + j_) * 64];
 #define XT_SUBBLOCK(vv, q)                                                                                                  \
     {                                                                                                                       \
         const dbl2 pc = *reinterpret_cast<const dbl2 *>(lq + XT_SBW * (q) + 2 * cc);                                        \
@@ -247,8 +255,9 @@ __device__ __forceinline__ void xt_tile_role(const XItem it, const XTile *__rest
         const dbl2 *base = reinterpret_cast<const dbl2 *>(tval + (size_t)(td.soff - sub_base) * XT_SUB) + lane;
         if (td.mask == 0xffu) {
             // full tile: 64 KiB contiguous, two sub-blocks (16 KiB) in flight per wave
-            dbl2 va[8], vb[8];
-            XT_LD(va, 0)
+            dbl2 vb[8];
+            if (!have_first) { XT_LD(va, 0) }
+            have_first = false;
 #pragma unroll 1
             for (int h = 0; h < 3; ++h) {                            // a real loop: the register budget stays at two sub-blocks
                 XT_LD(vb, 2 * h + 1)
@@ -264,7 +273,6 @@ __device__ __forceinline__ void xt_tile_role(const XItem it, const XTile *__rest
 #pragma unroll 1
             while (mm) {
                 const int q = __ffs(mm) - 1; mm &= mm - 1;
-                dbl2 va[8];
                 XT_LD(va, sl)
                 XT_SUBBLOCK(va, q)
                 ++sl;

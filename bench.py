@@ -202,12 +202,16 @@ def rooflines(sim, local_share=1.0):
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None,
                                 "us_per_iteration": round(us, 2), "iterations_timed": pr["kcg_iters"], "algorithmic_bytes_per_iteration": b}
     if pr["pair_n"] > 0 and st["n_charged"] > 0:
-        # pair sum: 64 fp64 flops per (site, charged site) pair
-        fl = 64.0 * sim.s.N * st["n_charged"]
+        # pair sum: 64 fp64 flops per evaluated (site, charged site) pair; pairs beyond the screening cut-off
+        # (erfc < 3.8e-20) pay the distance only, 12 flops
+        pairs = int(sim.s.N) * int(st["n_charged"])
+        ev = int(st["pair_evaluated"]) if st["pair_evaluated"] > 0 else pairs
+        fl = 64.0 * ev + 12.0 * (pairs - ev)
         ms = pr["pair_ms"] / pr["pair_n"]
         out["roofline_pair_sum"] = {"bound": "fp64-valu", "kernel": "k_pairwise", "achieved": round(fl / (ms * 1e-3) / 1e12, 2),
                                     "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / (ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS, 4),
-                                    "traffic": None, "ms_per_launch": round(ms, 4), "pairs": int(sim.s.N) * int(st["n_charged"])}
+                                    "traffic": None, "ms_per_launch": round(ms, 4), "pairs": pairs, "pairs_evaluated": ev,
+                                    "all_pairs_equivalent_TFLOPs": round(64.0 * pairs / (ms * 1e-3) / 1e12, 2)}
     return out
 
 

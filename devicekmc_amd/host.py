@@ -69,6 +69,14 @@ class GPUBuffers:
         check(L.dkmc_copy_to_const_memory(_np_ptr(E[0]), _np_ptr(E[1]), _np_ptr(E[2]), _np_ptr(E[3]), len(layers)))
         torch.cuda.synchronize(self.dev)
 
+    def __del__(self):
+        # the pattern arrays of initialize_sparsity are the only memory of this object that torch does not own
+        try:
+            if self.__dict__.get("c") is not None and _lib._lib is not None:
+                _lib._lib.dkmc_free_sparsity(C.byref(self.c))
+        except Exception:
+            pass
+
     def __getattr__(self, name):
         t = self.__dict__.get("t", {})
         if name in t:

@@ -40,7 +40,7 @@ class dkmc_stats(C.Structure):
                 ("spmv_tiles", C.c_int), ("spmv_pad2", C.c_int), ("spmv_tile_entries", C.c_longlong),
                 ("xt_subblocks", C.c_longlong), ("xt_local_subblocks", C.c_longlong), ("xt_items", C.c_int), ("xt_kc", C.c_int),
                 ("xt_sparse_nnz", C.c_longlong), ("xt_ns", C.c_int), ("xt_pad", C.c_int),
-                ("kcg_ms", C.c_double), ("kcg_iters_timed", C.c_int), ("kcg_pad", C.c_int), ("pair_ms", C.c_double)]
+                ("kcg_ms", C.c_double), ("kcg_iters_timed", C.c_int), ("kcg_pad", C.c_int), ("pair_ms", C.c_double), ("pair_evaluated", C.c_longlong)]
 
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
@@ -70,6 +70,7 @@ SYMBOLS = {
     "dkmc_copy_to_const_memory": (_I, [vp, vp, vp, vp, _I]),
     "dkmc_build_neighbor_index": (_I, [_I, vp, vp, vp, vp, _I, _D, c_int_p, vp]),
     "dkmc_initialize_sparsity": (_I, [C.POINTER(dkmc_gpubuf), _I, _D, _I]),
+    "dkmc_free_sparsity": (_I, [C.POINTER(dkmc_gpubuf)]),
     "dkmc_update_charge_gpu": (_I, [vp, vp, vp, _I, _I, vp, _I]),
     "dkmc_update_CB_edge_gpu_sparse": (_I, [C.POINTER(dkmc_gpubuf), _I, _I, _I, _D, _I, _D, _D, _D, _I]),
     "dkmc_background_potential_gpu_sparse": (_I, [C.POINTER(dkmc_gpubuf), _I, _I, _I, _D, _I, _D, _D, _D, _I, _I]),

@@ -95,6 +95,7 @@ typedef struct dkmc_stats {
     double kcg_ms;
     int kcg_iters_timed, kcg_pad;
     double pair_ms;
+    long long pair_evaluated;              /* (site, charged site) pairs inside the screening cut-off of the last pair sum (profiling on) */
 } dkmc_stats;
 
 const char *dkmc_last_error(void);
@@ -156,6 +157,9 @@ int dkmc_build_neighbor_index(int N, const double *d_x, const double *d_y, const
 /* ---- sparsity of K: initialize_sparsity (iterative_solvers_gpu.cu:96-109) ------------------- */
 /* fills Device_*, contact_left_*, contact_right_* of buf (allocated by the library) */
 int dkmc_initialize_sparsity(dkmc_gpubuf *buf, int pbc, double nn_dist, int num_atoms_contact);
+/* frees the six pattern arrays initialize_sparsity allocated and the solver state kept for this buffer (dkmc_gpubuf_free does both
+ * for buffers created by dkmc_gpubuf_create) */
+int dkmc_free_sparsity(dkmc_gpubuf *buf);
 
 /* ---- potential ------------------------------------------------------------------------------ */
 /* update_charge_gpu (potential_solver_gpu.cu:54-63) */

@@ -137,9 +137,20 @@ def test_current_solve(pair_2p5, hip, golden_dir):
     assert abs(dev.imacro / oi - 1) <= 1e-7                                        # CG to 1e-10 on both sides
     pw = get(gb, "site_power")
     assert np.abs(pw - o.power).max() <= 1e-6 * np.abs(o.power).max()
-    # the reference's own sparsity dump (after the step-0 event): identical outside vacancy-vacancy pairs
+    # the reference's own sparsity dump (after the step-0 event), every row: identical except 60 entries (40 only in the dump, 20
+    # only here), all of them vacancy-vacancy pairs (the dump's revision used another energy for those: DESIGN.md section 2)
     g = np.load(os.path.join(golden_dir, "x_pattern_2.5nm_step0.npz"))
-    assert np.array_equal(g["row_ptr"][:1300], rp[:1300])
+    assert len(g["row_ptr"]) == len(rp)
+    ael = X["ael"]
+    only_dump = only_here = 0
+    for r_ in range(len(rp) - 1):
+        a_ = g["col_idx"][g["row_ptr"][r_]:g["row_ptr"][r_ + 1]]; b_ = ci[rp[r_]:rp[r_ + 1]]
+        if len(a_) == len(b_) and np.array_equal(a_, b_):
+            continue
+        d1, d2 = np.setdiff1d(a_, b_), np.setdiff1d(b_, a_)
+        assert r_ >= 2 and ael[r_ - 2] == 2 and (ael[np.r_[d1, d2] - 2] == 2).all(), r_
+        only_dump += len(d1); only_here += len(d2)
+    assert (only_dump, only_here) == (40, 20)
     st = host.get_stats()
     assert st["N_atom"] == 6421 and st["X_nnz"] == len(ci)
     # size-independent properties: X symmetric; rows without boundary terms sum to zero

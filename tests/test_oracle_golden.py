@@ -49,8 +49,10 @@ def test_cpu_path_numbers_2p5nm(cell_2p5, ref_logs):
 
 
 def test_x_pattern_vs_reference_dump(cell_2p5, golden_dir):
-    """X sparsity after step 0 vs the CSR the reference CUDA path dumped.  Everything matches except 44 of
-    467 336 entries, all vacancy-vacancy tunnelling pairs (unknown code revision of the dump)."""
+    """X sparsity after step 0 vs the CSR the reference CUDA path dumped.  Everything matches except 60 of 467 336 entries (40 only
+    in the dump, 20 only in the oracle), all vacancy-vacancy tunnelling pairs whose |dE_CB| in this snapshot's CB edge lies up to 200x
+    the solver error away from the 0.01 eV threshold: another energy was used for those pairs by the revision that wrote the dump
+    (DESIGN.md section 2)."""
     g = np.load(os.path.join(golden_dir, "x_pattern_2.5nm_step0.npz"))
     p = pm.KMCParameters()
     o = oc.OracleKMC(cell_2p5.element, cell_2p5.x, cell_2p5.y, cell_2p5.z, p)
@@ -68,7 +70,7 @@ def test_x_pattern_vs_reference_dump(cell_2p5, golden_dir):
         d = np.setxor1d(a, b)
         assert r >= 2 and ael[r - 2] == pm.VACANCY and (ael[d - 2] == pm.VACANCY).all(), r
         ndiff += len(d)
-    assert ndiff <= 64
+    assert ndiff == 60
     # rows 0 and 1: 144 = {0,1} + 142 extraction columns; 146 = num_source_inj + 2
     assert X["row_ptr"][1] == 144 and X["row_ptr"][2] - X["row_ptr"][1] == 146
 

@@ -622,10 +622,11 @@ def test_tiled_X_agrees_with_csr_X(dev_7p5, hip):
     assert np.abs(b["power"] - a["power"]).max() <= 1e-8 * np.abs(a["power"]).max()
 
 
-@pytest.mark.parametrize("case", ["small_bias", "few_vacancies", "no_vacancies", "negative_bias"])
+@pytest.mark.parametrize("case", ["small_bias", "few_vacancies", "no_vacancies", "negative_bias", "empty_S"])
 def test_tiled_X_edge_cases(cell_2p5, hip, case):
     """Tiled X against CSR X where the tunnelling block degenerates: |Vd| so small that contact-contact pairs fall below the 0.01 eV
-    threshold (only ragged, sparse cells are left), very few / no vacancies (S = contact metals only), negative bias.  Same
+    threshold (only ragged, sparse cells are left), very few / no vacancies (S = contact metals only), negative bias, and an EMPTY
+    tunnelling set (no vacancies and an empty inner-contact window; X is its neighbour part alone).  Same
     column-sorted CSR out of both (pattern exact, values to 1e-12), same I_macro and dissipated power to 1e-8."""
     host, L = hip
     from devicekmc_amd import params as pm
@@ -633,8 +634,10 @@ def test_tiled_X_edge_cases(cell_2p5, hip, case):
     vd = {"small_bias": 0.03, "negative_bias": -3.0}.get(case, Vd)
     if case == "few_vacancies":
         p.initial_vacancy_concentration = 0.002
-    if case == "no_vacancies":
+    if case in ("no_vacancies", "empty_S"):
         p.initial_vacancy_concentration = 0.0
+    if case == "empty_S":
+        p.num_layers_contact = 100          # (nlc - 1) * n_src exceeds the atom count: the inner-contact window is empty
     out = {}
     try:
         for fmt in (0, 1):
@@ -655,6 +658,8 @@ def test_tiled_X_edge_cases(cell_2p5, hip, case):
     finally:
         L.dkmc_set_x_format(1)
     (i0, pw0, (rp0, ci0, d0), nnz0, m0), (i1, pw1, (rp1, ci1, d1), nnz1, m1) = out[0], out[1]
+    if case == "empty_S":
+        assert host.get_stats()["xt_ns"] == 0
     assert nnz0 == nnz1 == len(ci0) == len(ci1)
     assert np.array_equal(rp0, rp1) and np.array_equal(ci0, ci1)
     assert np.abs(d1 - d0).max() <= 1e-12 * np.abs(d0).max() and np.all(np.abs(d1 - d0) <= 1e-10 * np.abs(d0))

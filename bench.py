@@ -372,7 +372,7 @@ def main():
     ap.add_argument("--no-cpp-host", action="store_true", help="N = 1: skip the cross-check line through the C++ host driver")
     ap.add_argument("--no-pmc", action="store_true", help="N = 1: do not measure roofline.traffic (two rocprofv3 --pmc child runs)")
     ap.add_argument("--budget", type=float, default=420.0, help="time budget [s] for the timed steps of seconds-per-step workloads")
-    ap.add_argument("--timeout", type=float, default=900.0, help="watchdog [s]: exit 3 if the run has not finished")
+    ap.add_argument("--timeout", type=float, default=570.0, help="watchdog [s]: exit 3 if the run has not finished (a rank stuck in a collective cannot be unwound)")
     args = ap.parse_args()
 
     import torch

@@ -232,6 +232,39 @@ def summary(sim, elapsed, steps):
     }
 
 
+ALLREDUCE_US_ASSUMED = {1: 0.0, 2: 25.0, 4: 40.0, 8: 60.0}     # in-place all-reduce of |S| + 1 doubles (0.74 MB at 9.4e5 sites) over xGMI: ASSUMED, not measured
+
+
+def strong_scaling_model(sim, ms_per_step, reps=10):
+    """What can be measured of an N-GPU strong-scaling run on ONE GPU (dkmc_xt_time_share): the time per CG iteration of the kernels
+    one rank of an N-way sharded solve runs on its share of the tiles (a middle rank's share, work items sized as an N-rank run
+    sizes them), each kernel timed on its own.  The model adds an ASSUMED all-reduce latency:
+    T_N = T_1 - iters * (kernels_1 - kernels_N) + iters * allreduce_N."""
+    import ctypes as C
+    st = sim.host.get_stats()
+    iters = sim.cnt["cg_iters_X"] / max(sim.cnt["steps"], 1)
+    rows = {}
+    for n in (1, 2, 4, 8):
+        a, r, it, sb = C.c_double(0), (C.c_double * 3)(), C.c_int(0), C.c_longlong(0)
+        rc = sim.L.dkmc_xt_time_share(n, n // 2, reps, C.byref(a), r, C.byref(it), C.byref(sb))
+        if rc != 0:
+            sim.L.dkmc_clear_error()
+            return {"error": "dkmc_xt_time_share failed"}
+        rows[n] = {"apply_us": round(a.value, 2), "partial_row_sums_us": round(r[0], 2), "finish_us": round(r[1], 2), "vector_step_us": round(r[2], 2),
+                   "work_items": it.value, "subblocks": sb.value, "share_GBps": round(8192.0 * sb.value / a.value / 1e3, 1)}
+    # one GPU runs apply + row sums (finish fused in) + vector step; N > 1 runs apply + partial row sums + all-reduce + finish + vector step
+    t1 = rows[1]["apply_us"] + rows[1]["partial_row_sums_us"] + rows[1]["vector_step_us"]
+    for n in rows:
+        tk = rows[n]["apply_us"] + rows[n]["partial_row_sums_us"] + rows[n]["vector_step_us"] + (rows[n]["finish_us"] if n > 1 else 0.0)
+        tn = ms_per_step - iters * (t1 - tk) * 1e-3 + iters * ALLREDUCE_US_ASSUMED[n] * 1e-3
+        rows[n]["allreduce_us_assumed"] = ALLREDUCE_US_ASSUMED[n]
+        rows[n]["modelled_ms_per_step"] = round(tn, 1)
+        rows[n]["modelled_speedup"] = round(ms_per_step / tn, 2)
+    return {"what": "per-rank kernel times of an N-way sharded solve measured on one GPU (share of a middle rank); all-reduce latency ASSUMED; "
+                    "K-CG, pair sum, events, neighbour part and assembly stay replicated (in T_1)",
+            "cg_iters_X_per_step": iters, "single_gpu_ms_per_step": ms_per_step, "by_n_gpus": rows}
+
+
 def cpu_cg_baseline(sim, ncores):
     """CPU leg of a scale point: the oracle's CG iteration (okmc_cg_iter_bench: the loop body of okmc_cg_jacobi, OpenMP) timed on a
     CSR of X's shape at this size, x the GPU run's iteration count.  Everything else of a CPU step (assembly, K solve, events) is
@@ -446,6 +479,8 @@ def main():
                 if big:
                     r["note"] = "step 1 starts from the cold state (empty tunnelling-coefficient cache, zero start vector), step 2 with that history"
                 r.update(rooflines(sp))
+                if big:
+                    r["strong_scaling_model"] = strong_scaling_model(sp, r["ms_per_step"])
                 if not args.no_cpu_baseline:
                     r["cpu_baseline"] = cpu_cg_baseline(sp, ncores)
                     if r["cpu_baseline"]:

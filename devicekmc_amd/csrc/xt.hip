@@ -123,29 +123,72 @@ __global__ void k_xt_tile_list(int nK, long long ncell, const unsigned *__restri
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < ncell && cmask[i]) { XTile t; t.k = (int)(i % nK); t.w = (int)(i / nK); t.mask = cmask[i]; t.soff = soff[i]; tiles[toff[i]] = t; }
 }
-// per strip: number of work items; per row block: first / one-past-last window holding a tile
-__global__ void k_xt_strips(int nK, int nW, int kc, int ntiles, const int *__restrict__ toff, const unsigned *__restrict__ cmask,
-                            int *__restrict__ nitem_w, int2 *__restrict__ wrange)
+// per row block: first / one-past-last window holding a tile
+__global__ void k_xt_wrange(int nK, int nW, const unsigned *__restrict__ cmask, int2 *__restrict__ wrange)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nW) {
-        const int t0 = toff[(long long)i * nK], t1 = (i + 1 < nW) ? toff[(long long)(i + 1) * nK] : ntiles;
-        nitem_w[i] = (t1 - t0 + kc - 1) / kc;
-    }
     if (i < nK) {
         int b = nW, e = 0;
         for (int w = 0; w < nW; ++w) if (cmask[(long long)w * nK + i]) { b = min(b, w); e = w + 1; }
         wrange[i] = make_int2(b, e);
     }
 }
-__global__ void k_xt_items(int nK, int nW, int kc, int ntiles, const int *__restrict__ toff, const int *__restrict__ ioff,
-                           const XTile *__restrict__ tiles, XItem *__restrict__ items, int *__restrict__ isub)
+// Work items = runs of tiles of one strip.  The tile list (strip-major) is cut into the ranks' shares at tile boundaries, balanced by
+// stored sub-blocks; inside a share the run length is kc except towards the END of the share, where it halves every XT_TAPER tiles
+// down to single tiles: the last waves of a launch then stream 64 KiB each instead of a whole kc-tile run alone and latency-bound
+// (measured at a 1/8 share of the 9.4e5-site stack: 426 us per launch untapered against 357 us at the full-size rate).
+#define XT_MAXRANKS 64
+#define XT_TAPER 2048
+struct XSplit { int n; int tb[XT_MAXRANKS + 1]; int item_lo[XT_MAXRANKS + 1]; int max_items_per_strip; };
+__global__ void k_xt_split(int ntiles, long long nsub_total, const XTile *__restrict__ tiles, int n, XSplit *sp)
+{
+    const int r = threadIdx.x;
+    if (r > n) return;
+    int t = 0;
+    if (r == n) t = ntiles;
+    else if (r > 0) {
+        const long long want = nsub_total * r / n;
+        int lo = 0, hi = ntiles;                                       // first tile whose first sub-block is at or beyond `want`
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if ((long long)tiles[mid].soff < want) lo = mid + 1; else hi = mid; }
+        t = lo;
+    }
+    sp->tb[r] = t;
+    if (r == 0) { sp->n = n; sp->max_items_per_strip = 0; }
+}
+__device__ __forceinline__ int xt_run_len(int t, int t1, int kc, const XSplit *sp)
+{
+    int r = 0;
+    while (r + 1 < sp->n && t >= sp->tb[r + 1]) ++r;
+    const int end = sp->tb[r + 1], d = end - 1 - t;
+    const int sh = d / XT_TAPER;
+    int len = sh >= 5 ? kc : min(kc, 1 << sh);
+    return max(1, min(len, min(end, t1) - t));
+}
+// MODE 0: items per strip (+ the largest count); MODE 1: write them at ioff[w]
+template <int MODE>
+__global__ void k_xt_items(int nK, int nW, int kc, int ntiles, const int *__restrict__ toff, const int *__restrict__ ioff, const XTile *__restrict__ tiles,
+                           XSplit *sp, int *__restrict__ nitem_w, XItem *__restrict__ items)
 {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nW) return;
     const int t0 = toff[(long long)w * nK], t1 = (w + 1 < nW) ? toff[(long long)(w + 1) * nK] : ntiles;
-    int o = ioff[w], c = 0;
-    for (int t = t0; t < t1; t += kc, ++o, ++c) { const XTile f = tiles[t]; XItem it; it.t0 = t; it.t1 = min(t + kc, t1); it.w = w; it.c = c; it.k0 = f.k; it.mask0 = f.mask; it.soff0 = f.soff; it.pad = 0; items[o] = it; isub[o] = f.soff; }
+    int o = MODE ? ioff[w] : 0, c = 0;
+    for (int t = t0; t < t1; ++c) {
+        const int len = xt_run_len(t, t1, kc, sp);
+        if (MODE) { const XTile f = tiles[t]; XItem it; it.t0 = t; it.t1 = t + len; it.w = w; it.c = c; it.k0 = f.k; it.mask0 = f.mask; it.soff0 = f.soff; it.pad = 0; items[o + c] = it; }
+        t += len;
+    }
+    if (!MODE) { nitem_w[w] = c; atomicMax(&sp->max_items_per_strip, c); }
+}
+// first item of every rank's share (items are in tile order and never cross a share boundary)
+__global__ void k_xt_rank_items(int nitems, const XItem *__restrict__ items, XSplit *sp)
+{
+    const int r = threadIdx.x;
+    if (r > sp->n) return;
+    const int tb = sp->tb[r];
+    int lo = 0, hi = nitems;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (items[mid].t0 < tb) lo = mid + 1; else hi = mid; }
+    sp->item_lo[r] = lo;
 }
 
 // ---- fill: values of the stored sub-blocks --------------------------------------------------------------------------------
@@ -381,13 +424,18 @@ __global__ __launch_bounds__(XT_NT) void k_xt_tiles_only(int nitems, const XItem
 // over its share of ALL rows (the non-S rows were finished by the apply kernel) and writes one partial of each (XT_PSTRIDE
 // apart).  MODE 1: xout[s] = tile sums
 // only (this rank's share in the sharded solve; the diagonal and power passes).
+// [w_lo, w_hi): windows that can hold partial sums in this launch -- all of them on one GPU; in a sharded solve the windows of this
+// rank's tiles (every other cell of the partial arrays is zero on this rank: not reading it saves 7/8 of this kernel at 8 ranks)
 __device__ __forceinline__ double xt_row_block_sum(int k, int nW, int ns_pad, const int2 *__restrict__ wrange, const int *__restrict__ nitem_w,
-                                                   const double *__restrict__ rowpart, const double *__restrict__ colpart, double (*sl_sum)[XT_R])
+                                                   const double *__restrict__ rowpart, const double *__restrict__ colpart, double (*sl_sum)[XT_R],
+                                                   int w_lo, int w_hi)
 {
     const int r = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int s = XT_R * k + r;
-    const int2 wr = wrange[k];
-    const int nc = nitem_w[k / (XT_C / XT_R)];
+    int2 wr = wrange[k];
+    wr.x = max(wr.x, w_lo); wr.y = min(wr.y, w_hi);
+    const int wk = k / (XT_C / XT_R);
+    const int nc = (wk >= w_lo && wk < w_hi) ? nitem_w[wk] : 0;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     const double *rpp = rowpart + (size_t)k * nW * XT_R + r;
     const double *cpp = colpart + s;
@@ -439,7 +487,8 @@ __global__ __launch_bounds__(XT_NT) void k_xt_rows(int ns, int nK, int nW, int n
                                                    const double *__restrict__ rowpart, const double *__restrict__ colpart,
                                                    const int *__restrict__ srow, const double *__restrict__ sS, const double *__restrict__ pvec,
                                                    double *__restrict__ t, double *__restrict__ part, const XCtrl *ctrl, double *__restrict__ xout,
-                                                   int m, const int *__restrict__ nsrank, int flag_rank0, const double *__restrict__ rvec)
+                                                   int m, const int *__restrict__ nsrank, int flag_rank0, const double *__restrict__ rvec,
+                                                   int w_lo, int w_hi)
 {
     __shared__ double red[XT_NT / 64][4];
     __shared__ double sl_sum[8][XT_R];
@@ -464,7 +513,7 @@ __global__ __launch_bounds__(XT_NT) void k_xt_rows(int ns, int nK, int nW, int n
         if (sdone) return;
     }
     for (int k = blockIdx.x; k < nK; k += gridDim.x) {
-        const double sum = xt_row_block_sum(k, nW, ns_pad, wrange, nitem_w, rowpart, colpart, sl_sum);
+        const double sum = xt_row_block_sum(k, nW, ns_pad, wrange, nitem_w, rowpart, colpart, sl_sum, w_lo, w_hi);
         const int s = XT_R * k + (int)threadIdx.x;
         if (threadIdx.x < XT_R && s < ns) {
             if (MODE == 1) xout[s] = sum;
@@ -678,7 +727,7 @@ struct XTState {
     long long nsub_total = 0, xs_nnz = 0;
     unsigned long long t_upper = 0;
     // this rank's share
-    int item_lo = 0, item_n = 0, tile_lo = 0, tile_n = 0; long long sub_base = 0, sub_n = 0;
+    int item_lo = 0, item_n = 0, tile_lo = 0, tile_n = 0, w_lo = 0, w_hi = 0; long long sub_base = 0, sub_n = 0;
     bool valid = false;
 };
 static XTState g_xt;
@@ -686,6 +735,7 @@ static XTState g_xt;
 struct XTBuffers {
     SNodes S; int *srow; XTile *tiles; XItem *items; int2 *wrange; int *nitem_w; double *tval, *rowpart, *colpart;
     xrp_t *rp, *dpos; int *ci; double *val; int *nsrank;
+    unsigned *cmask; int *toff;      // census of the last assembly (kept for dkmc_xt_time_share)
 };
 static XTBuffers g_xb;
 
@@ -708,9 +758,52 @@ static int xt_tile_sums(const double *vS, double *out, int vpos)
     hipLaunchKernelGGL((k_xt_rows<1>), dim3(xt_grid(X.nK, 1, 1024)), dim3(XT_NT), 0, st, X.ns, X.nK, X.nW, X.ns_pad, (const int2 *)g_xb.wrange,
                        (const int *)g_xb.nitem_w, (const double *)g_xb.rowpart, (const double *)g_xb.colpart, (const int *)nullptr,
                        (const double *)nullptr, (const double *)nullptr, (double *)nullptr, (double *)nullptr, (const XCtrl *)nullptr, out,
-                       0, (const int *)nullptr, 0, (const double *)nullptr);
+                       0, (const int *)nullptr, 0, (const double *)nullptr, X.w_lo, X.w_hi);
     KCHK();
     if (comm_attached()) { int rc = comm_allreduce_sum_f64(out, (size_t)X.ns); if (rc) return rc; }
+    return 0;
+}
+
+// Builds the work items for an nranks-way split and reports rank `me`'s share.  Slots: where the item arrays go (the resident ones of
+// an assembly, or temporary ones of dkmc_xt_time_share).
+struct XShare { int nitems, maxchunk, item_lo, item_n, tile_lo, tile_n, w_lo, w_hi; long long sub_base, sub_n; XItem *items; int *nitem_w; };
+static int xt_build_items(int nK, int nW, int kc, int ntiles, long long nsub_total, const int *toff, const XTile *tiles, int nranks, int me,
+                          int slot_nitemw, int slot_items, int slot_split, XShare *out)
+{
+    Engine &e = eng(); hipStream_t st = e.stream;
+    if (nranks > XT_MAXRANKS) return dkmc_fail(46, "update_power: more ranks than XT_MAXRANKS", __FILE__, __LINE__);
+    int *nitem_w = (int *)scratch(slot_nitemw, (size_t)(nW + 4) * 4 * 2);
+    XSplit *sp = (XSplit *)scratch(slot_split, sizeof(XSplit));
+    if (!nitem_w || !sp) return e.err_code;
+    int *ioff = nitem_w + nW + 2;
+    XSplit h{};
+    out->nitem_w = nitem_w; out->items = nullptr; out->nitems = 0; out->maxchunk = 1;
+    out->item_lo = 0; out->item_n = 0; out->tile_lo = 0; out->tile_n = 0; out->sub_base = 0; out->sub_n = 0; out->w_lo = 0; out->w_hi = 0;
+    if (ntiles <= 0) { HIPCHK(hipMemsetAsync(nitem_w, 0, (size_t)(nW + 4) * 4 * 2, st)); return 0; }
+    hipLaunchKernelGGL(k_xt_split, dim3(1), dim3(XT_MAXRANKS + 1), 0, st, ntiles, nsub_total, tiles, nranks, sp);
+    hipLaunchKernelGGL((k_xt_items<0>), dim3((nW + 255) / 256), dim3(256), 0, st, nK, nW, kc, ntiles, toff, (const int *)nullptr, tiles, sp, nitem_w, (XItem *)nullptr);
+    int rc = dkmc_exclusive_scan_i32(nitem_w, ioff, nW, ioff + nW); if (rc) return rc;
+    int nitems = 0;
+    HIPCHK(hipMemcpyAsync(&nitems, ioff + nW, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    XItem *items = (XItem *)scratch(slot_items, (size_t)(nitems + 1) * sizeof(XItem));
+    if (!items) return e.err_code;
+    hipLaunchKernelGGL((k_xt_items<1>), dim3((nW + 255) / 256), dim3(256), 0, st, nK, nW, kc, ntiles, toff, (const int *)ioff, tiles, sp, nitem_w, items);
+    hipLaunchKernelGGL(k_xt_rank_items, dim3(1), dim3(XT_MAXRANKS + 1), 0, st, nitems, (const XItem *)items, sp);
+    HIPCHK(hipMemcpyAsync(&h, sp, sizeof(XSplit), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    out->items = items; out->nitems = nitems; out->maxchunk = std::max(1, h.max_items_per_strip);
+    out->item_lo = h.item_lo[me]; out->item_n = h.item_lo[me + 1] - h.item_lo[me];
+    out->tile_lo = h.tb[me]; out->tile_n = h.tb[me + 1] - h.tb[me];
+    int so[2] = {0, 0};                                             // sub-block offsets of the share's first tile and of the one behind its last
+    for (int q = 0; q < 2; ++q) {
+        const int t = h.tb[me + q];
+        if (t >= ntiles) so[q] = (int)nsub_total;
+        else { XTile td; HIPCHK(hipMemcpy(&td, tiles + t, sizeof(XTile), hipMemcpyDeviceToHost)); so[q] = td.soff; if (q == 0) out->w_lo = td.w; }
+    }
+    out->sub_base = so[0]; out->sub_n = so[1] - so[0];
+    if (out->tile_n > 0) { XTile td; HIPCHK(hipMemcpy(&td, tiles + h.tb[me + 1] - 1, sizeof(XTile), hipMemcpyDeviceToHost)); out->w_hi = td.w + 1; }
+    else out->w_hi = out->w_lo;
     return 0;
 }
 
@@ -790,46 +883,27 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
     const int ntiles = X.ntiles;
     // tiles per work item: ~4 k items per GPU.  Measured at 234 975 sites (19 372 tiles): 2 / 4 / 8 / 16 tiles per item -> 198 / 188 / 206 /
     // 222 us per launch (more items: ~2 us of start-up chain per wave round; fewer: the last waves stream alone, latency-bound)
-    X.kc = std::max(1, std::min(XT_MAXKC, ntiles / (comm_attached() ? comm_nranks() : 1) / 4096));
-    X.maxchunk = std::max(1, (nK + X.kc - 1) / X.kc);
+    const bool sharded = comm_attached() != 0;
+    const int nr = sharded ? comm_nranks() : 1, me = sharded ? comm_rank() : 0;
+    X.kc = std::max(1, std::min(XT_MAXKC, ntiles / nr / 4096));
     XTile *tiles = (XTile *)scratch(S_XT_TILES, (size_t)(ntiles + 1) * sizeof(XTile));
-    int *nitem_w = (int *)scratch(S_XT_NITEMW, (size_t)(nW + 4) * 4 * 2);
     int2 *wrange = (int2 *)scratch(S_XT_WRANGE, (size_t)(nK + 4) * sizeof(int2));
-    if (!tiles || !nitem_w || !wrange) return e.err_code;
-    int *ioff = nitem_w + nW + 2;
+    if (!tiles || !wrange) return e.err_code;
     if (ncell > 0) {
         hipLaunchKernelGGL(k_xt_tile_list, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, nK, ncell, (const unsigned *)cmask, (const int *)toff, (const int *)soff, tiles);
-        hipLaunchKernelGGL(k_xt_strips, dim3((std::max(nK, nW) + 255) / 256), dim3(256), 0, st, nK, nW, X.kc, ntiles, (const int *)toff, (const unsigned *)cmask, nitem_w, wrange);
-        rc = dkmc_exclusive_scan_i32(nitem_w, ioff, nW, ioff + nW); if (rc) return rc;
-        HIPCHK(hipMemcpyAsync(&X.nitems, ioff + nW, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        hipLaunchKernelGGL(k_xt_wrange, dim3((nK + 255) / 256), dim3(256), 0, st, nK, nW, (const unsigned *)cmask, wrange);
     }
-    const int nitems = X.nitems;
-    XItem *items = (XItem *)scratch(S_XT_ITEMS, (size_t)(nitems + 1) * sizeof(XItem));
-    int *isub = (int *)scratch(S_XT_ISUB, (size_t)(nitems + 2) * 4);
-    if (!items || !isub) return e.err_code;
-    if (nitems > 0) hipLaunchKernelGGL(k_xt_items, dim3((nW + 255) / 256), dim3(256), 0, st, nK, nW, X.kc, ntiles, (const int *)toff, (const int *)ioff, (const XTile *)tiles, items, isub);
+    XShare sh{};
+    rc = xt_build_items(nK, nW, X.kc, ntiles, X.nsub_total, toff, tiles, nr, me, S_XT_NITEMW, S_XT_ITEMS, S_XT_ISUB, &sh); if (rc) return rc;
+    X.nitems = sh.nitems; X.maxchunk = sh.maxchunk;
+    const int nitems = sh.nitems;
+    XItem *items = sh.items; int *nitem_w = sh.nitem_w;
     KCHK();
-    g_xb.tiles = tiles; g_xb.items = items; g_xb.wrange = wrange; g_xb.nitem_w = nitem_w;
+    g_xb.tiles = tiles; g_xb.items = items; g_xb.wrange = wrange; g_xb.nitem_w = nitem_w; g_xb.cmask = cmask; g_xb.toff = toff;
 
-    // ---- this rank's share of the work items (contiguous, balanced by stored bytes) ----
-    X.item_lo = 0; X.item_n = nitems; X.tile_lo = 0; X.tile_n = ntiles; X.sub_base = 0; X.sub_n = X.nsub_total;
-    const bool sharded = comm_attached() != 0;
-    if (sharded && nitems > 0) {
-        const int nr = comm_nranks(), me = comm_rank();
-        std::vector<int> hsub((size_t)nitems + 1);
-        HIPCHK(hipMemcpy(hsub.data(), isub, (size_t)nitems * 4, hipMemcpyDeviceToHost));
-        hsub[nitems] = (int)X.nsub_total;
-        auto cut = [&](int r) { const long long want = X.nsub_total * r / nr; return (int)(std::lower_bound(hsub.begin(), hsub.begin() + nitems, (int)want) - hsub.begin()); };
-        const int i0 = me == 0 ? 0 : cut(me), i1 = me == nr - 1 ? nitems : cut(me + 1);
-        X.item_lo = i0; X.item_n = std::max(0, i1 - i0);
-        XItem first{}, last{};
-        if (X.item_n > 0) {
-            HIPCHK(hipMemcpy(&first, items + i0, sizeof(XItem), hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(&last, items + i1 - 1, sizeof(XItem), hipMemcpyDeviceToHost));
-            X.tile_lo = first.t0; X.tile_n = last.t1 - first.t0; X.sub_base = hsub[i0]; X.sub_n = hsub[i1] - hsub[i0];
-        } else { X.tile_lo = 0; X.tile_n = 0; X.sub_base = 0; X.sub_n = 0; }
-    }
+    // ---- this rank's share of the work items (contiguous in the strip-major tile list, balanced by stored bytes) ----
+    X.item_lo = sh.item_lo; X.item_n = sh.item_n; X.tile_lo = sh.tile_lo; X.tile_n = sh.tile_n; X.sub_base = sh.sub_base; X.sub_n = sh.sub_n;
+    X.w_lo = sh.w_lo; X.w_hi = sh.w_hi;
     e.stats.comm_ranks = sharded ? comm_nranks() : 0;
     e.stats.comm_count_per_rank = sharded ? ns + 1 : 0;
     e.stats.comm_local_segments = X.item_n;
@@ -891,7 +965,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         if (sharded && ns > 0) {
             hipLaunchKernelGGL((k_xt_rows<1>), dim3(n2b), dim3(XT_NT), 0, st, ns, nK, nW, ns_pad, (const int2 *)wrange, (const int *)nitem_w, (const double *)rowpart,
                                (const double *)colpart, (const int *)srow, (const double *)sS, (const double *)p, t, part_pt, (const XCtrl *)ctrl, xbuf,
-                               m, (const int *)nsrank, comm_rank() == 0 ? 1 : 0, (const double *)r);
+                               m, (const int *)nsrank, comm_rank() == 0 ? 1 : 0, (const double *)r, X.w_lo, X.w_hi);
             if (int rcx = comm_allreduce_sum_f64(xbuf, (size_t)ns + 1)) return rcx;          // |S| row sums + rank 0's stop decision
             if (ec) HIPCHK(hipEventRecord(ec, st));
             hipExtLaunchKernelGGL(k_xt_rows_apply, dim3(n2b), dim3(XT_NT), 0, st, e2, e3, 0, ns, nK, (const double *)xbuf, (const int *)srow, (const double *)sS,
@@ -899,7 +973,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         } else
             hipExtLaunchKernelGGL((k_xt_rows<0>), dim3(n2b), dim3(XT_NT), 0, st, e2, e3, 0, ns, nK, nW, ns_pad, (const int2 *)wrange, (const int *)nitem_w,
                                   (const double *)rowpart, (const double *)colpart, (const int *)srow, (const double *)sS, (const double *)p, t,
-                                  part_pt, (const XCtrl *)ctrl, (double *)nullptr, m, (const int *)nsrank, 0, (const double *)r);
+                                  part_pt, (const XCtrl *)ctrl, (double *)nullptr, m, (const int *)nsrank, 0, (const double *)r, 0, nW);
         return 0;
     };
 
@@ -997,6 +1071,86 @@ int xt_power(dkmc_gpubuf *buf, const XParams &P, const int *aflag, const int *at
     KCHK();
     (void)P;
     return 0;
+}
+
+// ---- measurement aid (bench.py: strong-scaling model; no counterpart in the reference) -------------------------------------------
+// Times, on the X left resident by the last single-GPU solve, what ONE rank of an nranks-way sharded solve would run per CG
+// iteration: the apply kernel over that rank's share of the work items (built with the work-item size an nranks run uses) plus the
+// neighbour part, and the three kernels around the exchange (partial row sums, finish, vector step).  The exchange itself (one
+// all-reduce of |S| + 1 doubles) cannot be measured on one GPU.  Vectors are scratch: the numbers computed here are discarded.
+extern "C" int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_us, double *side_us, int *items_out, long long *subblocks_out)
+{
+    Engine &e = eng(); hipStream_t st = e.stream; const XTState &X = g_xt;
+    if (!X.valid || comm_attached() || X.nitems <= 0 || X.tile_n != X.ntiles) return dkmc_fail(13, "xt_time_share: needs the X of a single-GPU solve", __FILE__, __LINE__);
+    if (nranks < 1 || rank < 0 || rank >= nranks || reps < 1) return dkmc_fail(13, "xt_time_share: bad arguments", __FILE__, __LINE__);
+    const int nK = X.nK, nW = X.nW, ns = X.ns, ns_pad = X.ns_pad, m = X.Nsub, ntiles = X.ntiles;
+    const int kc = std::max(1, std::min(XT_MAXKC, ntiles / nranks / 4096));
+    XShare sh{};
+    int rc = xt_build_items(nK, nW, kc, ntiles, X.nsub_total, (const int *)g_xb.toff, (const XTile *)g_xb.tiles, nranks, rank,
+                            S_XT_T_NITEMW, S_XT_T_ITEMS, S_XT_T_ISUB, &sh);
+    if (rc) return rc;
+    const int item_n = sh.item_n, i0 = sh.item_lo;
+    const XItem *items = sh.items; const int *nitem_w = sh.nitem_w;
+    double *colpart = (double *)scratch(S_XT_T_COLPART, (size_t)sh.maxchunk * ns_pad * 8);
+    if (!colpart) return e.err_code;
+    HIPCHK(hipMemsetAsync(colpart, 0, (size_t)sh.maxchunk * ns_pad * 8, st));
+    if (items_out) *items_out = item_n;
+    if (subblocks_out) *subblocks_out = sh.sub_n;
+    // scratch vectors of the last solve (their contents do not matter) + a private y and control block
+    double *sc = (double *)e.buf[S_CG_S], *r = (double *)e.buf[S_CG_R], *p = (double *)e.buf[S_CG_P], *t = (double *)e.buf[S_CG_T], *q = (double *)e.buf[S_XT_Q];
+    double *vS = (double *)e.buf[S_CG_PS], *part = (double *)e.buf[S_CG_PART];
+    double *ytmp = (double *)scratch(S_MISC3, (size_t)(m + ns + 8) * 8);
+    XCtrl *ctrl = (XCtrl *)scratch(S_MISC2, 256);
+    if (!ytmp || !ctrl || !sc || !r || !p || !t || !q || !vS || !part) return e.err_code;
+    double *xbuf = ytmp + m;
+    double *qS = vS, *sS = vS + ns_pad, *part_pt = part, *part_rr = part + 4096;
+    HIPCHK(hipMemsetAsync(ctrl, 0, sizeof(XCtrl), st));
+    HIPCHK(hipMemsetAsync(ytmp, 0, (size_t)(m + ns + 8) * 8, st));
+    const int ntb = (item_n + 3) / 4, nsb = (std::max(m - 2, 1) + XT_NT / 8 - 1) / (XT_NT / 8);
+    const int n2b = xt_grid(std::max(std::max(nK, (m + 4095) / 4096), 1), 1, 1024), gv = xt_grid(m, XT_NT * 4, 256);
+    const bool nt_loads = (size_t)sh.sub_n * XT_SUB * 8 > ((size_t)200 << 20);
+    auto apply = [&]() {
+#define XT_TS_ARGS item_n, (const XItem *)items + i0, (const XTile *)g_xb.tiles, 0, (const double *)g_xb.tval, (const double *)qS, nW, ns_pad, \
+                   g_xb.rowpart, colpart, (const XCtrl *)ctrl, ntb, nsb, m, (const xrp_t *)g_xb.rp, (const int *)g_xb.ci, (const double *)g_xb.val, \
+                   (const double *)q, (const double *)sc, (const int *)g_xb.nsrank, t
+        if (nt_loads) hipLaunchKernelGGL((k_xt_apply<1>), dim3(ntb + nsb + 2), dim3(XT_NT), 0, st, XT_TS_ARGS);
+        else hipLaunchKernelGGL((k_xt_apply<0>), dim3(ntb + nsb + 2), dim3(XT_NT), 0, st, XT_TS_ARGS);
+#undef XT_TS_ARGS
+    };
+    auto side = [&](int which, int it) {
+        if (which == 0)
+            hipLaunchKernelGGL((k_xt_rows<1>), dim3(n2b), dim3(XT_NT), 0, st, ns, nK, nW, ns_pad, (const int2 *)g_xb.wrange, (const int *)nitem_w, (const double *)g_xb.rowpart,
+                               (const double *)colpart, (const int *)g_xb.srow, (const double *)sS, (const double *)p, t, part_pt, (const XCtrl *)ctrl, xbuf,
+                               m, (const int *)g_xb.nsrank, 0, (const double *)r, sh.w_lo, sh.w_hi);
+        else if (which == 1)
+            hipLaunchKernelGGL(k_xt_rows_apply, dim3(n2b), dim3(XT_NT), 0, st, ns, nK, (const double *)xbuf, (const int *)g_xb.srow, (const double *)sS,
+                               (const double *)p, t, part_pt, ctrl, m, (const int *)g_xb.nsrank, (const double *)r);
+        else
+            hipLaunchKernelGGL(k_xt_step, dim3(gv), dim3(XT_NT), 0, st, m, it, (const double *)part_pt, n2b, (const double *)(part_rr + 512 * (it & 1)), gv,
+                               part_rr + 512 * ((it + 1) & 1), p, (const double *)t, ytmp, r, (const double *)sc, q, (const int *)g_xb.nsrank, qS, ctrl, -1.0);
+    };
+    apply(); for (int w = 0; w < 3; ++w) side(w, 0);    // warm-up
+    hipEvent_t ev[8];
+    for (auto &x : ev) HIPCHK(hipEventCreate(&x));
+    // each kernel back to back with itself: in a solve the apply kernel and the exchange sit between them, so none of the three
+    // finds its operands in L2 from the previous one either
+    for (int w = 0; w < 4; ++w) {
+        HIPCHK(hipMemsetAsync(ctrl, 0, sizeof(XCtrl), st));
+        HIPCHK(hipEventRecord(ev[2 * w], st));
+        for (int k = 0; k < reps; ++k) { if (w == 0) apply(); else side(w - 1, k); }
+        HIPCHK(hipEventRecord(ev[2 * w + 1], st));
+    }
+    HIPCHK(hipEventSynchronize(ev[7]));
+    for (int w = 0; w < 4; ++w) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ev[2 * w], ev[2 * w + 1]));
+        const double us = (double)ms * 1e3 / reps;
+        if (w == 0) { if (apply_us) *apply_us = us; } else if (side_us) side_us[w - 1] = us;
+    }
+    for (auto &x : ev) (void)hipEventDestroy(x);
+    KCHK();
+    // the vectors of the last solve are garbage now: the next solve rebuilds all of them
+    return e.err_code;
 }
 
 const xrp_t *xt_xs_rp() { return g_xb.rp; }

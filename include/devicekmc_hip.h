@@ -249,6 +249,13 @@ int dkmc_update_temperature_local(dkmc_gpubuf *buf, double step_time, double del
                                   double k_th_interface, double k_th_vacancies, double nn_dist, int num_atoms_contact,
                                   int *n_solves_out, int *steady_out, int *cg_iters_out, double *T_bg_out);
 
+/* measurement aid (bench.py's strong-scaling model): on the tiled X left resident by the last single-GPU update_power, the time per CG
+ * iteration of what ONE rank of an nranks-way sharded solve runs -- apply_us: the apply kernel over that rank's share of the tiles
+ * (work items sized as an nranks run sizes them) + the neighbour part; side_us[3]: partial row sums, finish, vector step (each timed on its own).  The
+ * all-reduce between them cannot be measured on one GPU.  Scratch vectors are overwritten; results of the last solve already
+ * delivered (potentials, I_macro, power) are not. */
+int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_us, double *side_us /* [3] */, int *items_out, long long *subblocks_out);
+
 /* ---- multi-GPU: one simulation advanced in lockstep by N processes, one GPU each (no reference counterpart) ----
  * While a communicator is attached, update_power_gpu_sparse generates, stores and streams the tunnelling block of X in per-rank
  * shares (tiled X, the default) and completes the S-rows' sums with ONE in-place all-reduce of |S| + 1 doubles per matrix-vector

@@ -126,12 +126,15 @@ class Sim:
             pr["pair_ms"] += st["pair_ms"]; pr["pair_n"] += 1 if st["pair_ms"] > 0 else 0
         return t5 - t0
 
-    def run(self, steps, warmup, budget_s=None, barrier=None):
-        """warmup untimed steps, then `steps` timed ones (fewer if they would not fit budget_s; at least one).  Returns (seconds, steps)."""
+    def run(self, steps, warmup, budget_s=None, barrier=None, agree=None):
+        """warmup untimed steps, then `steps` timed ones (fewer if they would not fit budget_s; at least one).  Returns (seconds, steps).
+        agree: maps a local number to the one every rank uses (rank 0's) -- the budget decisions of ranks in lockstep."""
         import torch
+        agree = agree or (lambda v: v)
         tw = 0.0
         for _ in range(warmup):
             tw = self.step(False)
+        tw = agree(tw)
         if budget_s is not None and warmup > 0 and tw * steps > budget_s:
             steps = max(1, int(budget_s / tw))
         self.L.dkmc_set_profiling(1)
@@ -143,8 +146,9 @@ class Sim:
         done = 0
         for _ in range(steps):
             self.step(True); done += 1
-            if budget_s is not None and warmup == 0 and done < steps and (time.perf_counter() - t0) / done * (done + 1) > budget_s:
-                break
+            if budget_s is not None and warmup == 0 and done < steps:
+                if agree(1.0 if (time.perf_counter() - t0) / done * (done + 1) > budget_s else 0.0) != 0.0:
+                    break
         torch.cuda.synchronize()
         if barrier: barrier()
         torch.cuda.synchronize()
@@ -521,7 +525,8 @@ def main():
             sim = Sim(name, devname, kmc_seed=parallel.replica_kmc_seed(1, rank))
         big = sim.s.N > 150000
         warm = args.warmup if not big else min(args.warmup, 1)
-        elapsed, n = sim.run(args.steps, warm, budget_s=args.budget if big else None, barrier=parallel.barrier)
+        elapsed, n = sim.run(args.steps, warm, budget_s=args.budget if big else None, barrier=parallel.barrier,
+                             agree=(lambda v: parallel.from_rank0(v, red_dev)) if args.mode == "sharded" else None)
         # every rank must have timed the same number of steps (the budget rule uses local clocks)
         import torch.distributed as dist
         tn = torch.tensor([float(n)], dtype=torch.float64, device=red_dev)

@@ -6,8 +6,10 @@
 //   * tiled X (xt.hip, default): the work items (runs of tiles of the tunnelling block) are dealt to the ranks in contiguous,
 //     byte-balanced shares; a rank generates, stores and streams only its tiles, forms its partial sum of every S-row and ONE
 //     in-place all-reduce (|S| + 1 doubles: the row sums and rank 0's stop decision) completes them.  Every rank receives the
-//     same bits and takes its control decisions from that buffer alone, so no rank can leave the iteration loop while another
-//     waits in the collective.  The result equals the single-GPU one to rounding (the all-reduce regroups the sums).
+//     same stop flag (only rank 0 contributes to it, so it is exact whatever the all-reduce's grouping) and takes its control
+//     decisions from that buffer alone, so no rank can leave the iteration loop while another waits in the collective.  The
+//     solution and the power row sums are re-published from rank 0, so the ranks' states stay bit-identical even under an
+//     all-reduce whose ranks add in different orders.  The result equals the single-GPU one to rounding.
 //   * CSR X (cg.hip, dkmc_set_x_format(0)): the long rows are dealt to the ranks at row boundaries, balanced by segment count; a
 //     rank multiplies the segments of its rows and adds them per row; one in-place all-gather hands every rank every row sum.
 //     Values and summation orders are those of the single-GPU kernels: bit-identical to the single-GPU run.  (This variant
@@ -158,8 +160,9 @@ int comm_allgather_f64(double *buf, size_t count)
     return 0;
 }
 
-// in-place sum over the ranks of `count` doubles on the engine's stream; every rank ends with the same bits (RCCL reduces each
-// chunk once and distributes the result; the host transport adds the gathered vectors in rank order)
+// in-place sum over the ranks of `count` doubles on the engine's stream.  Ring and tree all-reduces hand every rank the same bits;
+// nothing here RELIES on that: control flow is taken from a flag only rank 0 contributes to (exact under any grouping of the
+// additions), and results that feed later phases are re-published from rank 0 (comm_bcast0_f64).
 int comm_allreduce_sum_f64(double *buf, size_t count)
 {
     Comm &c = g_comm; hipStream_t st = eng().stream;
@@ -185,4 +188,15 @@ int comm_allreduce_sum_f64(double *buf, size_t count)
         return 0;
     }
     return 0;
+}
+
+// every rank ends with rank 0's `count` doubles: the other ranks contribute zeros to a sum, which is exact whatever order the
+// transport adds in (x + 0 + ... + 0 = x), so no rank can be left with different bits.  Used once per solve on its results, so that
+// the replicated phases downstream (power, temperature, event rates) start from identical state on every rank.
+int comm_bcast0_f64(double *buf, size_t count)
+{
+    Comm &c = g_comm; hipStream_t st = eng().stream;
+    if (c.transport == DKMC_COMM_NONE || count == 0) return 0;
+    if (c.rank != 0) HIPCHK(hipMemsetAsync(buf, 0, count * sizeof(double), st));
+    return comm_allreduce_sum_f64(buf, count);
 }

@@ -148,7 +148,8 @@ int comm_attached();
 int comm_nranks();
 int comm_rank();
 int comm_allgather_f64(double *buf, size_t count);     // in place on the engine's stream; rank r owns buf[r*count, (r+1)*count)
-int comm_allreduce_sum_f64(double *buf, size_t count); // in place; every rank ends with the same bits
+int comm_allreduce_sum_f64(double *buf, size_t count); // in place; the sum over the ranks (grouping of the additions is the transport's)
+int comm_bcast0_f64(double *buf, size_t count);        // in place; every rank ends with rank 0's bits
 
 // shared primitives (scan.hip)
 // exclusive prefix sum of n ints (in -> out, out may alias in); total written to d_total (device int) if non-null

@@ -436,11 +436,17 @@ __device__ __forceinline__ double xt_row_block_sum(int k, int nW, int ns_pad, co
     wr.x = max(wr.x, w_lo); wr.y = min(wr.y, w_hi);
     const int wk = k / (XT_C / XT_R);
     const int nc = (wk >= w_lo && wk < w_hi) ? nitem_w[wk] : 0;
+    if (wr.x >= wr.y && nc == 0) return 0.0;                          // nothing of this row block on this rank (uniform over the workgroup)
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     const double *rpp = rowpart + (size_t)k * nW * XT_R + r;
     const double *cpp = colpart + s;
     int w = wr.x + sl, c = sl;
     // four independent loads in flight per list (the lists hold up to nK / 8 terms per slice)
+    for (; c + 56 < nc; c += 64) {                                    // tapered shares end in strips of single-tile items: up to nK terms
+        const double v0 = cpp[(size_t)c * ns_pad], v1 = cpp[(size_t)(c + 8) * ns_pad], v2 = cpp[(size_t)(c + 16) * ns_pad], v3 = cpp[(size_t)(c + 24) * ns_pad];
+        const double v4 = cpp[(size_t)(c + 32) * ns_pad], v5 = cpp[(size_t)(c + 40) * ns_pad], v6 = cpp[(size_t)(c + 48) * ns_pad], v7 = cpp[(size_t)(c + 56) * ns_pad];
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3; a0 += v4; a1 += v5; a2 += v6; a3 += v7;
+    }
     for (; c + 24 < nc; c += 32) { a0 += cpp[(size_t)c * ns_pad]; a1 += cpp[(size_t)(c + 8) * ns_pad]; a2 += cpp[(size_t)(c + 16) * ns_pad]; a3 += cpp[(size_t)(c + 24) * ns_pad]; }
     for (; c < nc; c += 8) a0 += cpp[(size_t)c * ns_pad];
     for (; w + 24 < wr.y; w += 32) { a0 += rpp[(size_t)w * XT_R]; a1 += rpp[(size_t)(w + 8) * XT_R]; a2 += rpp[(size_t)(w + 16) * XT_R]; a3 += rpp[(size_t)(w + 24) * XT_R]; }
@@ -755,12 +761,15 @@ static int xt_tile_sums(const double *vS, double *out, int vpos)
     if (X.item_n > 0)
         hipLaunchKernelGGL((k_xt_tiles_only<OP>), dim3((X.item_n + 3) / 4), dim3(XT_NT), 0, st, X.item_n, (const XItem *)g_xb.items + X.item_lo,
                            (const XTile *)g_xb.tiles, (int)X.sub_base, (const double *)g_xb.tval, vS, X.nW, X.ns_pad, g_xb.rowpart, g_xb.colpart, vpos);
-    hipLaunchKernelGGL((k_xt_rows<1>), dim3(xt_grid(X.nK, 1, 1024)), dim3(XT_NT), 0, st, X.ns, X.nK, X.nW, X.ns_pad, (const int2 *)g_xb.wrange,
+    hipLaunchKernelGGL((k_xt_rows<1>), dim3(std::max(X.nK, 1)), dim3(XT_NT), 0, st, X.ns, X.nK, X.nW, X.ns_pad, (const int2 *)g_xb.wrange,
                        (const int *)g_xb.nitem_w, (const double *)g_xb.rowpart, (const double *)g_xb.colpart, (const int *)nullptr,
                        (const double *)nullptr, (const double *)nullptr, (double *)nullptr, (double *)nullptr, (const XCtrl *)nullptr, out,
                        0, (const int *)nullptr, 0, (const double *)nullptr, X.w_lo, X.w_hi);
     KCHK();
-    if (comm_attached()) { int rc = comm_allreduce_sum_f64(out, (size_t)X.ns); if (rc) return rc; }
+    if (comm_attached()) {                                    // complete the sums, then rank 0's bits for everyone (diagonal, power)
+        int rc = comm_allreduce_sum_f64(out, (size_t)X.ns); if (rc) return rc;
+        rc = comm_bcast0_f64(out, (size_t)X.ns); if (rc) return rc;
+    }
     return 0;
 }
 
@@ -963,9 +972,9 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         else hipExtLaunchKernelGGL((k_xt_apply<0>), dim3(ntb + nsb + 2), dim3(XT_NT), 0, st, e0, e1, 0, XT_APPLY_ARGS);
 #undef XT_APPLY_ARGS
         if (sharded && ns > 0) {
-            hipLaunchKernelGGL((k_xt_rows<1>), dim3(n2b), dim3(XT_NT), 0, st, ns, nK, nW, ns_pad, (const int2 *)wrange, (const int *)nitem_w, (const double *)rowpart,
+            hipLaunchKernelGGL((k_xt_rows<1>), dim3(std::max(nK, 1)), dim3(XT_NT), 0, st, ns, nK, nW, ns_pad, (const int2 *)wrange, (const int *)nitem_w, (const double *)rowpart,
                                (const double *)colpart, (const int *)srow, (const double *)sS, (const double *)p, t, part_pt, (const XCtrl *)ctrl, xbuf,
-                               m, (const int *)nsrank, comm_rank() == 0 ? 1 : 0, (const double *)r, X.w_lo, X.w_hi);
+                               m, (const int *)nsrank, comm_rank() == 0 ? 1 : 0, (const double *)r, X.w_lo, X.w_hi);   // no partial arrays here: one workgroup per row block
             if (int rcx = comm_allreduce_sum_f64(xbuf, (size_t)ns + 1)) return rcx;          // |S| row sums + rank 0's stop decision
             if (ec) HIPCHK(hipEventRecord(ec, st));
             hipExtLaunchKernelGGL(k_xt_rows_apply, dim3(n2b), dim3(XT_NT), 0, st, e2, e3, 0, ns, nK, (const double *)xbuf, (const int *)srow, (const double *)sS,
@@ -1025,6 +1034,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
     if (loop_rc) return loop_rc;
     hipLaunchKernelGGL(k_xt_vec_mul, dim3(nbr), dim3(256), 0, st, m, y, (const double *)sc);
     KCHK();
+    if (sharded) { rc = comm_bcast0_f64(y, (size_t)m); if (rc) return rc; }        // the solution every later phase starts from: rank 0's bits
     HIPCHK(hipMemcpyAsync(&X.t_upper, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     e.x_iter_hint = h.iters;
@@ -1119,7 +1129,7 @@ extern "C" int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_
     };
     auto side = [&](int which, int it) {
         if (which == 0)
-            hipLaunchKernelGGL((k_xt_rows<1>), dim3(n2b), dim3(XT_NT), 0, st, ns, nK, nW, ns_pad, (const int2 *)g_xb.wrange, (const int *)nitem_w, (const double *)g_xb.rowpart,
+            hipLaunchKernelGGL((k_xt_rows<1>), dim3(std::max(nK, 1)), dim3(XT_NT), 0, st, ns, nK, nW, ns_pad, (const int2 *)g_xb.wrange, (const int *)nitem_w, (const double *)g_xb.rowpart,
                                (const double *)colpart, (const int *)g_xb.srow, (const double *)sS, (const double *)p, t, part_pt, (const XCtrl *)ctrl, xbuf,
                                m, (const int *)g_xb.nsrank, 0, (const double *)r, sh.w_lo, sh.w_hi);
         else if (which == 1)

@@ -52,6 +52,16 @@ def max_over_ranks(seconds: float, device="cpu") -> float:
     return float(t.item())
 
 
+def from_rank0(value: float, device="cpu") -> float:
+    """Rank 0's value on every rank.  Ranks that advance ONE simulation in lockstep must take every control decision that depends
+    on a local clock (how many steps fit a time budget) from one rank: a rank that stops a step early leaves the others in a collective."""
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.broadcast(t, src=0)
+    return float(t.item())
+
+
 def aggregate_rate(steps_per_rank: int, world: int, elapsed_max: float) -> float:
     """Whole-job throughput: every replica completed steps_per_rank steps within the slowest rank's time."""
     return world * steps_per_rank / elapsed_max

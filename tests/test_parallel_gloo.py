@@ -21,6 +21,7 @@ def _worker(rank, world, port, q):
     parallel.barrier()
     elapsed = parallel.max_over_ranks(1.0 + rank)            # rank 1 is the slow one
     rate = parallel.aggregate_rate(10, w, elapsed)
+    assert parallel.from_rank0(7.0 + rank) == 7.0            # lockstep ranks take clock-dependent decisions from rank 0
     q.put((rank, seed, float(u[0]), elapsed, rate))
     parallel.finalize()
 

@@ -1163,6 +1163,79 @@ extern "C" int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_
     return e.err_code;
 }
 
+// ---- test aid (tests/test_dist_sharded.py; no counterpart in the reference) -----------------------------------------------------
+// Emulates, on the X left resident by the last single-GPU solve, the tile pass of an nranks-way sharded matrix-vector product: for
+// every rank in turn it builds that rank's work items exactly as a sharded assembly does, runs the tile kernel over them into
+// zeroed partial arrays and the partial-row-sum kernel restricted to the rank's windows, and adds the ranks' results.  Reports the
+// largest deviation from the one-GPU tile pass over the same vector, and how many work items / sub-blocks the shares hold in total
+// (each must be covered exactly once).
+__global__ void k_xt_test_vector(int ns, double *__restrict__ v)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < ns) v[s] = 0.5 + (double)(((unsigned)s * 2654435761u) >> 16) / 65536.0;
+}
+__global__ void k_xt_test_accumulate(int ns, double *__restrict__ acc, const double *__restrict__ x)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < ns) acc[s] += x[s];
+}
+extern "C" int dkmc_xt_check_shares(int nranks, double *max_abs_diff, double *max_abs, long long *subblocks_sum, long long *items_sum, int *items_total)
+{
+    Engine &e = eng(); hipStream_t st = e.stream; const XTState &X = g_xt;
+    if (!X.valid || comm_attached() || X.tile_n != X.ntiles) return dkmc_fail(13, "xt_check_shares: needs the X of a single-GPU solve", __FILE__, __LINE__);
+    if (nranks < 1 || nranks > XT_MAXRANKS) return dkmc_fail(13, "xt_check_shares: bad arguments", __FILE__, __LINE__);
+    const int nK = X.nK, nW = X.nW, ns = X.ns, ns_pad = X.ns_pad, ntiles = X.ntiles;
+    if (max_abs_diff) *max_abs_diff = 0.0;
+    if (max_abs) *max_abs = 0.0;
+    if (subblocks_sum) *subblocks_sum = 0;
+    if (items_sum) *items_sum = 0;
+    if (items_total) *items_total = 0;
+    if (ns <= 0 || ntiles <= 0) return 0;
+    double *buf = (double *)scratch(S_XT_T_MISC, (size_t)4 * ns_pad * 8);
+    if (!buf) return e.err_code;
+    double *v = buf, *full = buf + ns_pad, *acc = buf + 2 * (size_t)ns_pad, *tmp = buf + 3 * (size_t)ns_pad;
+    const int gb = (ns + 255) / 256;
+    HIPCHK(hipMemsetAsync(buf, 0, (size_t)4 * ns_pad * 8, st));
+    hipLaunchKernelGGL(k_xt_test_vector, dim3(gb), dim3(256), 0, st, ns, v);
+    int rc = xt_tile_sums<0>(v, full, 0); if (rc) return rc;
+    const size_t rowpart_bytes = (size_t)((long long)nK * nW + 1) * XT_R * 8;
+    const int kc = std::max(1, std::min(XT_MAXKC, ntiles / nranks / 4096));
+    long long sb_sum = 0, it_sum = 0;
+    for (int r = 0; r < nranks; ++r) {
+        XShare sh{};
+        rc = xt_build_items(nK, nW, kc, ntiles, X.nsub_total, (const int *)g_xb.toff, (const XTile *)g_xb.tiles, nranks, r,
+                            S_XT_T_NITEMW, S_XT_T_ITEMS, S_XT_T_ISUB, &sh);
+        if (rc) return rc;
+        if (items_total) *items_total = sh.nitems;
+        sb_sum += sh.sub_n; it_sum += sh.item_n;
+        double *colpart = (double *)scratch(S_XT_T_COLPART, (size_t)sh.maxchunk * ns_pad * 8);
+        if (!colpart) return e.err_code;
+        HIPCHK(hipMemsetAsync(colpart, 0, (size_t)sh.maxchunk * ns_pad * 8, st));      // what a rank's assembly does: cells of tiles it does not own stay zero
+        HIPCHK(hipMemsetAsync(g_xb.rowpart, 0, rowpart_bytes, st));
+        if (sh.item_n > 0)
+            hipLaunchKernelGGL((k_xt_tiles_only<0>), dim3((sh.item_n + 3) / 4), dim3(XT_NT), 0, st, sh.item_n, (const XItem *)sh.items + sh.item_lo,
+                               (const XTile *)g_xb.tiles, 0, (const double *)g_xb.tval, (const double *)v, nW, ns_pad, g_xb.rowpart, colpart, 0);
+        hipLaunchKernelGGL((k_xt_rows<1>), dim3(std::max(nK, 1)), dim3(XT_NT), 0, st, ns, nK, nW, ns_pad, (const int2 *)g_xb.wrange,
+                           (const int *)sh.nitem_w, (const double *)g_xb.rowpart, (const double *)colpart, (const int *)nullptr,
+                           (const double *)nullptr, (const double *)nullptr, (double *)nullptr, (double *)nullptr, (const XCtrl *)nullptr, tmp,
+                           0, (const int *)nullptr, 0, (const double *)nullptr, sh.w_lo, sh.w_hi);
+        hipLaunchKernelGGL(k_xt_test_accumulate, dim3(gb), dim3(256), 0, st, ns, acc, (const double *)tmp);
+        KCHK();
+    }
+    HIPCHK(hipMemsetAsync(g_xb.rowpart, 0, rowpart_bytes, st));       // the resident layout again: every cell with a tile is rewritten by each apply
+    std::vector<double> hf(ns), ha(ns);
+    HIPCHK(hipMemcpyAsync(hf.data(), full, (size_t)ns * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(ha.data(), acc, (size_t)ns * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    double md = 0.0, ma = 0.0;
+    for (int i = 0; i < ns; ++i) { md = std::max(md, fabs(hf[i] - ha[i])); ma = std::max(ma, fabs(hf[i])); }
+    if (max_abs_diff) *max_abs_diff = md;
+    if (max_abs) *max_abs = ma;
+    if (subblocks_sum) *subblocks_sum = sb_sum;
+    if (items_sum) *items_sum = it_sum;
+    return e.err_code;
+}
+
 const xrp_t *xt_xs_rp() { return g_xb.rp; }
 const int *xt_xs_col() { return g_xb.ci; }
 const double *xt_xs_val() { return g_xb.val; }

@@ -255,6 +255,11 @@ int dkmc_update_temperature_local(dkmc_gpubuf *buf, double step_time, double del
  * all-reduce between them cannot be measured on one GPU.  Scratch vectors are overwritten; results of the last solve already
  * delivered (potentials, I_macro, power) are not. */
 int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_us, double *side_us /* [3] */, int *items_out, long long *subblocks_out);
+/* Test aid: emulates on ONE GPU the tile pass of an nranks-way sharded matrix-vector product over the X of the last single-GPU solve
+ * (every rank's work items built as a sharded assembly builds them, partial arrays zeroed per rank, partial row sums restricted to
+ * the rank's windows) and compares the sum of the ranks' results with the one-GPU pass.  subblocks_sum / items_sum: totals over the
+ * shares (must equal the stored sub-blocks / items_total: every tile in exactly one share). */
+int dkmc_xt_check_shares(int nranks, double *max_abs_diff, double *max_abs, long long *subblocks_sum, long long *items_sum, int *items_total);
 
 /* ---- multi-GPU: one simulation advanced in lockstep by N processes, one GPU each (no reference counterpart) ----
  * While a communicator is attached, update_power_gpu_sparse generates, stores and streams the tunnelling block of X in per-rank

@@ -116,6 +116,24 @@ def test_two_ranks_lockstep_bit_identical():
     assert abs(got0[3]["comm_local_segments"] - got1[3]["comm_local_segments"]) <= 64      # balanced up to one row
 
 
+def test_emulated_shares_cover_the_tunnelling_block():
+    """Shares of 2 ... 64 ranks built on one GPU as a sharded assembly builds them (dkmc_xt_check_shares): every stored sub-block and
+    every work item in exactly one share; the ranks' partial row sums add up to the one-GPU tile pass."""
+    import ctypes as C
+    import __graft_entry__ as g
+    g.build()
+    from devicekmc_amd import lib
+    ref = _supersteps(1, fmt=1, big=True)
+    L = lib.load()
+    for nr in (1, 2, 3, 8, 64):
+        md, ma, sb, its, itot = C.c_double(), C.c_double(), C.c_longlong(), C.c_longlong(), C.c_int()
+        lib.check(L.dkmc_xt_check_shares(nr, C.byref(md), C.byref(ma), C.byref(sb), C.byref(its), C.byref(itot)))
+        assert sb.value == ref[3]["xt_subblocks"] and its.value == itot.value > 0, (nr, sb.value, its.value, itot.value)
+        assert ma.value > 0 and md.value <= 1e-12 * ma.value, (nr, md.value, ma.value)
+    assert L.dkmc_xt_check_shares(65, None, None, None, None, None) != 0        # more ranks than the split table holds: refused
+    L.dkmc_clear_error()
+
+
 def test_rccl_transport_one_rank():
     import __graft_entry__ as g
     g.build()

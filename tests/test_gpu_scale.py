@@ -11,6 +11,9 @@ assemble it either (int32 CSR; hours of WKB integrals on the CPU).  So the check
     triangles of the tiled X and the solve, at full size;
   * the bookkeeping identities of the tiled X (entries of the neighbour part + twice the upper-triangle entries of the tiles =
     entries of X; the solver's stop test met);
+  * the 2-, 5- and 8-way sharding of the tunnelling block, emulated rank by rank on this one GPU (dkmc_xt_check_shares: work items
+    built as a sharded assembly builds them -- run length 9, tapered share ends --, partial sums restricted to the rank's
+    windows): every sub-block in exactly one share, the ranks' partial row sums add up to the one-GPU product;
   * run-to-run bit identity of (KMC time, I_macro, T_bg) over a repeated first superstep.
 """
 import os
@@ -103,6 +106,15 @@ def test_tile10_full_superstep_properties():
     st1 = host.get_stats()
     assert st1["cg_rr_X"] <= p.cg_tol ** 2 and abs(st1["X_nnz"] - st["X_nnz"]) < 1e-3 * st["X_nnz"]
     assert np.isfinite(dt1) and np.isfinite(dev.imacro) and dev.T_bg >= p.background_temp
+    # ---- the shares of an N-GPU run, one after the other on this GPU ----
+    import ctypes as C
+    from devicekmc_amd import lib
+    L = lib.load()
+    for nr in (2, 5, 8):
+        md, ma, sb, its, itot = C.c_double(), C.c_double(), C.c_longlong(), C.c_longlong(), C.c_int()
+        lib.check(L.dkmc_xt_check_shares(nr, C.byref(md), C.byref(ma), C.byref(sb), C.byref(its), C.byref(itot)))
+        assert sb.value == st1["xt_subblocks"] and its.value == itot.value > 0, (nr, sb.value, its.value, itot.value)
+        assert ma.value > 0 and md.value <= 1e-12 * ma.value, (nr, md.value, ma.value)      # regrouped fp64 sums of <= 3e3 terms
     del gb, sim, dev
     torch.cuda.empty_cache()
     # ---- run-to-run: a second fresh simulation reproduces superstep 0 bit for bit ----

@@ -179,7 +179,8 @@ def rooflines(sim, local_share=1.0):
             kname = "k_xt_apply"
             bytes_per_launch = (8192.0 * st["xt_local_subblocks"] + (16.0 + 256.0) * st["spmv_tiles"] * local_share
                                 + (32.0 + 2048.0) * (st["comm_local_segments"] if st["comm_ranks"] else st["xt_items"])
-                                + 12.0 * st["xt_sparse_nnz"] + 28.0 * rows_all)
+                                + (0.0 if st["xt_split_launch"] else 12.0 * st["xt_sparse_nnz"] + 28.0 * rows_all))
+            # (sharded solve: the timed launch is the tile pass alone; the neighbour part runs on a second stream beside the exchange)
         elif st["spmv_segments"] > 0:
             # CSR X, dense-run mode: k_spmv_segs (8 B per entry of a long run, 24 B per segment; short rows in CSR form)
             kname = "k_spmv_segs"
@@ -243,24 +244,31 @@ def strong_scaling_model(sim, ms_per_step, reps=10):
     """What can be measured of an N-GPU strong-scaling run on ONE GPU (dkmc_xt_time_share): the time per CG iteration of the kernels
     one rank of an N-way sharded solve runs on its share of the tiles (a middle rank's share, work items sized as an N-rank run
     sizes them), each kernel timed on its own.  The model adds an ASSUMED all-reduce latency:
-    T_N = T_1 - iters * (kernels_1 - kernels_N) + iters * allreduce_N."""
+    T_N = T_1 - iters * (iteration_1 - iteration_N), iteration_N = tile pass + max(partial row sums + allreduce_N, neighbour part)
+    + finish + vector step."""
     import ctypes as C
     st = sim.host.get_stats()
     iters = sim.cnt["cg_iters_X"] / max(sim.cnt["steps"], 1)
     rows = {}
     for n in (1, 2, 4, 8):
-        a, r, it, sb = C.c_double(0), (C.c_double * 3)(), C.c_int(0), C.c_longlong(0)
+        a, r, it, sb = C.c_double(0), (C.c_double * 4)(), C.c_int(0), C.c_longlong(0)
         rc = sim.L.dkmc_xt_time_share(n, n // 2, reps, C.byref(a), r, C.byref(it), C.byref(sb))
         if rc != 0:
             sim.L.dkmc_clear_error()
             return {"error": "dkmc_xt_time_share failed"}
         rows[n] = {"apply_us": round(a.value, 2), "partial_row_sums_us": round(r[0], 2), "finish_us": round(r[1], 2), "vector_step_us": round(r[2], 2),
-                   "work_items": it.value, "subblocks": sb.value, "share_GBps": round(8192.0 * sb.value / a.value / 1e3, 1)}
-    # one GPU runs apply + row sums (finish fused in) + vector step; N > 1 runs apply + partial row sums + all-reduce + finish + vector step
+                   "neighbour_part_us": round(r[3], 2), "work_items": it.value, "subblocks": sb.value,
+                   "share_GBps": round(8192.0 * sb.value / a.value / 1e3, 1)}
+    # one GPU: apply (tiles + neighbour part in one launch) + row sums (finish fused in) + vector step.
+    # N > 1: tile pass, then [partial row sums + all-reduce] beside [neighbour part on the second stream], then finish + vector step
     t1 = rows[1]["apply_us"] + rows[1]["partial_row_sums_us"] + rows[1]["vector_step_us"]
     for n in rows:
-        tk = rows[n]["apply_us"] + rows[n]["partial_row_sums_us"] + rows[n]["vector_step_us"] + (rows[n]["finish_us"] if n > 1 else 0.0)
-        tn = ms_per_step - iters * (t1 - tk) * 1e-3 + iters * ALLREDUCE_US_ASSUMED[n] * 1e-3
+        if n == 1:
+            tk = t1
+        else:
+            tk = (rows[n]["apply_us"] + max(rows[n]["partial_row_sums_us"] + ALLREDUCE_US_ASSUMED[n], rows[n]["neighbour_part_us"])
+                  + rows[n]["finish_us"] + rows[n]["vector_step_us"])
+        tn = ms_per_step - iters * (t1 - tk) * 1e-3
         rows[n]["allreduce_us_assumed"] = ALLREDUCE_US_ASSUMED[n]
         rows[n]["modelled_ms_per_step"] = round(tn, 1)
         rows[n]["modelled_speedup"] = round(ms_per_step / tn, 2)

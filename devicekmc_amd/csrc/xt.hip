@@ -139,7 +139,8 @@ __global__ void k_xt_wrange(int nK, int nW, const unsigned *__restrict__ cmask, 
 // (measured at a 1/8 share of the 9.4e5-site stack: 426 us per launch untapered against 357 us at the full-size rate).
 #define XT_MAXRANKS 64
 #define XT_TAPER 2048
-struct XSplit { int n; int tb[XT_MAXRANKS + 1]; int item_lo[XT_MAXRANKS + 1]; int max_items_per_strip; };
+struct XSplit { int n; int tb[XT_MAXRANKS + 1]; int item_lo[XT_MAXRANKS + 1]; int max_items_per_strip;
+                int soff[XT_MAXRANKS + 1], w_first[XT_MAXRANKS + 1], w_last[XT_MAXRANKS + 1]; };   // per share boundary r: sub-block offset and window of tile tb[r]; window of tile tb[r] - 1
 __global__ void k_xt_split(int ntiles, long long nsub_total, const XTile *__restrict__ tiles, int n, XSplit *sp)
 {
     const int r = threadIdx.x;
@@ -180,8 +181,8 @@ __global__ void k_xt_items(int nK, int nW, int kc, int ntiles, const int *__rest
     }
     if (!MODE) { nitem_w[w] = c; atomicMax(&sp->max_items_per_strip, c); }
 }
-// first item of every rank's share (items are in tile order and never cross a share boundary)
-__global__ void k_xt_rank_items(int nitems, const XItem *__restrict__ items, XSplit *sp)
+// first item of every rank's share (items are in tile order and never cross a share boundary) + what the host needs of the boundary tiles
+__global__ void k_xt_rank_items(int nitems, int ntiles, long long nsub_total, const XItem *__restrict__ items, const XTile *__restrict__ tiles, XSplit *sp)
 {
     const int r = threadIdx.x;
     if (r > sp->n) return;
@@ -189,6 +190,9 @@ __global__ void k_xt_rank_items(int nitems, const XItem *__restrict__ items, XSp
     int lo = 0, hi = nitems;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (items[mid].t0 < tb) lo = mid + 1; else hi = mid; }
     sp->item_lo[r] = lo;
+    sp->soff[r] = tb < ntiles ? tiles[tb].soff : (int)nsub_total;
+    sp->w_first[r] = tb < ntiles ? tiles[tb].w : 0;
+    sp->w_last[r] = tb > 0 ? tiles[tb - 1].w : 0;
 }
 
 // ---- fill: values of the stored sub-blocks --------------------------------------------------------------------------------
@@ -358,19 +362,22 @@ __global__ __launch_bounds__(XT_NT) void k_xt_apply(int nitems, const XItem *__r
                                                     double *__restrict__ rowpart, double *__restrict__ colpart, const XCtrl *ctrl,
                                                     int ntb, int nsb, int Nsub, const xrp_t *__restrict__ rp, const int *__restrict__ ci,
                                                     const double *__restrict__ val, const double *__restrict__ q, const double *__restrict__ sc,
-                                                    const int *__restrict__ nsrank, double *__restrict__ t)
+                                                    const int *__restrict__ nsrank, double *__restrict__ t, int vb0)
 {
     __shared__ double red[XT_NT / 64];
     __shared__ __attribute__((aligned(16))) double lcol[XT_NT / 64][2 * XT_C];
-    if ((int)blockIdx.x >= 2 && (int)blockIdx.x < 2 + ntb) {
+    // vb0: role offset of the launch's first workgroup.  0: the whole product in one launch.  A sharded solve launches the tile
+    // roles alone (vb0 = 2, ntb workgroups) and the neighbour part alone (ntb = 0) on a second stream, beside the exchange.
+    const int vb = (int)blockIdx.x + vb0;
+    if (vb >= 2 && vb < 2 + ntb) {
         const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        const int item = ((int)blockIdx.x - 2) * (XT_NT / 64) + wv;
+        const int item = (vb - 2) * (XT_NT / 64) + wv;
         const XItem it = items[min(item, nitems - 1)];              // in flight together with the stop flag
         if (ctrl->done || item >= nitems) return;                   // (the flag is set only by the last kernel of an iteration: uniform over the launch)
         xt_tile_role<0, NTL>(it, tiles, sub_base, tval, qS, nW, ns_pad, rowpart, colpart, true, lcol[wv], lcol[wv] + XT_C);
         return;
     }
-    const int bid = (int)blockIdx.x < 2 ? nsb + (int)blockIdx.x : (int)blockIdx.x - 2 - ntb;
+    const int bid = vb < 2 ? nsb + vb : vb - 2 - ntb;
     if (bid < nsb) {
         // 8 lanes per row; the row's entries are fetched in chunks of 32 with every load of a chunk issued before the first use:
         // three dependent memory latencies per row (row pointers -> values / columns -> q) instead of two per 8 entries
@@ -798,21 +805,34 @@ static int xt_build_items(int nK, int nW, int kc, int ntiles, long long nsub_tot
     XItem *items = (XItem *)scratch(slot_items, (size_t)(nitems + 1) * sizeof(XItem));
     if (!items) return e.err_code;
     hipLaunchKernelGGL((k_xt_items<1>), dim3((nW + 255) / 256), dim3(256), 0, st, nK, nW, kc, ntiles, toff, (const int *)ioff, tiles, sp, nitem_w, items);
-    hipLaunchKernelGGL(k_xt_rank_items, dim3(1), dim3(XT_MAXRANKS + 1), 0, st, nitems, (const XItem *)items, sp);
+    hipLaunchKernelGGL(k_xt_rank_items, dim3(1), dim3(XT_MAXRANKS + 1), 0, st, nitems, ntiles, nsub_total, (const XItem *)items, tiles, sp);
     HIPCHK(hipMemcpyAsync(&h, sp, sizeof(XSplit), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     out->items = items; out->nitems = nitems; out->maxchunk = std::max(1, h.max_items_per_strip);
     out->item_lo = h.item_lo[me]; out->item_n = h.item_lo[me + 1] - h.item_lo[me];
     out->tile_lo = h.tb[me]; out->tile_n = h.tb[me + 1] - h.tb[me];
-    int so[2] = {0, 0};                                             // sub-block offsets of the share's first tile and of the one behind its last
-    for (int q = 0; q < 2; ++q) {
-        const int t = h.tb[me + q];
-        if (t >= ntiles) so[q] = (int)nsub_total;
-        else { XTile td; HIPCHK(hipMemcpy(&td, tiles + t, sizeof(XTile), hipMemcpyDeviceToHost)); so[q] = td.soff; if (q == 0) out->w_lo = td.w; }
+    out->sub_base = h.soff[me]; out->sub_n = h.soff[me + 1] - h.soff[me];
+    out->w_lo = h.w_first[me]; out->w_hi = out->tile_n > 0 ? h.w_last[me + 1] + 1 : out->w_lo;
+    return 0;
+}
+
+// Second stream of the sharded solve: the neighbour part of the product (replicated on every rank, ~0.3 GB at 9.4e5 sites) runs
+// here, beside the tile pass, the partial row sums and the all-reduce on the engine's stream; the two meet again before the rows
+// are finished.  Events from a ring: a wait refers to the record that preceded it, the host may run a whole batch ahead.
+#define XT_SIDE_RING 64
+struct XSide { hipStream_t st = nullptr; hipEvent_t a[XT_SIDE_RING], b[XT_SIDE_RING]; int device = -1; unsigned seq = 0; bool ready = false; };
+static XSide g_side;
+static int xt_side_init()
+{
+    XSide &S = g_side; const int dev = eng().device;
+    if (S.ready && S.device == dev) return 0;
+    if (S.ready) { (void)hipStreamDestroy(S.st); for (int i = 0; i < XT_SIDE_RING; ++i) { (void)hipEventDestroy(S.a[i]); (void)hipEventDestroy(S.b[i]); } S.ready = false; }
+    HIPCHK(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
+    for (int i = 0; i < XT_SIDE_RING; ++i) {
+        HIPCHK(hipEventCreateWithFlags(&S.a[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&S.b[i], hipEventDisableTiming));
     }
-    out->sub_base = so[0]; out->sub_n = so[1] - so[0];
-    if (out->tile_n > 0) { XTile td; HIPCHK(hipMemcpy(&td, tiles + h.tb[me + 1] - 1, sizeof(XTile), hipMemcpyDeviceToHost)); out->w_hi = td.w + 1; }
-    else out->w_hi = out->w_lo;
+    S.device = dev; S.seq = 0; S.ready = true;
     return 0;
 }
 
@@ -964,25 +984,41 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
     double *xbuf = nullptr;
     if (sharded) { xbuf = (double *)scratch(S_CG_XCHG, (size_t)(ns + 2) * 8); if (!xbuf) return e.err_code; }
 
+    const bool split = sharded && ns > 0;                 // tile pass + exchange on the engine's stream, neighbour part on the side stream
+    if (split) { rc = xt_side_init(); if (rc) return rc; }
+    e.stats.xt_split_launch = split ? 1 : 0;
     auto matvec = [&](hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t ec) -> int {
-#define XT_APPLY_ARGS X.item_n, (const XItem *)items + X.item_lo, (const XTile *)tiles, (int)X.sub_base, (const double *)tval, (const double *)qS, nW, ns_pad, \
-                      rowpart, colpart, (const XCtrl *)ctrl, ntb, nsb, m, (const xrp_t *)rp, (const int *)col, (const double *)val, (const double *)q, \
+#define XT_APPLY_ARGS(NI, NTB) NI, (const XItem *)items + X.item_lo, (const XTile *)tiles, (int)X.sub_base, (const double *)tval, (const double *)qS, nW, ns_pad, \
+                      rowpart, colpart, (const XCtrl *)ctrl, NTB, nsb, m, (const xrp_t *)rp, (const int *)col, (const double *)val, (const double *)q, \
                       (const double *)sc, (const int *)nsrank, t
-        if (nt_loads) hipExtLaunchKernelGGL((k_xt_apply<1>), dim3(ntb + nsb + 2), dim3(XT_NT), 0, st, e0, e1, 0, XT_APPLY_ARGS);
-        else hipExtLaunchKernelGGL((k_xt_apply<0>), dim3(ntb + nsb + 2), dim3(XT_NT), 0, st, e0, e1, 0, XT_APPLY_ARGS);
-#undef XT_APPLY_ARGS
-        if (sharded && ns > 0) {
+        if (split) {
+            XSide &S = g_side; const int sl = (int)(S.seq++ % XT_SIDE_RING);
+            if (ntb > 0) {
+                if (nt_loads) hipExtLaunchKernelGGL((k_xt_apply<1>), dim3(ntb), dim3(XT_NT), 0, st, e0, e1, 0, XT_APPLY_ARGS(X.item_n, ntb), 2);
+                else hipExtLaunchKernelGGL((k_xt_apply<0>), dim3(ntb), dim3(XT_NT), 0, st, e0, e1, 0, XT_APPLY_ARGS(X.item_n, ntb), 2);
+            } else if (e0) { HIPCHK(hipEventRecord(e0, st)); HIPCHK(hipEventRecord(e1, st)); }     // a rank without tiles: the sampled interval is empty
+            // the neighbour part starts when the tile pass has drained (it would only share the HBM stream with it before) and runs
+            // beside the partial row sums and the exchange; q, the stop flag and the previous readers of t are behind this event too
+            HIPCHK(hipEventRecord(S.a[sl], st));
+            HIPCHK(hipStreamWaitEvent(S.st, S.a[sl], 0));
+            hipLaunchKernelGGL((k_xt_apply<0>), dim3(nsb + 2), dim3(XT_NT), 0, S.st, XT_APPLY_ARGS(0, 0), 0);
+            HIPCHK(hipEventRecord(S.b[sl], S.st));
             hipLaunchKernelGGL((k_xt_rows<1>), dim3(std::max(nK, 1)), dim3(XT_NT), 0, st, ns, nK, nW, ns_pad, (const int2 *)wrange, (const int *)nitem_w, (const double *)rowpart,
                                (const double *)colpart, (const int *)srow, (const double *)sS, (const double *)p, t, part_pt, (const XCtrl *)ctrl, xbuf,
                                m, (const int *)nsrank, comm_rank() == 0 ? 1 : 0, (const double *)r, X.w_lo, X.w_hi);   // no partial arrays here: one workgroup per row block
             if (int rcx = comm_allreduce_sum_f64(xbuf, (size_t)ns + 1)) return rcx;          // |S| row sums + rank 0's stop decision
             if (ec) HIPCHK(hipEventRecord(ec, st));
+            HIPCHK(hipStreamWaitEvent(st, S.b[sl], 0));                                       // the neighbour sums are in t
             hipExtLaunchKernelGGL(k_xt_rows_apply, dim3(n2b), dim3(XT_NT), 0, st, e2, e3, 0, ns, nK, (const double *)xbuf, (const int *)srow, (const double *)sS,
                                   (const double *)p, t, part_pt, ctrl, m, (const int *)nsrank, (const double *)r);
-        } else
-            hipExtLaunchKernelGGL((k_xt_rows<0>), dim3(n2b), dim3(XT_NT), 0, st, e2, e3, 0, ns, nK, nW, ns_pad, (const int2 *)wrange, (const int *)nitem_w,
-                                  (const double *)rowpart, (const double *)colpart, (const int *)srow, (const double *)sS, (const double *)p, t,
-                                  part_pt, (const XCtrl *)ctrl, (double *)nullptr, m, (const int *)nsrank, 0, (const double *)r, 0, nW);
+            return 0;
+        }
+        if (nt_loads) hipExtLaunchKernelGGL((k_xt_apply<1>), dim3(ntb + nsb + 2), dim3(XT_NT), 0, st, e0, e1, 0, XT_APPLY_ARGS(X.item_n, ntb), 0);
+        else hipExtLaunchKernelGGL((k_xt_apply<0>), dim3(ntb + nsb + 2), dim3(XT_NT), 0, st, e0, e1, 0, XT_APPLY_ARGS(X.item_n, ntb), 0);
+#undef XT_APPLY_ARGS
+        hipExtLaunchKernelGGL((k_xt_rows<0>), dim3(n2b), dim3(XT_NT), 0, st, e2, e3, 0, ns, nK, nW, ns_pad, (const int2 *)wrange, (const int *)nitem_w,
+                              (const double *)rowpart, (const double *)colpart, (const int *)srow, (const double *)sS, (const double *)p, t,
+                              part_pt, (const XCtrl *)ctrl, (double *)nullptr, m, (const int *)nsrank, 0, (const double *)r, 0, nW);
         return 0;
     };
 
@@ -1119,14 +1155,24 @@ extern "C" int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_
     const int ntb = (item_n + 3) / 4, nsb = (std::max(m - 2, 1) + XT_NT / 8 - 1) / (XT_NT / 8);
     const int n2b = xt_grid(std::max(std::max(nK, (m + 4095) / 4096), 1), 1, 1024), gv = xt_grid(m, XT_NT * 4, 256);
     const bool nt_loads = (size_t)sh.sub_n * XT_SUB * 8 > ((size_t)200 << 20);
-    auto apply = [&]() {
-#define XT_TS_ARGS item_n, (const XItem *)items + i0, (const XTile *)g_xb.tiles, 0, (const double *)g_xb.tval, (const double *)qS, nW, ns_pad, \
-                   g_xb.rowpart, colpart, (const XCtrl *)ctrl, ntb, nsb, m, (const xrp_t *)g_xb.rp, (const int *)g_xb.ci, (const double *)g_xb.val, \
+    // one GPU: the whole product in one launch.  nranks > 1: the tile pass alone, as the sharded solve launches it; the neighbour part
+    // (which that solve runs on a second stream beside the exchange) is timed on its own as the fourth side kernel.
+    auto apply = [&](int part) {
+#define XT_TS_ARGS(NI, NTB) NI, (const XItem *)items + i0, (const XTile *)g_xb.tiles, 0, (const double *)g_xb.tval, (const double *)qS, nW, ns_pad, \
+                   g_xb.rowpart, colpart, (const XCtrl *)ctrl, NTB, nsb, m, (const xrp_t *)g_xb.rp, (const int *)g_xb.ci, (const double *)g_xb.val, \
                    (const double *)q, (const double *)sc, (const int *)g_xb.nsrank, t
-        if (nt_loads) hipLaunchKernelGGL((k_xt_apply<1>), dim3(ntb + nsb + 2), dim3(XT_NT), 0, st, XT_TS_ARGS);
-        else hipLaunchKernelGGL((k_xt_apply<0>), dim3(ntb + nsb + 2), dim3(XT_NT), 0, st, XT_TS_ARGS);
+        if (part == 2) hipLaunchKernelGGL((k_xt_apply<0>), dim3(nsb + 2), dim3(XT_NT), 0, st, XT_TS_ARGS(0, 0), 0);
+        else if (part == 1) {
+            if (ntb <= 0) return;
+            if (nt_loads) hipLaunchKernelGGL((k_xt_apply<1>), dim3(ntb), dim3(XT_NT), 0, st, XT_TS_ARGS(item_n, ntb), 2);
+            else hipLaunchKernelGGL((k_xt_apply<0>), dim3(ntb), dim3(XT_NT), 0, st, XT_TS_ARGS(item_n, ntb), 2);
+        } else {
+            if (nt_loads) hipLaunchKernelGGL((k_xt_apply<1>), dim3(ntb + nsb + 2), dim3(XT_NT), 0, st, XT_TS_ARGS(item_n, ntb), 0);
+            else hipLaunchKernelGGL((k_xt_apply<0>), dim3(ntb + nsb + 2), dim3(XT_NT), 0, st, XT_TS_ARGS(item_n, ntb), 0);
+        }
 #undef XT_TS_ARGS
     };
+    const int apply_part = nranks > 1 ? 1 : 0;
     auto side = [&](int which, int it) {
         if (which == 0)
             hipLaunchKernelGGL((k_xt_rows<1>), dim3(std::max(nK, 1)), dim3(XT_NT), 0, st, ns, nK, nW, ns_pad, (const int2 *)g_xb.wrange, (const int *)nitem_w, (const double *)g_xb.rowpart,
@@ -1139,23 +1185,24 @@ extern "C" int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_
             hipLaunchKernelGGL(k_xt_step, dim3(gv), dim3(XT_NT), 0, st, m, it, (const double *)part_pt, n2b, (const double *)(part_rr + 512 * (it & 1)), gv,
                                part_rr + 512 * ((it + 1) & 1), p, (const double *)t, ytmp, r, (const double *)sc, q, (const int *)g_xb.nsrank, qS, ctrl, -1.0);
     };
-    apply(); for (int w = 0; w < 3; ++w) side(w, 0);    // warm-up
-    hipEvent_t ev[8];
+    apply(apply_part); for (int w = 0; w < 3; ++w) side(w, 0);    // warm-up
+    hipEvent_t ev[10];
     for (auto &x : ev) HIPCHK(hipEventCreate(&x));
     // each kernel back to back with itself: in a solve the apply kernel and the exchange sit between them, so none of the three
     // finds its operands in L2 from the previous one either
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < 5; ++w) {
         HIPCHK(hipMemsetAsync(ctrl, 0, sizeof(XCtrl), st));
         HIPCHK(hipEventRecord(ev[2 * w], st));
-        for (int k = 0; k < reps; ++k) { if (w == 0) apply(); else side(w - 1, k); }
+        if (w < 4 || nranks > 1)
+            for (int k = 0; k < reps; ++k) { if (w == 0) apply(apply_part); else if (w == 4) apply(2); else side(w - 1, k); }
         HIPCHK(hipEventRecord(ev[2 * w + 1], st));
     }
-    HIPCHK(hipEventSynchronize(ev[7]));
-    for (int w = 0; w < 4; ++w) {
+    HIPCHK(hipEventSynchronize(ev[9]));
+    for (int w = 0; w < 5; ++w) {
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, ev[2 * w], ev[2 * w + 1]));
         const double us = (double)ms * 1e3 / reps;
-        if (w == 0) { if (apply_us) *apply_us = us; } else if (side_us) side_us[w - 1] = us;
+        if (w == 0) { if (apply_us) *apply_us = us; } else if (side_us) side_us[w - 1] = (w == 4 && nranks == 1) ? 0.0 : us;
     }
     for (auto &x : ev) (void)hipEventDestroy(x);
     KCHK();

@@ -89,7 +89,7 @@ typedef struct dkmc_stats {
     long long xt_subblocks, xt_local_subblocks;
     int xt_items, xt_kc;
     long long xt_sparse_nnz;
-    int xt_ns, xt_pad;
+    int xt_ns, xt_split_launch;           /* 1: sharded solve, the neighbour part of A*p runs on a second stream beside the exchange */
     /* profiling on: HIP-event time of the whole iteration loop of the last CG solve on K (and the iterations it covers), and
      * of the last pair-sum kernel */
     double kcg_ms;
@@ -251,10 +251,11 @@ int dkmc_update_temperature_local(dkmc_gpubuf *buf, double step_time, double del
 
 /* measurement aid (bench.py's strong-scaling model): on the tiled X left resident by the last single-GPU update_power, the time per CG
  * iteration of what ONE rank of an nranks-way sharded solve runs -- apply_us: the apply kernel over that rank's share of the tiles
- * (work items sized as an nranks run sizes them) + the neighbour part; side_us[3]: partial row sums, finish, vector step (each timed on its own).  The
+ * (work items sized as an nranks run sizes them) + the neighbour part; side_us[4]: partial row sums, finish, vector step, and -- nranks > 1, where apply_us is the tile pass alone -- the
+ * neighbour part that a sharded solve runs on a second stream beside the exchange (each timed on its own).  The
  * all-reduce between them cannot be measured on one GPU.  Scratch vectors are overwritten; results of the last solve already
  * delivered (potentials, I_macro, power) are not. */
-int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_us, double *side_us /* [3] */, int *items_out, long long *subblocks_out);
+int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_us, double *side_us /* [4] */, int *items_out, long long *subblocks_out);
 /* Test aid: emulates on ONE GPU the tile pass of an nranks-way sharded matrix-vector product over the X of the last single-GPU solve
  * (every rank's work items built as a sharded assembly builds them, partial arrays zeroed per rank, partial row sums restricted to
  * the rank's windows) and compares the sum of the ranks' results with the one-GPU pass.  subblocks_sum / items_sum: totals over the

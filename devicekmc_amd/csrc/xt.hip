@@ -351,33 +351,12 @@ __device__ __forceinline__ void xt_tile_role(const XItem it, const XTile *__rest
     }
 }
 
-// Blocks 0, 1: the two driver rows (thousands of entries each: the longest dependent chain of the launch starts first).  Blocks
-// [2, 2 + ntb): tile work items (one per wave).  The rest: the atom rows of Xs, 8 lanes per row, one row per group (no barrier,
-// no partial sums: the p.t dot product is formed by the row kernel).  Non-S rows are finished here (scaled); S rows leave their sparse sum in t for the row kernel.
-// NTL: non-temporal loads of the tile stream once a sweep no longer fits the 256 MiB Infinity Cache (cg.hip: 45 vs 53 us at
-// 240 MB with the default policy, 478 vs 456 us at 1.86 GB).
-template <int NTL>
-__global__ __launch_bounds__(XT_NT) void k_xt_apply(int nitems, const XItem *__restrict__ items, const XTile *__restrict__ tiles, int sub_base,
-                                                    const double *__restrict__ tval, const double *__restrict__ qS, int nW, int ns_pad,
-                                                    double *__restrict__ rowpart, double *__restrict__ colpart, const XCtrl *ctrl,
-                                                    int ntb, int nsb, int Nsub, const xrp_t *__restrict__ rp, const int *__restrict__ ci,
-                                                    const double *__restrict__ val, const double *__restrict__ q, const double *__restrict__ sc,
-                                                    const int *__restrict__ nsrank, double *__restrict__ t, int vb0)
+// The neighbour part Xs of the product.  bid < nsb: atom rows, 8 lanes per row; bid = nsb, nsb + 1: the two driver rows (one
+// workgroup each).
+__device__ __forceinline__ void xt_neigh_roles(int bid, int nsb, int Nsub, const xrp_t *__restrict__ rp, const int *__restrict__ ci,
+                                               const double *__restrict__ val, const double *__restrict__ q, const double *__restrict__ sc,
+                                               const int *__restrict__ nsrank, const XCtrl *ctrl, double *__restrict__ t, double *red)
 {
-    __shared__ double red[XT_NT / 64];
-    __shared__ __attribute__((aligned(16))) double lcol[XT_NT / 64][2 * XT_C];
-    // vb0: role offset of the launch's first workgroup.  0: the whole product in one launch.  A sharded solve launches the tile
-    // roles alone (vb0 = 2, ntb workgroups) and the neighbour part alone (ntb = 0) on a second stream, beside the exchange.
-    const int vb = (int)blockIdx.x + vb0;
-    if (vb >= 2 && vb < 2 + ntb) {
-        const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-        const int item = (vb - 2) * (XT_NT / 64) + wv;
-        const XItem it = items[min(item, nitems - 1)];              // in flight together with the stop flag
-        if (ctrl->done || item >= nitems) return;                   // (the flag is set only by the last kernel of an iteration: uniform over the launch)
-        xt_tile_role<0, NTL>(it, tiles, sub_base, tval, qS, nW, ns_pad, rowpart, colpart, true, lcol[wv], lcol[wv] + XT_C);
-        return;
-    }
-    const int bid = vb < 2 ? nsb + vb : vb - 2 - ntb;
     if (bid < nsb) {
         // 8 lanes per row; the row's entries are fetched in chunks of 32 with every load of a chunk issued before the first use:
         // three dependent memory latencies per row (row pointers -> values / columns -> q) instead of two per 8 entries
@@ -411,6 +390,45 @@ __global__ __launch_bounds__(XT_NT) void k_xt_apply(int nitems, const XItem *__r
     if (p < p1) s0 += val[p] * q[ci[p]];
     const double s = block_sum_all<XT_NT>(s0 + s1, red);
     if (threadIdx.x == 0) t[row] = sc[row] * s;
+}
+// Blocks 0, 1: the two driver rows (thousands of entries each: the longest dependent chain of the launch starts first).  Blocks
+// [2, 2 + ntb): tile work items (one per wave).  The rest: the atom rows of Xs, 8 lanes per row, one row per group (no barrier,
+// no partial sums: the p.t dot product is formed by the row kernel).  Non-S rows are finished here (scaled); S rows leave their sparse sum in t for the row kernel.
+// NTL: non-temporal loads of the tile stream once a sweep no longer fits the 256 MiB Infinity Cache (cg.hip: 45 vs 53 us at
+// 240 MB with the default policy, 478 vs 456 us at 1.86 GB).
+template <int NTL>
+__global__ __launch_bounds__(XT_NT) void k_xt_apply(int nitems, const XItem *__restrict__ items, const XTile *__restrict__ tiles, int sub_base,
+                                                    const double *__restrict__ tval, const double *__restrict__ qS, int nW, int ns_pad,
+                                                    double *__restrict__ rowpart, double *__restrict__ colpart, const XCtrl *ctrl,
+                                                    int ntb, int nsb, int Nsub, const xrp_t *__restrict__ rp, const int *__restrict__ ci,
+                                                    const double *__restrict__ val, const double *__restrict__ q, const double *__restrict__ sc,
+                                                    const int *__restrict__ nsrank, double *__restrict__ t, int vb0)
+{
+    __shared__ double red[XT_NT / 64];
+    __shared__ __attribute__((aligned(16))) double lcol[XT_NT / 64][2 * XT_C];
+    // vb0: role offset of the launch's first workgroup.  0: the whole product in one launch.  A sharded solve launches the tile
+    // roles alone (vb0 = 2, ntb workgroups) and the neighbour part as k_xt_neigh on a second stream, beside the exchange.
+    const int vb = (int)blockIdx.x + vb0;
+    if (vb >= 2 && vb < 2 + ntb) {
+        const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int item = (vb - 2) * (XT_NT / 64) + wv;
+        const XItem it = items[min(item, nitems - 1)];              // in flight together with the stop flag
+        if (ctrl->done || item >= nitems) return;                   // (the flag is set only by the last kernel of an iteration: uniform over the launch)
+        xt_tile_role<0, NTL>(it, tiles, sub_base, tval, qS, nW, ns_pad, rowpart, colpart, true, lcol[wv], lcol[wv] + XT_C);
+        return;
+    }
+    xt_neigh_roles(vb < 2 ? nsb + vb : vb - 2 - ntb, nsb, Nsub, rp, ci, val, q, sc, nsrank, ctrl, t, red);
+}
+// The neighbour part alone (sharded solve: second stream, beside the exchange).  Same role bodies as in k_xt_apply, but compiled
+// without the tile role's registers and LDS: twice the resident waves for what is a chain of three dependent latencies per row
+// (DESIGN.md section 7).
+__global__ __launch_bounds__(XT_NT) void k_xt_neigh(int nsb, int Nsub, const xrp_t *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ val,
+                                                    const double *__restrict__ q, const double *__restrict__ sc, const int *__restrict__ nsrank,
+                                                    const XCtrl *ctrl, double *__restrict__ t)
+{
+    __shared__ double red[XT_NT / 64];
+    const int vb = (int)blockIdx.x;
+    xt_neigh_roles(vb < 2 ? nsb + vb : vb - 2, nsb, Nsub, rp, ci, val, q, sc, nsrank, ctrl, t, red);
 }
 // tiles only (diagonal pass with q = 1, power pass with q = m)
 template <int OP>
@@ -1001,7 +1019,8 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
             // beside the partial row sums and the exchange; q, the stop flag and the previous readers of t are behind this event too
             HIPCHK(hipEventRecord(S.a[sl], st));
             HIPCHK(hipStreamWaitEvent(S.st, S.a[sl], 0));
-            hipLaunchKernelGGL((k_xt_apply<0>), dim3(nsb + 2), dim3(XT_NT), 0, S.st, XT_APPLY_ARGS(0, 0), 0);
+            hipLaunchKernelGGL(k_xt_neigh, dim3(nsb + 2), dim3(XT_NT), 0, S.st, nsb, m, (const xrp_t *)rp, (const int *)col, (const double *)val, (const double *)q,
+                               (const double *)sc, (const int *)nsrank, (const XCtrl *)ctrl, t);
             HIPCHK(hipEventRecord(S.b[sl], S.st));
             hipLaunchKernelGGL((k_xt_rows<1>), dim3(std::max(nK, 1)), dim3(XT_NT), 0, st, ns, nK, nW, ns_pad, (const int2 *)wrange, (const int *)nitem_w, (const double *)rowpart,
                                (const double *)colpart, (const int *)srow, (const double *)sS, (const double *)p, t, part_pt, (const XCtrl *)ctrl, xbuf,
@@ -1161,7 +1180,8 @@ extern "C" int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_
 #define XT_TS_ARGS(NI, NTB) NI, (const XItem *)items + i0, (const XTile *)g_xb.tiles, 0, (const double *)g_xb.tval, (const double *)qS, nW, ns_pad, \
                    g_xb.rowpart, colpart, (const XCtrl *)ctrl, NTB, nsb, m, (const xrp_t *)g_xb.rp, (const int *)g_xb.ci, (const double *)g_xb.val, \
                    (const double *)q, (const double *)sc, (const int *)g_xb.nsrank, t
-        if (part == 2) hipLaunchKernelGGL((k_xt_apply<0>), dim3(nsb + 2), dim3(XT_NT), 0, st, XT_TS_ARGS(0, 0), 0);
+        if (part == 2) hipLaunchKernelGGL(k_xt_neigh, dim3(nsb + 2), dim3(XT_NT), 0, st, nsb, m, (const xrp_t *)g_xb.rp, (const int *)g_xb.ci, (const double *)g_xb.val,
+                                          (const double *)q, (const double *)sc, (const int *)g_xb.nsrank, (const XCtrl *)ctrl, t);
         else if (part == 1) {
             if (ntb <= 0) return;
             if (nt_loads) hipLaunchKernelGGL((k_xt_apply<1>), dim3(ntb), dim3(XT_NT), 0, st, XT_TS_ARGS(item_n, ntb), 2);

@@ -351,34 +351,56 @@ __device__ __forceinline__ void xt_tile_role(const XItem it, const XTile *__rest
     }
 }
 
+#define XT_RPG_FUSED 4           // atom rows per 8-lane group of the neighbour role inside k_xt_apply
 // The neighbour part Xs of the product.  bid < nsb: atom rows, 8 lanes per row; bid = nsb, nsb + 1: the two driver rows (one
 // workgroup each).
+template <int RPG>
 __device__ __forceinline__ void xt_neigh_roles(int bid, int nsb, int Nsub, const xrp_t *__restrict__ rp, const int *__restrict__ ci,
                                                const double *__restrict__ val, const double *__restrict__ q, const double *__restrict__ sc,
                                                const int *__restrict__ nsrank, const XCtrl *ctrl, double *__restrict__ t, double *red)
 {
     if (bid < nsb) {
-        // 8 lanes per row; the row's entries are fetched in chunks of 32 with every load of a chunk issued before the first use:
-        // three dependent memory latencies per row (row pointers -> values / columns -> q) instead of two per 8 entries
+        // 8 lanes per row, RPG rows per lane group.  The first 32 entries of all RPG rows (every entry of an ordinary atom row) are
+        // fetched together, each level of the dependent chain -- row pointers -> values / columns -> q -- issued for all rows
+        // before the first use.  RPG = 4 next to the tile role, where the launch runs at 2 waves per SIMD and the loads in flight
+        // per lane are what hides the latency (85 k sites: 27.8 -> 27.5 us); RPG = 1 in the stand-alone kernel, where 42 VGPRs give
+        // full occupancy instead (9.4e5 sites: 38 us against 50 us with RPG = 4).
         const int g = threadIdx.x >> 3, l = threadIdx.x & 7;
-        const int row = 2 + bid * (XT_NT / 8) + g;
-        if (row >= Nsub) return;
-        const xrp_t p0 = rp[row], p1 = rp[row + 1];
-        const int sr = nsrank[row];
-        const double scale = sc[row];
-        if (ctrl->done) return;
-        double s = 0.0;
-        for (xrp_t pb = p0 + l; pb < p1; pb += 32) {
-            double v[4]; int c[4];
+        const int base = 2 + bid * (XT_NT / 8) * RPG + g;
+        xrp_t p0[RPG], p1[RPG]; int sr[RPG]; double scale[RPG];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const xrp_t p = pb + 8 * u; const bool ok = p < p1; v[u] = ok ? val[p] : 0.0; c[u] = ok ? ci[p] : 0; }
-            double x[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) x[u] = q[c[u]];
-            s += (v[0] * x[0] + v[1] * x[1]) + (v[2] * x[2] + v[3] * x[3]);
+        for (int j = 0; j < RPG; ++j) {
+            const int row = base + j * (XT_NT / 8);
+            const bool ok = row < Nsub;
+            p0[j] = ok ? rp[row] : 0; p1[j] = ok ? rp[row + 1] : 0; sr[j] = ok ? nsrank[row] : 0; scale[j] = ok ? sc[row] : 0.0;
         }
-        s += __shfl_xor(s, 4, 8); s += __shfl_xor(s, 2, 8); s += __shfl_xor(s, 1, 8);
-        if (l == 0) t[row] = sr < 0 ? scale * s : s;
+        if (ctrl->done) return;
+        double v[RPG][4]; int c[RPG][4];
+#pragma unroll
+        for (int j = 0; j < RPG; ++j)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const xrp_t p = p0[j] + l + 8 * u; const bool ok = p < p1[j]; v[j][u] = ok ? val[p] : 0.0; c[j][u] = ok ? ci[p] : 0; }
+        double x[RPG][4];
+#pragma unroll
+        for (int j = 0; j < RPG; ++j)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[j][u] = q[c[j][u]];
+#pragma unroll
+        for (int j = 0; j < RPG; ++j) {
+            const int row = base + j * (XT_NT / 8);
+            double s = (v[j][0] * x[j][0] + v[j][1] * x[j][1]) + (v[j][2] * x[j][2] + v[j][3] * x[j][3]);
+            for (xrp_t pb = p0[j] + l + 32; pb < p1[j]; pb += 32) {            // rows with more than 32 entries
+                double vv[4]; int cc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const xrp_t p = pb + 8 * u; const bool ok = p < p1[j]; vv[u] = ok ? val[p] : 0.0; cc[u] = ok ? ci[p] : 0; }
+                double xx[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xx[u] = q[cc[u]];
+                s += (vv[0] * xx[0] + vv[1] * xx[1]) + (vv[2] * xx[2] + vv[3] * xx[3]);
+            }
+            s += __shfl_xor(s, 4, 8); s += __shfl_xor(s, 2, 8); s += __shfl_xor(s, 1, 8);
+            if (l == 0 && row < Nsub) t[row] = sr[j] < 0 ? scale[j] * s : s;
+        }
         return;
     }
     if (ctrl->done) return;
@@ -417,7 +439,7 @@ __global__ __launch_bounds__(XT_NT) void k_xt_apply(int nitems, const XItem *__r
         xt_tile_role<0, NTL>(it, tiles, sub_base, tval, qS, nW, ns_pad, rowpart, colpart, true, lcol[wv], lcol[wv] + XT_C);
         return;
     }
-    xt_neigh_roles(vb < 2 ? nsb + vb : vb - 2 - ntb, nsb, Nsub, rp, ci, val, q, sc, nsrank, ctrl, t, red);
+    xt_neigh_roles<XT_RPG_FUSED>(vb < 2 ? nsb + vb : vb - 2 - ntb, nsb, Nsub, rp, ci, val, q, sc, nsrank, ctrl, t, red);
 }
 // The neighbour part alone (sharded solve: second stream, beside the exchange).  Same role bodies as in k_xt_apply, but compiled
 // without the tile role's registers and LDS: twice the resident waves for what is a chain of three dependent latencies per row
@@ -428,7 +450,7 @@ __global__ __launch_bounds__(XT_NT) void k_xt_neigh(int nsb, int Nsub, const xrp
 {
     __shared__ double red[XT_NT / 64];
     const int vb = (int)blockIdx.x;
-    xt_neigh_roles(vb < 2 ? nsb + vb : vb - 2, nsb, Nsub, rp, ci, val, q, sc, nsrank, ctrl, t, red);
+    xt_neigh_roles<1>(vb < 2 ? nsb + vb : vb - 2, nsb, Nsub, rp, ci, val, q, sc, nsrank, ctrl, t, red);
 }
 // tiles only (diagonal pass with q = 1, power pass with q = m)
 template <int OP>
@@ -994,7 +1016,8 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
 
     // ---- launch shapes ----
     const int ntb = (X.item_n + 3) / 4;
-    const int nsb = (std::max(m - 2, 1) + XT_NT / 8 - 1) / (XT_NT / 8);
+    const int nsb = (std::max(m - 2, 1) + XT_NT / 8 * XT_RPG_FUSED - 1) / (XT_NT / 8 * XT_RPG_FUSED);     // neighbour role inside k_xt_apply
+    const int nsb1 = (std::max(m - 2, 1) + XT_NT / 8 - 1) / (XT_NT / 8);                                    // k_xt_neigh
     const int n2b = xt_grid(std::max(std::max(nK, (m + 4095) / 4096), 1), 1, 1024);    // row kernel: S row blocks + its share of the p.t dot
     const int gv = xt_grid(m, XT_NT * 4, 256);
     const int np_pt = n2b;
@@ -1019,7 +1042,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
             // beside the partial row sums and the exchange; q, the stop flag and the previous readers of t are behind this event too
             HIPCHK(hipEventRecord(S.a[sl], st));
             HIPCHK(hipStreamWaitEvent(S.st, S.a[sl], 0));
-            hipLaunchKernelGGL(k_xt_neigh, dim3(nsb + 2), dim3(XT_NT), 0, S.st, nsb, m, (const xrp_t *)rp, (const int *)col, (const double *)val, (const double *)q,
+            hipLaunchKernelGGL(k_xt_neigh, dim3(nsb1 + 2), dim3(XT_NT), 0, S.st, nsb1, m, (const xrp_t *)rp, (const int *)col, (const double *)val, (const double *)q,
                                (const double *)sc, (const int *)nsrank, (const XCtrl *)ctrl, t);
             HIPCHK(hipEventRecord(S.b[sl], S.st));
             hipLaunchKernelGGL((k_xt_rows<1>), dim3(std::max(nK, 1)), dim3(XT_NT), 0, st, ns, nK, nW, ns_pad, (const int2 *)wrange, (const int *)nitem_w, (const double *)rowpart,
@@ -1171,7 +1194,7 @@ extern "C" int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_
     double *qS = vS, *sS = vS + ns_pad, *part_pt = part, *part_rr = part + 4096;
     HIPCHK(hipMemsetAsync(ctrl, 0, sizeof(XCtrl), st));
     HIPCHK(hipMemsetAsync(ytmp, 0, (size_t)(m + ns + 8) * 8, st));
-    const int ntb = (item_n + 3) / 4, nsb = (std::max(m - 2, 1) + XT_NT / 8 - 1) / (XT_NT / 8);
+    const int ntb = (item_n + 3) / 4, nsb = (std::max(m - 2, 1) + XT_NT / 8 * XT_RPG_FUSED - 1) / (XT_NT / 8 * XT_RPG_FUSED), nsb1 = (std::max(m - 2, 1) + XT_NT / 8 - 1) / (XT_NT / 8);
     const int n2b = xt_grid(std::max(std::max(nK, (m + 4095) / 4096), 1), 1, 1024), gv = xt_grid(m, XT_NT * 4, 256);
     const bool nt_loads = (size_t)sh.sub_n * XT_SUB * 8 > ((size_t)200 << 20);
     // one GPU: the whole product in one launch.  nranks > 1: the tile pass alone, as the sharded solve launches it; the neighbour part
@@ -1180,7 +1203,7 @@ extern "C" int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_
 #define XT_TS_ARGS(NI, NTB) NI, (const XItem *)items + i0, (const XTile *)g_xb.tiles, 0, (const double *)g_xb.tval, (const double *)qS, nW, ns_pad, \
                    g_xb.rowpart, colpart, (const XCtrl *)ctrl, NTB, nsb, m, (const xrp_t *)g_xb.rp, (const int *)g_xb.ci, (const double *)g_xb.val, \
                    (const double *)q, (const double *)sc, (const int *)g_xb.nsrank, t
-        if (part == 2) hipLaunchKernelGGL(k_xt_neigh, dim3(nsb + 2), dim3(XT_NT), 0, st, nsb, m, (const xrp_t *)g_xb.rp, (const int *)g_xb.ci, (const double *)g_xb.val,
+        if (part == 2) hipLaunchKernelGGL(k_xt_neigh, dim3(nsb1 + 2), dim3(XT_NT), 0, st, nsb1, m, (const xrp_t *)g_xb.rp, (const int *)g_xb.ci, (const double *)g_xb.val,
                                           (const double *)q, (const double *)sc, (const int *)g_xb.nsrank, (const XCtrl *)ctrl, t);
         else if (part == 1) {
             if (ntb <= 0) return;

@@ -138,8 +138,8 @@ enum {
     S_P_IMACRO, S_HEAT, S_HEAT_A, S_HEAT_B, S_HEAT_Y,
     S_MISC0, S_MISC1, S_MISC2, S_MISC3,
     S_XT_DPOS, S_XT_SNODE_D, S_XT_SNODE_I, S_XT_CMASK, S_XT_ISTILE, S_XT_NSUBC, S_XT_TOFF, S_XT_SOFF, S_XT_TILES, S_XT_NITEMW, S_XT_WRANGE,
-    S_XT_ITEMS, S_XT_ISUB, S_XT_TVAL, S_XT_ROWPART, S_XT_COLPART, S_XT_CNT, S_XT_Q,
-    S_XT_T_NITEMW, S_XT_T_ITEMS, S_XT_T_ISUB, S_XT_T_COLPART, S_XT_T_MISC,
+    S_XT_ITEMS, S_XT_SPLIT, S_XT_TVAL, S_XT_ROWPART, S_XT_COLPART, S_XT_CNT, S_XT_Q,
+    S_XT_T_NITEMW, S_XT_T_ITEMS, S_XT_T_SPLIT, S_XT_T_COLPART, S_XT_T_MISC,
     S_NSLOTS
 };
 

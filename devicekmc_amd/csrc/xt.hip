@@ -963,7 +963,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         hipLaunchKernelGGL(k_xt_wrange, dim3((nK + 255) / 256), dim3(256), 0, st, nK, nW, (const unsigned *)cmask, wrange);
     }
     XShare sh{};
-    rc = xt_build_items(nK, nW, X.kc, ntiles, X.nsub_total, toff, tiles, nr, me, S_XT_NITEMW, S_XT_ITEMS, S_XT_ISUB, &sh); if (rc) return rc;
+    rc = xt_build_items(nK, nW, X.kc, ntiles, X.nsub_total, toff, tiles, nr, me, S_XT_NITEMW, S_XT_ITEMS, S_XT_SPLIT, &sh); if (rc) return rc;
     X.nitems = sh.nitems; X.maxchunk = sh.maxchunk;
     const int nitems = sh.nitems;
     XItem *items = sh.items; int *nitem_w = sh.nitem_w;
@@ -1175,7 +1175,7 @@ extern "C" int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_
     const int kc = std::max(1, std::min(XT_MAXKC, ntiles / nranks / 4096));
     XShare sh{};
     int rc = xt_build_items(nK, nW, kc, ntiles, X.nsub_total, (const int *)g_xb.toff, (const XTile *)g_xb.tiles, nranks, rank,
-                            S_XT_T_NITEMW, S_XT_T_ITEMS, S_XT_T_ISUB, &sh);
+                            S_XT_T_NITEMW, S_XT_T_ITEMS, S_XT_T_SPLIT, &sh);
     if (rc) return rc;
     const int item_n = sh.item_n, i0 = sh.item_lo;
     const XItem *items = sh.items; const int *nitem_w = sh.nitem_w;
@@ -1294,7 +1294,7 @@ extern "C" int dkmc_xt_check_shares(int nranks, double *max_abs_diff, double *ma
     for (int r = 0; r < nranks; ++r) {
         XShare sh{};
         rc = xt_build_items(nK, nW, kc, ntiles, X.nsub_total, (const int *)g_xb.toff, (const XTile *)g_xb.tiles, nranks, r,
-                            S_XT_T_NITEMW, S_XT_T_ITEMS, S_XT_T_ISUB, &sh);
+                            S_XT_T_NITEMW, S_XT_T_ITEMS, S_XT_T_SPLIT, &sh);
         if (rc) return rc;
         if (items_total) *items_total = sh.nitems;
         sb_sum += sh.sub_n; it_sum += sh.item_n;

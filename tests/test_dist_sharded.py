@@ -132,6 +132,13 @@ def test_emulated_shares_cover_the_tunnelling_block():
         assert ma.value > 0 and md.value <= 1e-12 * ma.value, (nr, md.value, ma.value)
     assert L.dkmc_xt_check_shares(65, None, None, None, None, None) != 0        # more ranks than the split table holds: refused
     L.dkmc_clear_error()
+    # the 2.5 nm device has 32 tiles: with 64 ranks most shares are empty
+    small = _supersteps(1, fmt=1)
+    assert 0 < small[3]["spmv_tiles"] < 64
+    md, ma, sb, its, itot = C.c_double(), C.c_double(), C.c_longlong(), C.c_longlong(), C.c_int()
+    lib.check(L.dkmc_xt_check_shares(64, C.byref(md), C.byref(ma), C.byref(sb), C.byref(its), C.byref(itot)))
+    assert sb.value == small[3]["xt_subblocks"] and its.value == itot.value == small[3]["spmv_tiles"]
+    assert md.value <= 1e-12 * ma.value
 
 
 def test_rccl_transport_one_rank():

@@ -434,7 +434,8 @@ __global__ __launch_bounds__(XT_NT) void k_xt_apply(int nitems, const XItem *__r
     // Workgroup -> role.  0, 1: the driver rows.  NTL = 0 (the sweep fits the Infinity Cache; the launch is ramp- and latency-bound):
     // tile and neighbour workgroups ALTERNATE in groups of 8 (8 consecutive workgroups land on the 8 XCDs, so every XCD sees both
     // kinds) while both kinds last, the rest of the longer list behind -- the neighbour rows, a latency chain at 2 waves per SIMD,
-    // then run beside the tile stream from the first microsecond instead of in the tail of the launch (85 k sites: 27.2 -> 24.4 us).
+    // then run beside the tile stream from the first microsecond instead of in the tail of the launch (85 k sites: 27.2 -> 24.4 us;
+    // all neighbour workgroups first: 25.5 us).
     // NTL = 1 (the tiles stream from HBM): all tile workgroups first; there the tile waves alone saturate HBM and every slot a
     // neighbour workgroup holds early costs tile bytes in flight (9.4e5 sites: 2.67 ms against 2.86 ms interleaved).
     int tile_idx = -1, nb_idx = -1;

@@ -351,7 +351,9 @@ __device__ __forceinline__ void xt_tile_role(const XItem it, const XTile *__rest
     }
 }
 
-#define XT_RPG_FUSED 4           // atom rows per 8-lane group of the neighbour role inside k_xt_apply
+#ifndef XT_RPG_FUSED
+#define XT_RPG_FUSED 4           // atom rows per 8-lane group of the neighbour role inside k_xt_apply (85 k sites, same box: 2 -> 26.0, 4 -> 24.2, 8 -> 27.5 us)
+#endif
 // The neighbour part Xs of the product.  bid < nsb: atom rows, 8 lanes per row; bid = nsb, nsb + 1: the two driver rows (one
 // workgroup each).
 template <int RPG>

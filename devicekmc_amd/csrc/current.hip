@@ -92,7 +92,8 @@ struct TCacheState {
 // Solver state that outlives a call -- the coefficient cache and the private warm-start copy -- is kept PER GPUBuffers (keyed by
 // its site_x array), so that several devices in one process (e.g. one per crossbar cell) do not share or thrash it.  Up to 8
 // buffers, least recently used one evicted.  The engine's scratch buffers are shared: they carry nothing across calls.
-struct XBufState { const void *key = nullptr; TCacheState tc; double *warm = nullptr; int warm_n = 0; unsigned long long stamp = 0; };
+struct XBufState { const void *key = nullptr; TCacheState tc; double *warm = nullptr; int warm_n = 0; unsigned long long stamp = 0;
+                   double lat[3] = {0, 0, 0}; bool lat_ok = false; };       // lattice: constant per GPUBuffers, fetched once
 static XBufState g_states[8];
 static XBufState *g_cur = &g_states[0];
 static unsigned long long g_stamp = 0;
@@ -223,19 +224,26 @@ __global__ __launch_bounds__(256) void k_imacro(const double *__restrict__ xv, c
     if (threadIdx.x == 0) *imacro = t;
 }
 // update_m (current_solver_gpu.cu:447-457, 1044-1047): m += |min(m[2 .. Na+1])|
-__global__ __launch_bounds__(256) void k_min_m(const double *m, int lo, int hi, double *out)
+// (min is exact in any order: per-workgroup minima, then every workgroup of the shift kernel takes the minimum of those)
+#define MINM_BLOCKS 128
+__global__ __launch_bounds__(256) void k_min_m(const double *__restrict__ m, int lo, int hi, double *__restrict__ part)
 {
     __shared__ double red[256];
     double v = INFINITY;
-    for (int i = lo + threadIdx.x; i < hi; i += 256) v = fmin(v, m[i]);
+    for (int i = lo + (int)(blockIdx.x * 256 + threadIdx.x); i < hi; i += MINM_BLOCKS * 256) v = fmin(v, m[i]);
     red[threadIdx.x] = v; __syncthreads();
     for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] = fmin(red[threadIdx.x], red[threadIdx.x + s]); __syncthreads(); }
-    if (threadIdx.x == 0) *out = fabs(red[0]);
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
-__global__ void k_shift(double *m, int n, const double *shift)
+__global__ __launch_bounds__(256) void k_shift(double *m, int n, const double *__restrict__ part)
 {
+    __shared__ double red[MINM_BLOCKS];
+    if (threadIdx.x < MINM_BLOCKS) red[threadIdx.x] = part[threadIdx.x];
+    __syncthreads();
+    for (int s = MINM_BLOCKS / 2; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] = fmin(red[threadIdx.x], red[threadIdx.x + s]); __syncthreads(); }
+    const double shift = fabs(red[0]);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) m[i] += *shift;
+    if (i < n) m[i] += shift;
 }
 // Dissipated power on X's pattern: host formula (current_solver.cpp:288-357) restricted to the atoms kept
 // in the sparse system; set_ineg_sparse + reduce_rows_into_diag + SpMV + copy_pdisp fused (see SURVEY B8/B9
@@ -309,8 +317,8 @@ extern "C" int dkmc_update_power_gpu_sparse(dkmc_gpubuf *buf, int n_src, int n_g
     if (Na > buf->N_atom_) return dkmc_fail(9, "update_power: more atoms than GPUBuffers was sized for (N_atom_)", __FILE__, __LINE__);
     e.stats.N_atom = Na;
     const int Nsub = Na + 1;
-    double lat[3];
-    HIPCHK(hipMemcpy(lat, buf->lattice, 3 * sizeof(double), hipMemcpyDeviceToHost));
+    if (!g_cur->lat_ok) { HIPCHK(hipMemcpy(g_cur->lat, buf->lattice, 3 * sizeof(double), hipMemcpyDeviceToHost)); g_cur->lat_ok = true; }
+    const double *lat = g_cur->lat;
     XParams P; P.Na = Na; P.nn = nn; P.n_src = n_src; P.n_gnd = n_gnd; P.nlc = nlc; P.pbc = pbc; P.tol = tol; P.nn_dist = nn_dist;
     P.high_G = high_G; P.low_G = low_G; P.loop_G = loop_G; P.m_e = m_e; P.V0 = V0; P.laty = lat[1]; P.latz = lat[2];
 
@@ -397,14 +405,15 @@ extern "C" int dkmc_update_power_gpu_sparse(dkmc_gpubuf *buf, int n_src, int n_g
     }
     // ---- 6. I_macro (:1015-1029) ----
     hipLaunchKernelGGL(k_scale, dim3((Na + 2 + 255) / 256), dim3(256), 0, st, m, Na + 2, G0);
-    double *d_im = (double *)scratch(S_P_IMACRO, 2 * sizeof(double));
+    double *d_im = (double *)scratch(S_P_IMACRO, (2 + MINM_BLOCKS) * sizeof(double));     // I_macro, spare, per-workgroup minima of m
     if (!d_im) return e.err_code;
     hipLaunchKernelGGL(k_imacro, dim3(1), dim3(256), 0, st, data, rp, col, m, d_im);
     HIPCHK(hipMemcpyAsync(h_imacro, d_im, sizeof(double), hipMemcpyDeviceToHost, st));
     // ---- 7. dissipated power (:1041-1136) ----
     if (heat_local || heat_global) {
-        hipLaunchKernelGGL(k_min_m, dim3(1), dim3(256), 0, st, m, 2, Na + 2, d_im + 1);
-        hipLaunchKernelGGL(k_shift, dim3((Na + 2 + 255) / 256), dim3(256), 0, st, m, Na + 2, d_im + 1);
+        double *minpart = d_im + 2;
+        hipLaunchKernelGGL(k_min_m, dim3(MINM_BLOCKS), dim3(256), 0, st, (const double *)m, 2, Na + 2, minpart);
+        hipLaunchKernelGGL(k_shift, dim3((Na + 2 + 255) / 256), dim3(256), 0, st, m, Na + 2, (const double *)minpart);
         if (e.x_format != 0) { rc = xt_power(buf, P, aflag, atom_site, m, Vd, alpha_disp); if (rc) return rc; }
         else {
             int *rows = (int *)scratch(S_MISC0, (size_t)Nsub * 4);

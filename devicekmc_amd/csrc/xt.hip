@@ -139,7 +139,7 @@ __global__ void k_xt_wrange(int nK, int nW, const unsigned *__restrict__ cmask, 
 // (measured at a 1/8 share of the 9.4e5-site stack: 426 us per launch untapered against 357 us at the full-size rate).
 #define XT_MAXRANKS 64
 #define XT_TAPER 2048
-struct XSplit { int n; int tb[XT_MAXRANKS + 1]; int item_lo[XT_MAXRANKS + 1]; int max_items_per_strip;
+struct XSplit { int n; int tb[XT_MAXRANKS + 1]; int item_lo[XT_MAXRANKS + 1]; int max_items_per_strip; int nitems;
                 int soff[XT_MAXRANKS + 1], w_first[XT_MAXRANKS + 1], w_last[XT_MAXRANKS + 1]; };   // per share boundary r: sub-block offset and window of tile tb[r]; window of tile tb[r] - 1
 __global__ void k_xt_split(int ntiles, long long nsub_total, const XTile *__restrict__ tiles, int n, XSplit *sp)
 {
@@ -182,9 +182,12 @@ __global__ void k_xt_items(int nK, int nW, int kc, int ntiles, const int *__rest
     if (!MODE) { nitem_w[w] = c; atomicMax(&sp->max_items_per_strip, c); }
 }
 // first item of every rank's share (items are in tile order and never cross a share boundary) + what the host needs of the boundary tiles
-__global__ void k_xt_rank_items(int nitems, int ntiles, long long nsub_total, const XItem *__restrict__ items, const XTile *__restrict__ tiles, XSplit *sp)
+__global__ void k_xt_rank_items(const int *__restrict__ nitems_dev, int ntiles, long long nsub_total, const XItem *__restrict__ items,
+                                const XTile *__restrict__ tiles, XSplit *sp)
 {
     const int r = threadIdx.x;
+    const int nitems = *nitems_dev;
+    if (r == 0) sp->nitems = nitems;
     if (r > sp->n) return;
     const int tb = sp->tb[r];
     int lo = 0, hi = nitems;
@@ -739,6 +742,7 @@ __global__ __launch_bounds__(XT_NT) void k_xt_step(int m, int it, const double *
         if (!(rr_new > tol2)) { if (ctrl->sharded) ctrl->done_local = 1; else ctrl->done = 1; }
     }
 }
+__global__ void k_xt_set_sharded(XCtrl *ctrl) { ctrl->sharded = 1; }
 __global__ void k_xt_vec_mul(int m, double *__restrict__ y, const double *__restrict__ s)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -854,15 +858,13 @@ static int xt_build_items(int nK, int nW, int kc, int ntiles, long long nsub_tot
     hipLaunchKernelGGL(k_xt_split, dim3(1), dim3(XT_MAXRANKS + 1), 0, st, ntiles, nsub_total, tiles, nranks, sp);
     hipLaunchKernelGGL((k_xt_items<0>), dim3((nW + 255) / 256), dim3(256), 0, st, nK, nW, kc, ntiles, toff, (const int *)nullptr, tiles, sp, nitem_w, (XItem *)nullptr);
     int rc = dkmc_exclusive_scan_i32(nitem_w, ioff, nW, ioff + nW); if (rc) return rc;
-    int nitems = 0;
-    HIPCHK(hipMemcpyAsync(&nitems, ioff + nW, sizeof(int), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    XItem *items = (XItem *)scratch(slot_items, (size_t)(nitems + 1) * sizeof(XItem));
+    XItem *items = (XItem *)scratch(slot_items, (size_t)(ntiles + 1) * sizeof(XItem));      // an item holds at least one tile: no need to wait for the count
     if (!items) return e.err_code;
     hipLaunchKernelGGL((k_xt_items<1>), dim3((nW + 255) / 256), dim3(256), 0, st, nK, nW, kc, ntiles, toff, (const int *)ioff, tiles, sp, nitem_w, items);
-    hipLaunchKernelGGL(k_xt_rank_items, dim3(1), dim3(XT_MAXRANKS + 1), 0, st, nitems, ntiles, nsub_total, (const XItem *)items, tiles, sp);
+    hipLaunchKernelGGL(k_xt_rank_items, dim3(1), dim3(XT_MAXRANKS + 1), 0, st, (const int *)(ioff + nW), ntiles, nsub_total, (const XItem *)items, tiles, sp);
     HIPCHK(hipMemcpyAsync(&h, sp, sizeof(XSplit), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    const int nitems = h.nitems;
     out->items = items; out->nitems = nitems; out->maxchunk = std::max(1, h.max_items_per_strip);
     out->item_lo = h.item_lo[me]; out->item_n = h.item_lo[me + 1] - h.item_lo[me];
     out->tile_lo = h.tb[me]; out->tile_n = h.tb[me + 1] - h.tb[me];
@@ -1080,7 +1082,8 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
     };
 
     // ---- r = A y - b, p = -r ----
-    { XCtrl c0{}; c0.sharded = (sharded && ns > 0) ? 1 : 0; HIPCHK(hipMemcpyAsync(ctrl, &c0, sizeof(XCtrl), hipMemcpyHostToDevice, st)); HIPCHK(hipStreamSynchronize(st)); }
+    HIPCHK(hipMemsetAsync(ctrl, 0, sizeof(XCtrl), st));
+    if (sharded && ns > 0) hipLaunchKernelGGL(k_xt_set_sharded, dim3(1), dim3(1), 0, st, ctrl);
     HIPCHK(hipMemsetAsync(p, 0, (size_t)m * 8, st));
     rc = matvec(nullptr, nullptr, nullptr, nullptr, nullptr); if (rc) return rc;
     hipLaunchKernelGGL(k_xt_resid_init, dim3(gv), dim3(XT_NT), 0, st, m, (const double *)t, (const double *)rhs, r, p, (const double *)sc, q, (const int *)nsrank, qS, part_rr);

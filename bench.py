@@ -266,7 +266,8 @@ def strong_scaling_model(sim, ms_per_step, reps=10):
                    "share_GBps": round(8192.0 * sb.value / a.value / 1e3, 1)}
     # one GPU: apply (tiles + neighbour part in one launch) + row sums (finish fused in) + vector step.
     # N > 1: tile pass, then [partial row sums + all-reduce] beside [neighbour part on the second stream], then finish + vector step
-    t1 = rows[1]["apply_us"] + rows[1]["partial_row_sums_us"] + rows[1]["vector_step_us"]
+    t1 = rows[1]["apply_us"] + rows[1]["neighbour_part_us"] + rows[1]["partial_row_sums_us"] + rows[1]["vector_step_us"]
+    # (neighbour_part_us of N = 1 is non-zero when the one-GPU solve runs it as its own kernel behind the tile pass: multi-GB sweeps)
     for n in rows:
         if n == 1:
             tk = t1

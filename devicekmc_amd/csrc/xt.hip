@@ -1043,8 +1043,9 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
     if (sharded) { xbuf = (double *)scratch(S_CG_XCHG, (size_t)(ns + 2) * 8); if (!xbuf) return e.err_code; }
 
     const bool split = sharded && ns > 0;                 // tile pass + exchange on the engine's stream, neighbour part on the side stream
+    const bool seq_neigh = !split && (size_t)X.sub_n * XT_SUB * 8 > ((size_t)2 << 30);
     if (split) { rc = xt_side_init(); if (rc) return rc; }
-    e.stats.xt_split_launch = split ? 1 : 0;
+    e.stats.xt_split_launch = (split || seq_neigh) ? 1 : 0;  // the timed apply launch carries the tiles only
     auto matvec = [&](hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t ec) -> int {
 #define XT_APPLY_ARGS(NI, NTB, NSB) NI, (const XItem *)items + X.item_lo, (const XTile *)tiles, (int)X.sub_base, (const double *)tval, (const double *)qS, nW, ns_pad, \
                       rowpart, colpart, (const XCtrl *)ctrl, NTB, NSB, m, (const xrp_t *)rp, (const int *)col, (const double *)val, (const double *)q, \
@@ -1072,7 +1073,15 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
                                   (const double *)p, t, part_pt, ctrl, m, (const int *)nsrank, (const double *)r);
             return 0;
         }
-        if (nt_loads) hipExtLaunchKernelGGL((k_xt_apply<1>), dim3(ntb + nsb + 2), dim3(XT_NT), 0, st, e0, e1, 0, XT_APPLY_ARGS(X.item_n, ntb, nsb), 0);
+        if (seq_neigh) {
+            // multi-GB sweeps: the neighbour rows leave the tile launch altogether (there they are a 65-190 us tail at 2 waves per SIMD);
+            // tile pass, then the neighbour part as its own full-occupancy kernel (38-42 us at 9.4e5 sites): 13.82 / 13.49 -> 13.39 s per
+            // step at 9.4e5 sites; even at 2.35e5 sites (1 GB), a loss at 1.5e5 (0.4 GB), where the extra launch costs more than the tail
+            if (ntb > 0) hipExtLaunchKernelGGL((k_xt_apply<1>), dim3(ntb), dim3(XT_NT), 0, st, e0, e1, 0, XT_APPLY_ARGS(X.item_n, ntb, 0), 2);
+            else if (e0) { HIPCHK(hipEventRecord(e0, st)); HIPCHK(hipEventRecord(e1, st)); }
+            hipLaunchKernelGGL(k_xt_neigh, dim3(nsb1 + 2), dim3(XT_NT), 0, st, nsb1, m, (const xrp_t *)rp, (const int *)col, (const double *)val, (const double *)q,
+                               (const double *)sc, (const int *)nsrank, (const XCtrl *)ctrl, t);
+        } else if (nt_loads) hipExtLaunchKernelGGL((k_xt_apply<1>), dim3(ntb + nsb + 2), dim3(XT_NT), 0, st, e0, e1, 0, XT_APPLY_ARGS(X.item_n, ntb, nsb), 0);
         else hipExtLaunchKernelGGL((k_xt_apply<0>), dim3(ntb + nsb + 2), dim3(XT_NT), 0, st, e0, e1, 0, XT_APPLY_ARGS(X.item_n, ntb, nsb), 0);
 #undef XT_APPLY_ARGS
         hipExtLaunchKernelGGL((k_xt_rows<0>), dim3(n2b), dim3(XT_NT), 0, st, e2, e3, 0, ns, nK, nW, ns_pad, (const int2 *)wrange, (const int *)nitem_w,
@@ -1233,7 +1242,8 @@ extern "C" int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_
         }
 #undef XT_TS_ARGS
     };
-    const int apply_part = nranks > 1 ? 1 : 0;
+    const bool seq_neigh = (size_t)sh.sub_n * XT_SUB * 8 > ((size_t)2 << 30);     // one GPU, multi-GB sweep: the solve runs tile pass + k_xt_neigh too
+    const int apply_part = (nranks > 1 || seq_neigh) ? 1 : 0;
     auto side = [&](int which, int it) {
         if (which == 0)
             hipLaunchKernelGGL((k_xt_rows<1>), dim3(std::max(nK, 1)), dim3(XT_NT), 0, st, ns, nK, nW, ns_pad, (const int2 *)g_xb.wrange, (const int *)nitem_w, (const double *)g_xb.rowpart,
@@ -1254,7 +1264,7 @@ extern "C" int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_
     for (int w = 0; w < 5; ++w) {
         HIPCHK(hipMemsetAsync(ctrl, 0, sizeof(XCtrl), st));
         HIPCHK(hipEventRecord(ev[2 * w], st));
-        if (w < 4 || nranks > 1)
+        if (w < 4 || apply_part == 1)
             for (int k = 0; k < reps; ++k) { if (w == 0) apply(apply_part); else if (w == 4) apply(2); else side(w - 1, k); }
         HIPCHK(hipEventRecord(ev[2 * w + 1], st));
     }
@@ -1263,7 +1273,7 @@ extern "C" int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, ev[2 * w], ev[2 * w + 1]));
         const double us = (double)ms * 1e3 / reps;
-        if (w == 0) { if (apply_us) *apply_us = us; } else if (side_us) side_us[w - 1] = (w == 4 && nranks == 1) ? 0.0 : us;
+        if (w == 0) { if (apply_us) *apply_us = us; } else if (side_us) side_us[w - 1] = (w == 4 && apply_part == 0) ? 0.0 : us;
     }
     for (auto &x : ev) (void)hipEventDestroy(x);
     KCHK();

@@ -251,7 +251,7 @@ int dkmc_update_temperature_local(dkmc_gpubuf *buf, double step_time, double del
 
 /* measurement aid (bench.py's strong-scaling model): on the tiled X left resident by the last single-GPU update_power, the time per CG
  * iteration of what ONE rank of an nranks-way sharded solve runs -- apply_us: the apply kernel over that rank's share of the tiles
- * (work items sized as an nranks run sizes them) + the neighbour part; side_us[4]: partial row sums, finish, vector step, and -- nranks > 1, where apply_us is the tile pass alone -- the
+ * (work items sized as an nranks run sizes them) + the neighbour part; side_us[4]: partial row sums, finish, vector step, and -- nranks > 1 or a multi-GB sweep, where apply_us is the tile pass alone -- the
  * neighbour part that a sharded solve runs on a second stream beside the exchange (each timed on its own).  The
  * all-reduce between them cannot be measured on one GPU.  Scratch vectors are overwritten; results of the last solve already
  * delivered (potentials, I_macro, power) are not. */

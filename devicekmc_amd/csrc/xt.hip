@@ -491,16 +491,19 @@ __global__ __launch_bounds__(XT_NT) void k_xt_tiles_only(int nitems, const XItem
 // only (this rank's share in the sharded solve; the diagonal and power passes).
 // [w_lo, w_hi): windows that can hold partial sums in this launch -- all of them on one GPU; in a sharded solve the windows of this
 // rank's tiles (every other cell of the partial arrays is zero on this rank: not reading it saves 7/8 of this kernel at 8 ranks)
-__device__ __forceinline__ double xt_row_block_sum(int k, int nW, int ns_pad, const int2 *__restrict__ wrange, const int *__restrict__ nitem_w,
+__device__ __forceinline__ int xt_row_block_runs(int k, const int *__restrict__ nitem_w, int w_lo, int w_hi)
+{
+    const int wk = k / (XT_C / XT_R);
+    return (wk >= w_lo && wk < w_hi) ? nitem_w[wk] : 0;
+}
+// wr = wrange[k], nc = xt_row_block_runs(k, ...): fetched by the caller, with whatever else starts its chain
+__device__ __forceinline__ double xt_row_block_sum(int k, int nW, int ns_pad, int2 wr, int nc,
                                                    const double *__restrict__ rowpart, const double *__restrict__ colpart, double (*sl_sum)[XT_R],
                                                    int w_lo, int w_hi)
 {
     const int r = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int s = XT_R * k + r;
-    int2 wr = wrange[k];
     wr.x = max(wr.x, w_lo); wr.y = min(wr.y, w_hi);
-    const int wk = k / (XT_C / XT_R);
-    const int nc = (wk >= w_lo && wk < w_hi) ? nitem_w[wk] : 0;
     if (wr.x >= wr.y && nc == 0) return 0.0;                          // nothing of this row block on this rank (uniform over the workgroup)
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     const double *rpp = rowpart + (size_t)k * nW * XT_R + r;
@@ -578,13 +581,17 @@ __global__ __launch_bounds__(XT_NT) void k_xt_rows(int ns, int nK, int nW, int n
         const int s = XT_R * (int)blockIdx.x + (int)threadIdx.x;
         if (MODE == 0 && (int)blockIdx.x < nK && threadIdx.x < XT_R && s < ns) { row0 = srow[s]; s0 = sS[s]; t0 = t[row0]; p0 = pvec[row0]; r0 = rvec[row0]; }
     }
+    // ... and the extent of the first row block's partial lists: one dependent level less behind the flag
+    int2 wr0 = make_int2(0, 0); int nc0 = 0;
+    if ((int)blockIdx.x < nK) { wr0 = wrange[blockIdx.x]; nc0 = xt_row_block_runs(blockIdx.x, nitem_w, w_lo, w_hi); }
     if (ctrl) {
         if (threadIdx.x == 0) sdone = ctrl->done;
         __syncthreads();
         if (sdone) return;
     }
     for (int k = blockIdx.x; k < nK; k += gridDim.x) {
-        const double sum = xt_row_block_sum(k, nW, ns_pad, wrange, nitem_w, rowpart, colpart, sl_sum, w_lo, w_hi);
+        const bool own = k == (int)blockIdx.x;
+        const double sum = xt_row_block_sum(k, nW, ns_pad, own ? wr0 : wrange[k], own ? nc0 : xt_row_block_runs(k, nitem_w, w_lo, w_hi), rowpart, colpart, sl_sum, w_lo, w_hi);
         const int s = XT_R * k + (int)threadIdx.x;
         if (threadIdx.x < XT_R && s < ns) {
             if (MODE == 1) xout[s] = sum;

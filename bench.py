@@ -214,7 +214,7 @@ def rooflines(sim, local_share=1.0):
     if pr["pair_n"] > 0 and st["n_charged"] > 0:
         # pair sum: 64 fp64 flops per evaluated (site, charged site) pair; pairs beyond the screening cut-off
         # (erfc < 3.8e-20) pay the distance only, 12 flops
-        pairs = int(sim.s.N) * int(st["n_charged"])
+        pairs = int(sim.s.N) * int(st["n_charged"]) // max(int(st["comm_ranks"]), 1)      # a sharded run: this rank's slab of sites
         ev = int(st["pair_evaluated"]) if st["pair_evaluated"] > 0 else pairs
         fl = 64.0 * ev + 12.0 * (pairs - ev)
         ms = pr["pair_ms"] / pr["pair_n"]
@@ -572,7 +572,7 @@ def main():
                              "subblocks_rank0": int(st["xt_local_subblocks"]), "rank0_share": round(share, 4),
                              "exchange_us": round(sim.prof["comm_ms"] / max(sim.prof["comm_n"], 1) * 1e3, 2),
                              "exchanged_doubles": int(st["comm_count_per_rank"]),
-                             "replicated_phases": "charge, K-CG, pair sum, event loop, neighbour part of X (all < 5 % of a step at this size)"},
+                             "replicated_phases": "charge, K-CG, event loop, neighbour part of X (all < 5 % of a step at this size); pair sum: site slabs + all-gather"},
                 "replicas": replicas, "single_gpu_reference": None,
             }
             if single is not None:

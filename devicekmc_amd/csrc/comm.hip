@@ -15,6 +15,7 @@
 //     Values and summation orders are those of the single-GPU kernels: bit-identical to the single-GPU run.  (This variant
 //     relies on every rank computing identical dot products from identical data; it carries no flag in the exchange.)
 // Everything downstream (dot products, vector updates) is computed identically everywhere: no dot-product all-reduce is needed.
+// The pair sum (potential.hip) uses the all-gather too: a slab of sites per rank, the potentials gathered in place.
 //
 // Two transports behind the same call:
 //   * RCCL over xGMI (production): ncclAllGather on the engine's stream.  librccl is opened at run time (dlopen) so that

@@ -265,12 +265,12 @@ __global__ __launch_bounds__(PW_NT) void k_pairwise(int N, const double *__restr
                                                     const double *__restrict__ z, const double *__restrict__ lattice, int pbc,
                                                     const double *__restrict__ sigma_p, const double *__restrict__ k_p,
                                                     const ChargedSite *__restrict__ list, const int *__restrict__ ncharged,
-                                                    double *__restrict__ out, unsigned long long *__restrict__ nevaluated)
+                                                    double *__restrict__ out, unsigned long long *__restrict__ nevaluated, int i0)
 {
     __shared__ ChargedSite tile[PW_NT];
     __shared__ double partial[PW_NT / 64][PW_SITES];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int i = blockIdx.x * PW_SITES + lane;
+    const int i = i0 + blockIdx.x * PW_SITES + lane;               // sites [i0, N): all of them on one GPU, this rank's slab in a sharded run
     const int nc = *ncharged;
     const double sigma = *sigma_p, kk = *k_p, laty = lattice[1], latz = lattice[2];
     const double rc = PW_CUT * sigma * sqrt(2.0) * 1e10;           // [A]
@@ -320,8 +320,24 @@ extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, 
     }
     unsigned long long *d_ne = (unsigned long long *)(cnt + 4);
     HIPCHK(hipMemsetAsync(d_ne, 0, 8, st));
-    hipLaunchKernelGGL(k_pairwise, dim3((N + PW_SITES - 1) / PW_SITES), dim3(PW_NT), 0, st, N, x, y, z, lattice, pbc, sigma, k, list, cnt, out, d_ne);
-    KCHK();
+    if (comm_attached() && comm_nranks() > 1) {
+        // SURVEY 8(e), "pairwise Poisson": the rows are independent -- every rank holds the (replicated) charged list and sums the
+        // sites of its slab; one in-place all-gather hands every rank every potential.  Same arithmetic per site as on one GPU:
+        // bit-identical.
+        const int nr = comm_nranks(), me = comm_rank();
+        const int chunk = ((N + nr - 1) / nr + PW_SITES - 1) / PW_SITES * PW_SITES;
+        double *xbuf = (double *)scratch(S_CG_XCHG, (size_t)nr * chunk * 8);
+        if (!xbuf) return e.err_code;
+        const int lo = std::min(N, me * chunk), hi = std::min(N, lo + chunk);
+        if (hi > lo)
+            hipLaunchKernelGGL(k_pairwise, dim3((hi - lo + PW_SITES - 1) / PW_SITES), dim3(PW_NT), 0, st, hi, x, y, z, lattice, pbc, sigma, k, list, cnt, xbuf, d_ne, lo);
+        KCHK();
+        rc = comm_allgather_f64(xbuf, (size_t)chunk); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(out, xbuf, (size_t)N * 8, hipMemcpyDeviceToDevice, st));
+    } else {
+        hipLaunchKernelGGL(k_pairwise, dim3((N + PW_SITES - 1) / PW_SITES), dim3(PW_NT), 0, st, N, x, y, z, lattice, pbc, sigma, k, list, cnt, out, d_ne, 0);
+        KCHK();
+    }
     e.stats.pair_ms = 0.0;
     if (e.profiling) {
         HIPCHK(hipEventRecord(evp[1], st));

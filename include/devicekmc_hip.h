@@ -267,8 +267,9 @@ int dkmc_xt_check_shares(int nranks, double *max_abs_diff, double *max_abs, long
  * shares (tiled X, the default) and completes the S-rows' sums with ONE in-place all-reduce of |S| + 1 doubles per matrix-vector
  * product; all ranks receive the same bits -- including rank 0's stop decision, from which every rank takes its control flow --
  * and the result equals the single-GPU one to rounding.  With dkmc_set_x_format(0) (CSR X) the long rows are dealt to the ranks
- * and an all-gather of row sums keeps the result bit-identical to the single-GPU one.  Every other phase is computed redundantly
- * and identically on every rank, so all ranks hold the same state after every call.  Every rank must make the same sequence of
+ * and an all-gather of row sums keeps the result bit-identical to the single-GPU one.  poisson_gridless_gpu sums a slab of sites
+ * per rank and all-gathers the potentials (bit-identical).  Every other phase is computed redundantly and identically on every
+ * rank, so all ranks hold the same state after every call.  Every rank must make the same sequence of
  * calls with the same inputs.
  * Transports: RCCL over xGMI (unique id from rank 0, distributed by the caller), or a host callback that all-gathers a
  * pinned host buffer in place (rehearsal on machines where the ranks share a GPU, which RCCL refuses). */

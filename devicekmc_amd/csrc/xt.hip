@@ -16,8 +16,12 @@
 // (t_j += x_ij q_i): 4 B of HBM traffic per entry of X.  Work items are runs of up to KC tiles of one 256-column strip:
 // column sums stay in registers across the run, row sums (32 per tile) go to a grid-indexed array; a small second kernel
 // adds, per S-row, its row partials, its column partials and the sparse part.
-// Multi-GPU (comm.hip): work items are dealt to the ranks in contiguous, byte-balanced shares; a rank generates, stores
-// and streams only its tiles; one all-reduce of |S| doubles per matrix-vector product completes the rows.
+// Where the neighbour part runs depends on the size of the sweep: inside the tile launch, tile and neighbour workgroups alternating
+// (the sweep fits the Infinity Cache: the launch is ramp-bound and the neighbour rows hide beside the stream); inside it, behind
+// the tile workgroups (up to ~2 GB); as its own full-occupancy kernel behind the tile pass (multi-GB sweeps).  See k_xt_apply.
+// Multi-GPU (comm.hip): work items are dealt to the ranks in contiguous, byte-balanced shares (runs shrink towards the end of a
+// share); a rank generates, stores and streams only its tiles; one all-reduce of |S| + 1 doubles per matrix-vector product
+// completes the rows, with the neighbour part on a second stream beside it; results are re-published from rank 0.
 #include "xshared.h"
 #include <hip/hip_ext.h>
 #include <vector>

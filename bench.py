@@ -17,7 +17,8 @@ Contract: python bench.py --gpus N --steps K --warmup W ; prints ONE JSON line o
 
 N = 1: `value` = steps/s of the default workload; the same line carries `scale_points` -- tile:5 and tile:10 measured in the same
 run (a few steps each: a tile:10 step takes seconds) with their own ms/step split, CG iteration counts, HIP-event roofline of the
-dominant kernel and a CPU baseline (the oracle's CG iteration timed at that size x the GPU run's iteration count).
+dominant kernel and a CPU baseline (the oracle's CG iteration timed at that size x the GPU run's iteration count); the tile:10 point
+also carries `strong_scaling_model`: the kernels one rank of a 2/4/8-way sharded solve runs, timed on this GPU on that rank's share.
 
 N > 1 (launched with torch.distributed.run; the reference has no multi-GPU path): STRONG scaling of ONE simulation of the ~1e6-site
 stack (tile:10): every rank advances the same simulation in lockstep, the tunnelling block of X -- > 95 % of a step -- is generated,

@@ -154,7 +154,11 @@ static int tc_reset(const XParams &P, int N, const int *aflag, const double *acb
     if (nM <= 0) { g_tc.valid = 0; return 0; }
     const int n_vacancies = n_vac - nM > 64 ? n_vac - nM : 64;          // n_vac carries |S| = vacancies + inner-contact metals
     size_t cap = (size_t)4 * n_vacancies + 256;
-    const size_t budget = (size_t)8 << 30;                              // at most 8 GiB of cached coefficients
+    // budget: a third of the device memory that is free now, between 8 and 128 GiB (1.9e6 sites need 25 GB for one row per vacancy,
+    // 3.8e6 sites 106 GB; the tiles of a rank's share come on top)
+    size_t mem_free = 0, mem_total = 0;
+    if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 0;
+    const size_t budget = std::min((size_t)128 << 30, std::max((size_t)8 << 30, mem_free / 3));
     if (cap * nM * 8 > budget) cap = budget / ((size_t)nM * 8);
     if (cap < (size_t)n_vacancies + 16) { g_tc.valid = 0; return 0; }         // does not fit: run uncached
     g_tc.N = N; g_tc.Na = Na; g_tc.nM = nM; g_tc.cap = (int)cap;

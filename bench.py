@@ -12,6 +12,7 @@ Workloads (config.workload):
   2.5nm   9 399 sites (configs[0], plumbing)
   tile:K  the 2.5 nm cell tiled K x K laterally: tile:3 = 84 591, tile:5 = 234 975, tile:10 = 939 900 sites
           (configs[2], the "~1e6" stack)                                                          [default at N > 1]
+          (tile:14 = 1 842 204 sites, 1.4e10 matrix entries, is the largest run so far on one GPU: 66 s per cold superstep)
 
 Contract: python bench.py --gpus N --steps K --warmup W ; prints ONE JSON line on rank 0.
 

@@ -68,12 +68,16 @@ def make_workload(name):
 class Sim:
     """One simulation resident on the GPU: the reference's host objects (Device / KMCProcess / GPUBuffers mirror) + one superstep."""
 
-    def __init__(self, name, devname, kmc_seed=None, x_format=1, warm_start=0):
+    def __init__(self, name, devname, kmc_seed=None, x_format=1, warm_start=0, log_revision=False, cg_tol=None):
         from devicekmc_amd import host, lib
         self.host, self.L = host, lib.load()
         self.name = name
         t0 = time.perf_counter()
         self.s, self.p = make_workload(name)
+        if log_revision:
+            self.p = self.p.log_revision()           # cg_tol 1e-12 + CB edge on atoms: the settings that reproduce the reference's own log
+        if cg_tol is not None:
+            self.p.cg_tol = cg_tol
         if kmc_seed is not None:
             self.p.rnd_seed_kmc = kmc_seed
         self.dev = host.Device(self.s, self.p, gpu_neighbors=devname)   # HIP cell-list neighbour index (setup, outside the timed region)
@@ -206,13 +210,16 @@ def rooflines(sim, local_share=1.0):
         # (warm-started K solves of 1-4 iterations are a host poll, not a kernel measurement: no entry below 32 iterations per solve)
         # one Jacobi-CG iteration on K (SpMV + update + direction): 12 nnz + 4 (m + 1) + 96 m bytes
         m, nnz = sim.s.N - 2 * sim.p.num_atoms_first_layer, int(sim.gb.c.Device_nnz)
-        b = 12.0 * nnz + 4.0 * (m + 1) + 96.0 * m
+        # bytes the three kernels move: 4 B per stored entry (column | class bit, no value array) + row pointers + 15 vector touches of 8 B
+        b = 4.0 * nnz + 4.0 * (m + 1) + 120.0 * m
+        b_csr = 12.0 * nnz + 4.0 * (m + 1) + 96.0 * m
         us = pr["kcg_ms"] / pr["kcg_iters"] * 1e3
         out["roofline_K_cg"] = {"bound": "hbm", "kernel": "one CG iteration on K (k_kc_apply + k_kc_update + k_kc_direction)", "achieved": round(b / us / 1e3, 1),
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None,
                                 "us_per_iteration": round(us, 2), "iterations_timed": pr["kcg_iters"], "algorithmic_bytes_per_iteration": b,
-                                "note": "bytes of the CSR formulation (SURVEY 8d: 12 nnz + 4 (m + 1) + 96 m); the kernel itself moves 4 B per non-zero (class bits, no value array)",
-                                "actual_bytes_per_iteration": 4.0 * nnz + 4.0 * (m + 1) + 120.0 * m}
+                                "note": "achieved / frac count the bytes this formulation moves (4 nnz + 4 (m + 1) + 120 m); csr_equivalent_* prices the "
+                                        "same iteration at the bytes of the reference's CSR formulation (SURVEY 8d: 12 nnz + 4 (m + 1) + 96 m)",
+                                "csr_equivalent_bytes_per_iteration": b_csr, "csr_equivalent_GBps": round(b_csr / us / 1e3, 1)}
     if pr["pair_n"] > 0 and st["n_charged"] > 0:
         # pair sum: 64 fp64 flops per evaluated (site, charged site) pair; pairs beyond the screening cut-off
         # (erfc < 3.8e-20) pay the distance only, 12 flops
@@ -350,7 +357,7 @@ def cpp_host_crosscheck(sim, steps, warmup):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def pmc_traffic(workload, kernel_prefix, x_format):
+def pmc_traffic(workload, kernel_prefix, x_format, cg_tol=None):
     """HBM bytes per launch of the dominant kernel from the PMC counters, measured in this run: two rocprofv3 child runs of this
     script on the same workload (one step), `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes with the kernel trace only
     (MI355X_MICROARCH.md, HBM / rocprofv3 sections); median over the kernel's working launches (the no-op launches behind the
@@ -370,7 +377,9 @@ def pmc_traffic(workload, kernel_prefix, x_format):
         d = tempfile.mkdtemp(prefix="dkmc_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
                sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
-               "--scale-points", "none", "--no-alt", "--no-pmc", "--x-format", str(x_format)]
+               "--scale-points", "none", "--no-alt", "--no-pmc", "--no-cpp-host", "--no-log-tolerance", "--x-format", str(x_format)]
+        if cg_tol is not None:      # bytes per launch do not depend on how many iterations the solve takes: a loose tolerance shortens the (serialised) counter run
+            cmd += ["--cg-tol", repr(cg_tol)]
         try:
             subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True,
                            cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
@@ -382,18 +391,47 @@ def pmc_traffic(workload, kernel_prefix, x_format):
                             vals.append(float(r["Counter_Value"]))
             if not vals:
                 return None, {"error": "no %s samples of %s" % (counter, kernel_prefix)}
+            # working launches only, in both passes: the no-op launches behind the last iteration of a batch move next to nothing
             top = max(vals)
-            work = [v for v in vals if v > 0.5 * top] if counter == "FETCH_SIZE" else vals
+            work = [v for v in vals if v > 0.5 * top]
             med[counter] = (statistics.median(work), len(work))
         except Exception as exc:
             return None, {"error": repr(exc)[:200]}
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    if med["WRITE_SIZE"][1] != med["FETCH_SIZE"][1]:      # same launches in both passes: take the working ones of the write pass by rank
-        pass
     b = (2.0 * med["FETCH_SIZE"][0] + med["WRITE_SIZE"][0]) * 1024.0
-    return b, {"FETCH_SIZE_KB_median": med["FETCH_SIZE"][0], "WRITE_SIZE_KB_median": med["WRITE_SIZE"][0], "launches": med["FETCH_SIZE"][1],
+    return b, {"FETCH_SIZE_KB_median": med["FETCH_SIZE"][0], "WRITE_SIZE_KB_median": med["WRITE_SIZE"][0], "launches": med["FETCH_SIZE"][1], "launches_write_pass": med["WRITE_SIZE"][1],
                "formula": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024, separate --pmc passes"}
+
+
+def log_tolerance_block(devname, x_format, steps, warmup):
+    """The 85 071-site workload under KMCParameters.log_revision() (CG tolerance 1e-12, "used to be 1e-12", iterative_solvers_gpu.cu:322;
+    CB edge solved on atoms): the configuration in which KMC time AND current of all 19 supersteps of the reference's own CUDA-path log
+    are reproduced to the printed digits (tests/test_gpu_parity.py::test_reference_log_7p5_currents).  Same timing rule as `value`; the
+    steps run here are checked against the log on the way (fixture tests/golden/reference_logs.json; no oracle involved)."""
+    sim = Sim("7.5nm", devname, x_format=x_format, log_revision=True)
+    sim.p.solve_heating_global = False          # the log was written with heating off (its parameters.txt); the timed phases are the log's
+    elapsed, n = sim.run(steps, warmup)
+    res = summary(sim, elapsed, n)
+    blk = {"workload": "7.5nm", "cg_tol": sim.p.cg_tol, "cb_edge_domain": sim.p.cb_edge_domain, "steps": n, "warmup": warmup,
+           "value": round(n / elapsed, 4), "unit": "KMC steps/s", "ms_per_step": res["ms_per_step"], "split_ms": res["split_ms"],
+           "per_step": {k: res["per_step"][k] for k in ("events", "cg_iters_K", "cg_iters_X", "X_nnz")}}
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "reference_logs.json")) as f:
+            gold = json.load(f)["timing_7.5nm/output_noguess.txt"]["steps"]
+        # sim.trace holds the timed steps = logged steps warmup .. warmup + n - 1 (the warm-up steps were steps 0 .. warmup - 1)
+        t_log0 = gold[warmup - 1]["KMC time"] if warmup > 0 else 0.0
+        t, worst_t, worst_i, k = t_log0, 0.0, 0.0, 0
+        for (dt, im, _), g in zip(sim.trace, gold[warmup:]):
+            t += dt; k += 1
+            worst_t = max(worst_t, abs(t / g["KMC time"] - 1)); worst_i = max(worst_i, abs(im * 1e6 - g["Current [uA]"]))
+        blk["vs_reference_log"] = {"steps_compared": k, "max_abs_current_diff_uA": worst_i, "max_rel_kmc_time_diff": worst_t,
+                                   "log": "structures/single_devices/timing_7.5nm/output_noguess.txt (6 printed digits)",
+                                   "agrees_to_printed_digits": bool(worst_i <= 1e-4 and worst_t < 1e-5)}
+    except Exception as exc:
+        blk["vs_reference_log"] = {"error": repr(exc)[:200]}
+    sim.close()
+    return blk
 
 
 def arm_watchdog(seconds, rank, what):
@@ -425,6 +463,8 @@ def main():
     ap.add_argument("--no-alt", action="store_true", help="skip the alt_warm_start block")
     ap.add_argument("--no-cpp-host", action="store_true", help="N = 1: skip the cross-check line through the C++ host driver")
     ap.add_argument("--no-pmc", action="store_true", help="N = 1: do not measure roofline.traffic (two rocprofv3 --pmc child runs)")
+    ap.add_argument("--no-log-tolerance", action="store_true", help="N = 1: skip the at_log_tolerance block")
+    ap.add_argument("--cg-tol", type=float, default=None, help="override the CG tolerance (default: the reference's 1e-6)")
     ap.add_argument("--budget", type=float, default=420.0, help="time budget [s] for the timed steps of seconds-per-step workloads")
     ap.add_argument("--timeout", type=float, default=570.0, help="watchdog [s]: exit 3 if the run has not finished (a rank stuck in a collective cannot be unwound)")
     args = ap.parse_args()
@@ -445,7 +485,7 @@ def main():
 
     if world == 1:
         name = args.workload or "7.5nm"
-        sim = Sim(name, devname, x_format=args.x_format, warm_start=args.warm_start)
+        sim = Sim(name, devname, x_format=args.x_format, warm_start=args.warm_start, cg_tol=args.cg_tol)
         elapsed, n = sim.run(args.steps, args.warmup, budget_s=args.budget if sim.s.N > 150000 else None)
         res = summary(sim, elapsed, n)
         roofs = rooflines(sim)
@@ -487,18 +527,27 @@ def main():
             if tb:
                 out["roofline"]["traffic_over_algorithmic"] = round(tb / out["roofline"]["algorithmic_bytes_per_launch"], 3)
         # ---- scale points: the larger stacks of BASELINE.json's configs, measured in the same run ----
+        # ---- the same workload under the settings that reproduce the reference's own log (parity-verified configuration) ----
+        if name == "7.5nm" and not args.no_log_tolerance and args.cg_tol is None:
+            out["at_log_tolerance"] = log_tolerance_block(devname, args.x_format, min(n, 10), 2)
         sp_names = (args.scale_points if args.scale_points is not None else ("tile:5,tile:10" if args.workload is None else "none"))
         points = {}
         for spn in [x for x in sp_names.split(",") if x and x != "none"]:
             try:
                 big = spn.startswith("tile:") and int(spn.split(":")[1]) >= 8
                 sp = Sim(spn, devname, x_format=args.x_format)
-                # tile:10: one step from the cold state (fills the coefficient cache, sizes every buffer) + one with that history; tile:5: 3 steps after one
-                el, ns_ = sp.run(2 if big else 3, 0 if big else 1, budget_s=150.0)
+                # tile:10 (the ~1e6 stack): the cold step (fills the coefficient cache, sizes every buffer, zero start vector) + 3 steady ones,
+                # reported separately; tile:5: 3 steps after one
+                el, ns_ = sp.run(4 if big else 3, 0 if big else 1, budget_s=150.0)
                 r = summary(sp, el, ns_)
                 r["steps"] = ns_; r["warmup"] = 0 if big else 1
-                if big:
-                    r["note"] = "step 1 starts from the cold state (empty tunnelling-coefficient cache, zero start vector), step 2 with that history"
+                if big and ns_ >= 2:
+                    cold, steady = sp.step_log[0], sp.step_log[1:]
+                    ts = sum(t for t, _ in steady) / len(steady)
+                    r["cold_step"] = {"ms": round(cold[0] * 1e3, 1), "cg_iters_X": cold[1]}
+                    r["steady"] = {"steps": len(steady), "ms_per_step": round(ts * 1e3, 1), "steps_per_s": round(1.0 / ts, 5),
+                                   "cg_iters_X": sum(i for _, i in steady) / len(steady), "ms_each": [round(t * 1e3, 1) for t, _ in steady]}
+                    r["note"] = "ms_per_step / steps_per_s average ALL timed steps (cold one included); `steady` = the steps after it"
                 r.update(rooflines(sp))
                 if big:
                     r["strong_scaling_model"] = strong_scaling_model(sp, r["ms_per_step"])
@@ -508,6 +557,14 @@ def main():
                         r["gpu_over_cpu_lower_bound"] = round(r["steps_per_s"] / r["cpu_baseline"]["value"], 1)
                 points[spn] = r
                 sp.close()
+                if not args.no_pmc and "roofline" in r:
+                    # traffic per launch of the dominant kernel at this size; the counter run stops its solves early (cg_tol 1e-3):
+                    # the bytes one launch moves do not depend on the iteration count
+                    tb, detail = pmc_traffic(spn, r["roofline"]["kernel"], args.x_format, cg_tol=1e-3)
+                    r["roofline"]["traffic"] = tb
+                    r["roofline"]["traffic_detail"] = detail
+                    if tb:
+                        r["roofline"]["traffic_over_algorithmic"] = round(tb / r["roofline"]["algorithmic_bytes_per_launch"], 3)
             except Exception as exc:                 # a failed scale point must not void the main measurement
                 points[spn] = {"error": repr(exc)[:300]}
         if points:

@@ -103,6 +103,7 @@ struct Engine {
     double cg_tol = 1e-6;
     int current_warm_start = 0;
     int profiling = 0;
+    int cb_edge_domain = 0;        // 0: CB-edge system over every site (snapshot source); 1: over atoms only (dkmc_set_cb_edge_domain)
     int x_format = 1;              // 1: tiled X (xt.hip, default); 0: CSR X as the reference stores it (current.hip + cg.hip)
     int x_iter_hint = 0;           // iteration count of the previous CG solve of X (sizes the first launch batch)
     dkmc_stats stats{};

@@ -16,6 +16,9 @@
 struct KCtrl { double rr[2]; double pad; int done; int iters; };
 
 // ---- assembly: class bits + diagonal + rhs in one pass (16 lanes per row) ------------------------------------------------
+// CB: 0 potential rule, 1 CB-edge rule, 2 CB-edge rule on atoms only (dkmc_set_cb_edge_domain(1): links to interstitial sites, DEFECT or
+// OXYGEN_DEFECT, do not exist -- the domain the revision behind the reference's own CSR dump and current log solved the CB edge on)
+__device__ __forceinline__ bool k_interstitial(int e) { return e == DEFECT || e == OXYGEN_DEFECT; }
 template <int CB>
 __device__ __forceinline__ bool k_high(int ei, int ej, int qi, int qj, const MetalSet &ms)
 {
@@ -44,18 +47,22 @@ __global__ __launch_bounds__(KC_NT) void k_kc_assemble(int m, int N_left, const 
         const int c = ci[p];
         if (c == r) { cf[p] = c; continue; }
         const int j = N_left + c;
-        const bool hi = k_high<CB>(ei, element[j], qi, charge[j], ms);
+        const int ej = element[j];
+        if (CB == 2 && (k_interstitial(ei) || k_interstitial(ej))) { cf[p] = r; continue; }      // no link: stored as the row's own column, which k_kc_apply skips
+        const bool hi = k_high<CB>(ei, ej, qi, charge[j], ms);
         cf[p] = hi ? (c | (int)0x80000000) : c;
         off += hi ? high_G : low_G;
     }
-    for (int p = lrp[r] + l; p < lrp[r + 1]; p += LPR) { const int j = lci[p]; kl += k_high<CB>(ei, element[j], qi, charge[j], ms) ? high_G : low_G; }
-    for (int p = rrp[r] + l; p < rrp[r + 1]; p += LPR) { const int j = N_left + m + rci[p]; kr += k_high<CB>(ei, element[j], qi, charge[j], ms) ? high_G : low_G; }
+    const bool cut = CB == 2 && k_interstitial(ei);
+    for (int p = lrp[r] + l; p < lrp[r + 1] && !cut; p += LPR) { const int j = lci[p]; const int ej = element[j]; if (CB == 2 && k_interstitial(ej)) continue; kl += k_high<CB>(ei, ej, qi, charge[j], ms) ? high_G : low_G; }
+    for (int p = rrp[r] + l; p < rrp[r + 1] && !cut; p += LPR) { const int j = N_left + m + rci[p]; const int ej = element[j]; if (CB == 2 && k_interstitial(ej)) continue; kr += k_high<CB>(ei, ej, qi, charge[j], ms) ? high_G : low_G; }
 #pragma unroll
     for (int o = LPR / 2; o > 0; o >>= 1) { off += __shfl_xor(off, o, LPR); kl += __shfl_xor(kl, o, LPR); kr += __shfl_xor(kr, o, LPR); }
     if (l == 0) {
         double d = off;          // reduce_rows_into_diag: -(sum of off-diagonals)
         d += kl;                 // add_vector_to_diagonal (left)
         d += kr;                 // add_vector_to_diagonal (right)
+        if (CB == 2 && d == 0.0) d = 1.0;      // an unlinked interstitial site: identity row, value 0
         diag[r] = d;
         rhs[r] = kl * VL + kr * VR;
     }
@@ -210,7 +217,8 @@ int kcg_assemble_and_solve(int cb, int m, int N_left, const int *element, const 
     double *diag = rhs + m, *part_pt = part, *part_rr = part + 4096;
     const double tol2 = e.cg_tol * e.cg_tol;
     const int ab = (m + 15) / 16;
-    if (cb) hipLaunchKernelGGL((k_kc_assemble<1>), dim3(ab), dim3(KC_NT), 0, st, m, N_left, element, charge, ms, high_G, low_G, rp, ci, lrp, lci, rrp, rci, VL, VR, cf, diag, rhs);
+    if (cb == 2) hipLaunchKernelGGL((k_kc_assemble<2>), dim3(ab), dim3(KC_NT), 0, st, m, N_left, element, charge, ms, high_G, low_G, rp, ci, lrp, lci, rrp, rci, VL, VR, cf, diag, rhs);
+    else if (cb) hipLaunchKernelGGL((k_kc_assemble<1>), dim3(ab), dim3(KC_NT), 0, st, m, N_left, element, charge, ms, high_G, low_G, rp, ci, lrp, lci, rrp, rci, VL, VR, cf, diag, rhs);
     else hipLaunchKernelGGL((k_kc_assemble<0>), dim3(ab), dim3(KC_NT), 0, st, m, N_left, element, charge, ms, high_G, low_G, rp, ci, lrp, lci, rrp, rci, VL, VR, cf, diag, rhs);
     const int vb = (m + 255) / 256;
     hipLaunchKernelGGL(k_kc_scale, dim3(vb), dim3(256), 0, st, m, (const double *)diag, s, rhs, y, q);

@@ -204,7 +204,7 @@ extern "C" int dkmc_update_CB_edge_gpu_sparse(dkmc_gpubuf *buf, int N, int N_lef
     (void)pbc; (void)nn_dist;
     tcache_invalidate(buf->site_x);
     Engine &e = eng();
-    int rc = solve_K(buf, N, N_left, N_right, Vd / 2, -Vd / 2, 1, high_G, low_G, num_metals, buf->site_CB_edge,
+    int rc = solve_K(buf, N, N_left, N_right, Vd / 2, -Vd / 2, e.cb_edge_domain ? 2 : 1, high_G, low_G, num_metals, buf->site_CB_edge,
                      &e.stats.cg_iters_CB, &e.stats.cg_rr_CB);
     if (rc) return rc;
     hipLaunchKernelGGL(k_fill_contacts, dim3((N + 255) / 256), dim3(256), 0, e.stream, buf->site_CB_edge, N, N_left, N_right,

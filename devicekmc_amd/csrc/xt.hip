@@ -41,7 +41,7 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 struct __attribute__((aligned(16))) XTile { int k, w; unsigned mask; int soff; };   // cell (k, w); present sub-blocks; first sub-block slot
 struct __attribute__((aligned(32))) XItem { int t0, t1, w, c, k0; unsigned mask0; int soff0, pad; };   // tiles [t0, t1) of strip w; c = position of the run in its strip; descriptor of tile t0
 struct XCtrl { double rr[2]; int done_local, sharded; int done; int iters; };
-// `done` gates every kernel of the loop.  Single GPU: set by the direction kernel.  Sharded solve: the direction kernel only sets
+// `done` (non-zero) gates every kernel of the loop; see k_xt_step for its iteration stamp.  Single GPU: set by the step kernel.  Sharded solve: the direction kernel only sets
 // done_local; rank 0's done_local travels in the all-reduced buffer (slot ns) and k_xt_rows_apply turns it into `done` on every
 // rank in the same iteration -- all control flow derives from data every rank received from the same collective, so the ranks
 // cannot leave the loop at different iterations even if their arithmetic differed in a bit.
@@ -694,7 +694,11 @@ __global__ __launch_bounds__(XT_NT) void k_xt_step(int m, int it, const double *
 {
     __shared__ double red[XT_NT / 64][4];
     __shared__ int sdone;
-    if (threadIdx.x == 0) sdone = ctrl->done;
+    // `done` is a stop word stamped with the iteration: 0 = keep going, d > 0 = kernels of iterations >= d - 1 must not run.  This
+    // kernel is the one launch that both reads and (workgroup 0, below) writes it: the value it writes, it + 2, does not stop
+    // iteration `it`, so a workgroup scheduled after workgroup 0 has published still updates its slice of y and r (a plain 0/1 flag
+    // let such a workgroup skip y += alpha p on the converging iteration: a partially updated, run-dependent solution).
+    if (threadIdx.x == 0) { const int d = ctrl->done; sdone = d != 0 && it + 1 >= d; }
     // the first four elements of this thread are fetched before the partial sums are reduced: their latency hides behind the
     // reduction chain (one element batch covers the whole vector unless the grid is capped)
     const int stride = gridDim.x * XT_NT, i0 = blockIdx.x * XT_NT + threadIdx.x;
@@ -750,7 +754,7 @@ __global__ __launch_bounds__(XT_NT) void k_xt_step(int m, int it, const double *
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctrl->rr[(it + 1) & 1] = rr_new;
         ctrl->iters = it + 1;
-        if (!(rr_new > tol2)) { if (ctrl->sharded) ctrl->done_local = 1; else ctrl->done = 1; }
+        if (!(rr_new > tol2)) { if (ctrl->sharded) ctrl->done_local = 1; else ctrl->done = it + 2; }
     }
 }
 __global__ void k_xt_set_sharded(XCtrl *ctrl) { ctrl->sharded = 1; }

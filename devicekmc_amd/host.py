@@ -177,6 +177,7 @@ class Device:
         n = p.num_atoms_first_layer
         gpubuf.sync_HostToGPU(self)
         _use_stream(gpubuf.dev)
+        _lib.load().dkmc_set_cb_edge_domain(1 if p.cb_edge_domain == "atoms" else 0)
         check(_lib.load().dkmc_update_CB_edge_gpu_sparse(C.byref(gpubuf.c), self.N, n, n, Vd, int(self.pbc), p.high_G, p.low_G,
                                                          self.nn_dist, len(p.metals)))
         gpubuf.sync_GPUToHost(self)

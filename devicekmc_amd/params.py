@@ -73,6 +73,10 @@ class KMCParameters:
     m_0: float = 9.11e-31
     layers: List[Layer] = field(default_factory=default_layers)
     cg_tol: float = 1e-6                    # iterative_solvers_gpu.cu:322
+    # Domain of the CB-edge system (tools/pin_current_constants.py).  "sites" = update_CB_edge_gpu_sparse as in the
+    # snapshot's source (potential_solver_gpu.cu:595-694: every site, interstitials included); "atoms" = interstitial sites (DEFECT /
+    # OXYGEN_DEFECT) carry no link -- the revision that wrote the reference's CSR dump and its current log (`log_revision()`).
+    cb_edge_domain: str = "sites"
     # local temperature model (parameters.txt:76-91)
     k_th_metal: float = 29.0
     k_th_non_vacancy: float = 0.5
@@ -127,6 +131,15 @@ class KMCParameters:
     @property
     def X_tol(self) -> float:
         return self.q * 0.01
+
+    def log_revision(self) -> "KMCParameters":
+        """The settings under which the reference's own artefacts are reproduced: CG tolerance 1e-12 ("used to be 1e-12",
+        iterative_solvers_gpu.cu:322) and the CB edge solved on atoms only."""
+        import copy
+        p = copy.deepcopy(self)
+        p.cg_tol = 1e-12
+        p.cb_edge_domain = "atoms"
+        return p
 
     def for_tiling(self, k: int) -> "KMCParameters":
         """Parameters for the shipped 2.5 nm cell tiled k x k laterally."""

@@ -110,6 +110,12 @@ int dkmc_set_stream(void *hip_stream);
 int dkmc_synchronize(void);
 /* tolerance of solve_sparse_CG_Jacobi; the reference hard-codes 1e-6 (iterative_solvers_gpu.cu:322) */
 void dkmc_set_cg_tolerance(double tol);
+/* Domain of the system update_CB_edge_gpu_sparse solves.  0 (default): every site, as potential_solver_gpu.cu:595-694 of the reference
+ * snapshot does.  1: atoms only -- links to interstitial sites (DEFECT, OXYGEN_DEFECT) are left out and those sites get CB edge 0.  The
+ * reference's own artefacts (X pattern dump timing_2.5nm/fullmatrix_assembly, the 19 currents of timing_7.5nm/output_noguess.txt) were
+ * written by a revision that solved on atoms (its host twin still shows `gesv(.., &N_atom, ..)` as a comment, potential_solver.cpp:98):
+ * with 1 they are reproduced to every entry / printed digit, with 0 the current is 0.83 % lower. */
+void dkmc_set_cb_edge_domain(int atoms_only);
 /* 0 (default): warm-start the current solve from gpubuf.atom_virtual_potentials exactly as the
  * reference does (the buffer holds G0*m of the previous step, current_solver_gpu.cu:1015-1016);
  * 1: warm-start from a private unscaled copy of the previous solution. */

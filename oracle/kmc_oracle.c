@@ -30,7 +30,18 @@ enum { EV_GEN = 0, EV_REC = 1, EV_VDIFF = 2, EV_IDIFF = 3, EV_NULL = 4 };
 
 static const double kB = 8.617333262e-5;      /* kmc_events.cu:4 */
 static const double Q_E = 1.60217663e-19;     /* gpu_solvers.h:261, potential_solver_gpu.cu:4 */
-static const double H_BAR = 1.054571817e-34;  /* iterative_solvers_gpu.cu:8 */
+
+/* Unit constants of the WKB term, populate_sparse_X_gpu2 (iterative_solvers_gpu.cu:1649-1679).  The snapshot holds TWO values of
+ * eV_to_J: 1.60217663e-19 (iterative_solvers_gpu.cu:7, current_solver_gpu.cu:5, potential_solver_gpu.cu:4, input_parser.h:100) and
+ * 1.6e-19 (Device.h:116, KMCProcess.h:41, the constants block of every shipped parameters.txt).  Defaults = the snapshot's device
+ * code; okmc_set_x_constants() switches them one use at a time (tools/pin_current_constants.py: which set wrote the logs). */
+static double X_EVJ_BARRIER = 1.60217663e-19;   /* E1 = eV_to_J * V0, :1662,1679 */
+static double X_EVJ_STEP = 1.60217663e-19;      /* dE = eV_to_J * dV, :1656 */
+static double X_HBAR = 1.054571817e-34;         /* prefac, :1649 */
+void okmc_set_x_constants(double evj_barrier, double evj_step, double h_bar)
+{
+    X_EVJ_BARRIER = evj_barrier; X_EVJ_STEP = evj_step; X_HBAR = h_bar;
+}
 
 /* ------------------------------------------------------------------------- */
 /* geometry: gpu_solvers.h:225-257 (site_dist_gpu), host twin utils.cpp:100-137 */
@@ -295,11 +306,16 @@ int okmc_k_pattern(int N, int nn, const int *neigh, int N_left, int N_right, int
     return nnz;
 }
 
-/* conductance rule: potential_solver_gpu.cu:202-217 (cb == 0) and :239-249 (cb == 1) */
+/* conductance rule: potential_solver_gpu.cu:202-217 (cb == 0) and :239-249 (cb == 1).
+ * cb == 2: the CB-edge rule restricted to ATOMS -- interstitial sites (DEFECT, OXYGEN_DEFECT) carry no link.  This is not in the
+ * snapshot's source; it is the domain the revision that wrote the reference's CSR dump and current log solved the CB edge on (the
+ * host twin still carries the call `gesv(&N_interface, &one, D, &N_atom, ...)` as a comment, potential_solver.cpp:98-99): with it
+ * the dump's 467 336 pattern entries are reproduced exactly, see tools/pin_current_constants.py and DESIGN.md section 2. */
 static inline double k_conductance(int ei, int ej, int qi, int qj, const int *metals, int nm,
                                    double high_G, double low_G, int cb)
 {
     int m1 = is_metal(ei, metals, nm), m2 = is_metal(ej, metals, nm);
+    if (cb == 2 && (ei == DEFECT || ei == OXYGEN_DEFECT || ej == DEFECT || ej == OXYGEN_DEFECT)) return 0.0;
     if (cb) return (m1 || m2) ? high_G : low_G;
     int cv1 = (ei == VACANCY) && (qi == 0), cv2 = (ej == VACANCY) && (qj == 0);
     return ((m1 && m2) || (cv1 && cv2)) ? high_G : low_G;
@@ -340,6 +356,7 @@ void okmc_k_assemble(int N, int N_left, int N_right, const int *element, const i
         double d = -off;   /* reduce_rows_into_diag */
         d += kl;           /* add_vector_to_diagonal (left) */
         d += kr;           /* add_vector_to_diagonal (right) */
+        if (cb == 2 && d == 0.0) d = 1.0;   /* an unlinked interstitial site: identity row, value 0 */
         data[dpos] = d;
         rhs[r] = kl * VL + kr * VR;
     }
@@ -689,18 +706,18 @@ static double x_offdiag_atom(int a, int b, const double *ax, const double *ay, c
         int kind = tunnel_kind(a, b, ael, acb, metals, nm, nlc, n_src, n_gnd, N_full, tol);
         if (kind) {
             double drop = fabs(acb[a] - acb[b]);
-            double prefac = -(sqrt(2 * m_e) / H_BAR) * (2.0 / 3.0);
+            double prefac = -(sqrt(2 * m_e) / X_HBAR) * (2.0 / 3.0);
             double dist = 1e-10 * dA;
             if (kind == 1) {
-                double dE = Q_E * 0.01, T = 0.0;
+                double dE = X_EVJ_STEP * 0.01, T = 0.0;
                 for (double iv = 0; iv < drop; iv += dE) {
-                    double E1 = Q_E * V0 + iv, E2 = E1 - drop;
+                    double E1 = X_EVJ_BARRIER * V0 + iv, E2 = E1 - drop;
                     if (E2 > 0) T += exp(prefac * (dist / drop) * (pow(E1, 1.5) - pow(E2, 1.5)));
                     if (E2 < 0) T += exp(prefac * (dist / drop) * (pow(E1, 1.5)));
                 }
                 v = -T;
             } else {
-                double E1 = Q_E * V0, E2 = E1 - drop;
+                double E1 = X_EVJ_BARRIER * V0, E2 = E1 - drop;
                 if (E2 > 0) v = -exp(prefac * (dist / fabs(E1 - E2)) * (pow(E1, 1.5) - pow(E2, 1.5)));
                 if (E2 < 0) v = -exp(prefac * (dist / fabs(E1 - E2)) * (pow(E1, 1.5)));
             }

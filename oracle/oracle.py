@@ -173,7 +173,8 @@ class OracleKMC:
     def set_laplace_potential(self, Vd, tol=None):
         tol = self.p.cg_tol if tol is None else tol
         nl = self.p.num_atoms_first_layer
-        it, rr = self._solve_K(self.CB_edge, Vd / 2, -Vd / 2, 1, tol)
+        # cb_edge_domain "atoms": the log revision's CB edge (k_conductance cb == 2), see params.KMCParameters.cb_edge_domain
+        it, rr = self._solve_K(self.CB_edge, Vd / 2, -Vd / 2, 2 if self.p.cb_edge_domain == "atoms" else 1, tol)
         self.CB_edge[:nl] = Vd / 2
         self.CB_edge[self.N - nl:] = -Vd / 2
         self.CB_edge *= 1.60217663e-19

@@ -191,6 +191,34 @@ int comm_allreduce_sum_f64(double *buf, size_t count)
     return 0;
 }
 
+// Agreement point of a sharded phase: every rank contributes whether its LOCAL work so far succeeded; if any rank failed, every rank
+// returns an error (the failing rank its own code, the others 46) -- nobody is left waiting in the collective that would have
+// followed.  Callers make sure every rank reaches exactly one agreement point per phase, whatever happened before it.
+static int g_agree_count = 0;
+int comm_agree_count() { return g_agree_count; }
+int comm_agree(int local_rc, const char *what)
+{
+    Comm &c = g_comm; Engine &e = eng(); hipStream_t st = e.stream;
+    if (c.transport == DKMC_COMM_NONE) return local_rc;
+    ++g_agree_count;
+    // the word travels in its own small device buffer: the engine's scratch may be what failed
+    static double *d_word = nullptr;
+    if (!d_word && hipMalloc((void **)&d_word, 64) != hipSuccess) d_word = nullptr;
+    const double mine = local_rc ? 1.0 : 0.0;
+    double total = mine;
+    bool moved = false;
+    if (d_word && hipMemcpyAsync(d_word, &mine, 8, hipMemcpyHostToDevice, st) == hipSuccess) {
+        const int saved_code = e.err_code; char saved_msg[sizeof(e.err)]; memcpy(saved_msg, e.err, sizeof(e.err));
+        if (comm_allreduce_sum_f64(d_word, 1) == 0 && hipStreamSynchronize(st) == hipSuccess &&
+            hipMemcpy(&total, d_word, 8, hipMemcpyDeviceToHost) == hipSuccess) moved = true;
+        if (local_rc) { e.err_code = saved_code; memcpy(e.err, saved_msg, sizeof(e.err)); }       // keep the first error's text
+    }
+    if (local_rc) return local_rc;
+    if (!moved) return dkmc_fail(45, "comm: agreement exchange failed", __FILE__, __LINE__);
+    if (total != 0.0) { char msg[160]; snprintf(msg, sizeof(msg), "a peer rank failed in: %s", what ? what : "a sharded phase"); return dkmc_fail(46, msg, __FILE__, __LINE__); }
+    return 0;
+}
+
 // every rank ends with rank 0's `count` doubles: the other ranks contribute zeros to a sum, which is exact whatever order the
 // transport adds in (x + 0 + ... + 0 = x), so no rank can be left with different bits.  Used once per solve on its results, so that
 // the replicated phases downstream (power, temperature, event rates) start from identical state on every rank.

@@ -150,6 +150,8 @@ int comm_nranks();
 int comm_rank();
 int comm_allgather_f64(double *buf, size_t count);     // in place on the engine's stream; rank r owns buf[r*count, (r+1)*count)
 int comm_allreduce_sum_f64(double *buf, size_t count); // in place; the sum over the ranks (grouping of the additions is the transport's)
+int comm_agree(int local_rc, const char *what);         // agreement point: non-zero on EVERY rank if any rank passed a non-zero local_rc (comm.hip)
+int comm_agree_count();
 int comm_bcast0_f64(double *buf, size_t count);        // in place; every rank ends with rank 0's bits
 
 // shared primitives (scan.hip)

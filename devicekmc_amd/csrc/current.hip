@@ -293,10 +293,28 @@ __global__ void k_iota_rows(int n, int *rows)
 // state of the last call (for dkmc_get_last_X and the private warm start)
 static int g_last_rows = 0; static long long g_last_nnz = 0; static bool g_last_tiled = false;
 
+static int update_power_body(dkmc_gpubuf *buf, int n_src, int n_gnd, int nlc, double Vd, int pbc,
+                             double high_G, double low_G, double loop_G, double G0, double tol, double nn_dist,
+                             double m_e, double V0, int num_metals, double *h_imacro,
+                             int heat_local, int heat_global, double alpha_disp);
 extern "C" int dkmc_update_power_gpu_sparse(dkmc_gpubuf *buf, int n_src, int n_gnd, int nlc, double Vd, int pbc,
                                             double high_G, double low_G, double loop_G, double G0, double tol, double nn_dist,
                                             double m_e, double V0, int num_metals, double *h_imacro,
                                             int heat_local, int heat_global, double alpha_disp)
+{
+    // Sharded solve on the tiled X: every rank passes exactly one agreement point per call (comm_agree, in xt_assemble_and_solve, after
+    // all local set-up and before the first collective).  A rank that fails BEFORE it (compaction, S, coefficient cache) reaches it
+    // here instead, so that its peers learn of the failure rather than wait for a collective that never comes.
+    const int agreed_before = comm_agree_count();
+    const int rc = update_power_body(buf, n_src, n_gnd, nlc, Vd, pbc, high_G, low_G, loop_G, G0, tol, nn_dist, m_e, V0, num_metals, h_imacro,
+                                     heat_local, heat_global, alpha_disp);
+    if (rc && comm_attached() && eng().x_format != 0 && comm_agree_count() == agreed_before) (void)comm_agree(rc, "set-up of the current solve");
+    return rc;
+}
+static int update_power_body(dkmc_gpubuf *buf, int n_src, int n_gnd, int nlc, double Vd, int pbc,
+                             double high_G, double low_G, double loop_G, double G0, double tol, double nn_dist,
+                             double m_e, double V0, int num_metals, double *h_imacro,
+                             int heat_local, int heat_global, double alpha_disp)
 {
     Engine &e = eng(); hipStream_t st = e.stream;
     const int N = buf->N_, nn = buf->nn_;

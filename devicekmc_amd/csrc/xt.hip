@@ -40,7 +40,7 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 
 struct __attribute__((aligned(16))) XTile { int k, w; unsigned mask; int soff; };   // cell (k, w); present sub-blocks; first sub-block slot
 struct __attribute__((aligned(32))) XItem { int t0, t1, w, c, k0; unsigned mask0; int soff0, pad; };   // tiles [t0, t1) of strip w; c = position of the run in its strip; descriptor of tile t0
-struct XCtrl { double rr[2]; int done_local, sharded; int done; int iters; };
+struct XCtrl { double rr[2]; int done_local, sharded; int done; int iters; int abort_local, aborted; int pad[2]; };
 // `done` (non-zero) gates every kernel of the loop; see k_xt_step for its iteration stamp.  Single GPU: set by the step kernel.  Sharded solve: the direction kernel only sets
 // done_local; rank 0's done_local travels in the all-reduced buffer (slot ns) and k_xt_rows_apply turns it into `done` on every
 // rank in the same iteration -- all control flow derives from data every rank received from the same collective, so the ranks
@@ -604,7 +604,8 @@ __global__ __launch_bounds__(XT_NT) void k_xt_rows(int ns, int nK, int nW, int n
         }
     }
     if (MODE == 1) {
-        if (ctrl && blockIdx.x == 0 && threadIdx.x == 0) xout[ns] = (flag_rank0 && ctrl->done_local) ? 1.0 : 0.0;   // the stop decision rides in the all-reduce
+        // the stop decision (rank 0's) and the abort word (any rank's) ride in the all-reduce, slots ns and ns + 1
+        if (ctrl && blockIdx.x == 0 && threadIdx.x == 0) { xout[ns] = (flag_rank0 && ctrl->done_local) ? 1.0 : 0.0; xout[ns + 1] = ctrl->abort_local ? 1.0 : 0.0; }
         return;
     }
     // the non-S rows of this workgroup's share of the vector
@@ -620,9 +621,9 @@ __global__ __launch_bounds__(XT_NT) void k_xt_rows_apply(int ns, int nK, const d
 {
     __shared__ double red[XT_NT / 64][4];
     __shared__ int sdone;
-    if (threadIdx.x == 0) sdone = ctrl->done || xbuf[ns] != 0.0;     // xbuf[ns]: rank 0's stop decision, identical on every rank
+    if (threadIdx.x == 0) sdone = ctrl->done || xbuf[ns] != 0.0 || xbuf[ns + 1] != 0.0;     // xbuf[ns]: rank 0's stop decision; xbuf[ns + 1]: a rank aborted -- the same on every rank
     __syncthreads();
-    if (sdone) { if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->done = 1; return; }
+    if (sdone) { if (blockIdx.x == 0 && threadIdx.x == 0) { ctrl->done = 1; if (xbuf[ns + 1] != 0.0) ctrl->aborted = 1; } return; }
     double acc = 0.0, arr = 0.0, att = 0.0;
     for (int k = blockIdx.x; k < nK; k += gridDim.x) {
         const int s = XT_R * k + (int)threadIdx.x;
@@ -758,6 +759,11 @@ __global__ __launch_bounds__(XT_NT) void k_xt_step(int m, int it, const double *
     }
 }
 __global__ void k_xt_set_sharded(XCtrl *ctrl) { ctrl->sharded = 1; }
+// a rank whose host side failed between two collectives: its contribution to the next all-reduce says so (whatever else it holds)
+__global__ void k_xt_abort_word(XCtrl *ctrl, double *xbuf, int ns) { ctrl->abort_local = 1; xbuf[ns + 1] = 1.0; }
+// test aid: make this rank fail once, in the assembly (phase 1) or on the host side of CG iteration `iteration` (phase 2)
+static int g_fault_phase = 0, g_fault_iter = 0;
+extern "C" void dkmc_debug_inject_fault(int phase, int iteration) { g_fault_phase = phase; g_fault_iter = iteration; }
 __global__ void k_xt_vec_mul(int m, double *__restrict__ y, const double *__restrict__ s)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -923,119 +929,137 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
     const long long ncell = (long long)nK * nW;
     if (ncell > 0x7ffffff0ll) return dkmc_fail(47, "update_power: too many tile cells", __FILE__, __LINE__);
 
-    // ---- sparse part Xs: neighbour pattern of every row + values (same kernels as the CSR path, all rows) ----
-    int *cnt = (int *)scratch(S_X_CNT, (size_t)(Nsub + 4) * 4);
-    xrp_t *rp = (xrp_t *)scratch(S_X_ROWPTR, (size_t)(Nsub + 4) * sizeof(xrp_t));
-    xrp_t *dpos = (xrp_t *)scratch(S_XT_DPOS, (size_t)(Nsub + 4) * sizeof(xrp_t));
-    int *nsrank = (int *)scratch(S_X_SCB, (size_t)(Nsub + 4) * 4);
-    if (!cnt || !rp || !dpos || !nsrank) return e.err_code;
-    const int nbr = (Nsub + 255) / 256;
-    hipLaunchKernelGGL((k_xpat_plain<0>), dim3(nbr), dim3(256), 0, st, P, (const int *)nullptr, aneigh, ancnt, cnt, (const xrp_t *)nullptr, (int *)nullptr);
-    int rc = dkmc_exclusive_scan_i32_i64(cnt, rp, Nsub, rp + Nsub); if (rc) return rc;
-    long long xs_nnz = 0;
-    HIPCHK(hipMemcpyAsync(&xs_nnz, rp + Nsub, sizeof(long long), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (xs_nnz <= 0) return dkmc_fail(10, "update_power: empty X", __FILE__, __LINE__);
-    X.xs_nnz = xs_nnz;
-    int *col = (int *)scratch(S_X_COL, (size_t)xs_nnz * 4);
-    double *val = (double *)scratch(S_X_DATA, (size_t)xs_nnz * 8);
-    if (!col || !val) return e.err_code;
-    hipLaunchKernelGGL((k_xpat_plain<1>), dim3(nbr), dim3(256), 0, st, P, (const int *)nullptr, aneigh, ancnt, cnt, (const xrp_t *)rp, col);
-    hipLaunchKernelGGL((k_xval<16>), dim3((Nsub + 15) / 16), dim3(256), 0, st, P, Nsub, (const SEntry *)nullptr, 0, (const int *)nullptr, (const xrp_t *)rp,
-                       (const int *)col, (const double *)buf->atom_x, (const double *)buf->atom_y, (const double *)buf->atom_z, aflag,
-                       (const double *)buf->atom_CB_edge, val, TC, atom_site, dpos);
-    hipLaunchKernelGGL(k_xt_node_srank, dim3(nbr), dim3(256), 0, st, Nsub, srank, nsrank);
-    KCHK();
-    g_xb.rp = rp; g_xb.dpos = dpos; g_xb.ci = col; g_xb.val = val; g_xb.nsrank = nsrank;
-
-    // ---- S in solver order ----
-    double *sd = (double *)scratch(S_XT_SNODE_D, (size_t)ns_pad * 4 * 8);
-    int *si = (int *)scratch(S_XT_SNODE_I, (size_t)ns_pad * 4 * 4);
-    if (!sd || !si) return e.err_code;
-    SNodes SN; SN.x = sd; SN.y = sd + ns_pad; SN.z = sd + 2 * (size_t)ns_pad; SN.cb = sd + 3 * (size_t)ns_pad;
-    SN.flag = si; SN.slot = si + ns_pad; SN.mr = si + 2 * (size_t)ns_pad;
-    int *srow = si + 3 * (size_t)ns_pad;
-    hipLaunchKernelGGL(k_xt_snodes, dim3((ns_pad + 255) / 256), dim3(256), 0, st, ns, ns_pad, S, (const double *)buf->atom_x, (const double *)buf->atom_y,
-                       (const double *)buf->atom_z, atom_site, TC, sd, sd + ns_pad, sd + 2 * (size_t)ns_pad, sd + 3 * (size_t)ns_pad,
-                       si, si + ns_pad, si + 2 * (size_t)ns_pad, srow);
-    g_xb.S = SN; g_xb.srow = srow;
-
-    // ---- census -> tile list -> work items ----
-    X.ntiles = 0; X.nitems = 0; X.nsub_total = 0; X.t_upper = 0; X.kc = 1;
-    unsigned *cmask = nullptr; int *is_tile = nullptr, *nsubc = nullptr, *toff = nullptr, *soff = nullptr;
-    if (ncell > 0) {
-        cmask = (unsigned *)scratch(S_XT_CMASK, (size_t)(ncell + 4) * 4);
-        is_tile = (int *)scratch(S_XT_ISTILE, (size_t)(ncell + 4) * 4);
-        nsubc = (int *)scratch(S_XT_NSUBC, (size_t)(ncell + 4) * 4);
-        toff = (int *)scratch(S_XT_TOFF, (size_t)(ncell + 4) * 4);
-        soff = (int *)scratch(S_XT_SOFF, (size_t)(ncell + 4) * 4);
-        if (!cmask || !is_tile || !nsubc || !toff || !soff) return e.err_code;
-        hipLaunchKernelGGL(k_xt_census, dim3((unsigned)((ncell + 3) / 4)), dim3(XT_NT), 0, st, P, ns, nK, nW, SN, cmask);
-        hipLaunchKernelGGL(k_xt_cell_counts, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, ncell, (const unsigned *)cmask, is_tile, nsubc);
-        rc = dkmc_exclusive_scan_i32(is_tile, toff, (int)ncell, toff + ncell); if (rc) return rc;
-        rc = dkmc_exclusive_scan_i32(nsubc, soff, (int)ncell, soff + ncell); if (rc) return rc;
-        int h2[2] = {0, 0};
-        HIPCHK(hipMemcpyAsync(&h2[0], toff + ncell, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(&h2[1], soff + ncell, sizeof(int), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        X.ntiles = h2[0]; X.nsub_total = h2[1];
-        if (h2[1] < 0) return dkmc_fail(47, "update_power: more than 2^31 sub-blocks", __FILE__, __LINE__);
-    }
-    const int ntiles = X.ntiles;
-    // tiles per work item: ~4 k items per GPU.  Measured at 234 975 sites (19 372 tiles): 2 / 4 / 8 / 16 tiles per item -> 198 / 188 / 206 /
-    // 222 us per launch (more items: ~2 us of start-up chain per wave round; fewer: the last waves stream alone, latency-bound)
+    // Everything up to the first collective is LOCAL work (pattern, census, tile list, this rank's share, storage, fill): in a sharded
+    // solve a failure here (an allocation that does not fit, a launch error) must not leave the peers blocked in the collective that
+    // follows -- the ranks agree on the outcome of this phase first (comm_agree) and leave together.
+    const int nbr = (Nsub + 255) / 256, m = Nsub;
     const bool sharded = comm_attached() != 0;
     const int nr = sharded ? comm_nranks() : 1, me = sharded ? comm_rank() : 0;
-    X.kc = std::max(1, std::min(XT_MAXKC, ntiles / nr / 4096));
-    XTile *tiles = (XTile *)scratch(S_XT_TILES, (size_t)(ntiles + 1) * sizeof(XTile));
-    int2 *wrange = (int2 *)scratch(S_XT_WRANGE, (size_t)(nK + 4) * sizeof(int2));
-    if (!tiles || !wrange) return e.err_code;
-    if (ncell > 0) {
-        hipLaunchKernelGGL(k_xt_tile_list, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, nK, ncell, (const unsigned *)cmask, (const int *)toff, (const int *)soff, tiles);
-        hipLaunchKernelGGL(k_xt_wrange, dim3((nK + 255) / 256), dim3(256), 0, st, nK, nW, (const unsigned *)cmask, wrange);
-    }
-    XShare sh{};
-    rc = xt_build_items(nK, nW, X.kc, ntiles, X.nsub_total, toff, tiles, nr, me, S_XT_NITEMW, S_XT_ITEMS, S_XT_SPLIT, &sh); if (rc) return rc;
-    X.nitems = sh.nitems; X.maxchunk = sh.maxchunk;
-    const int nitems = sh.nitems;
-    XItem *items = sh.items; int *nitem_w = sh.nitem_w;
-    KCHK();
-    g_xb.tiles = tiles; g_xb.items = items; g_xb.wrange = wrange; g_xb.nitem_w = nitem_w; g_xb.cmask = cmask; g_xb.toff = toff;
+    int rc = 0, ntiles = 0;
+    long long xs_nnz = 0;
+    int *cnt = nullptr, *nsrank = nullptr, *col = nullptr, *si = nullptr, *srow = nullptr, *nitem_w = nullptr;
+    xrp_t *rp = nullptr, *dpos = nullptr;
+    double *val = nullptr, *sd = nullptr, *tval = nullptr, *rowpart = nullptr, *colpart = nullptr, *sc = nullptr, *r = nullptr, *p = nullptr, *t = nullptr,
+           *q = nullptr, *vS = nullptr, *part = nullptr, *qS = nullptr, *sS = nullptr, *xS = nullptr, *part_pt = nullptr, *part_rr = nullptr;
+    XTile *tiles = nullptr; int2 *wrange = nullptr; XItem *items = nullptr; unsigned long long *d_cnt = nullptr; XCtrl *ctrl = nullptr;
+    SNodes SN{};
+    double *xbuf = nullptr;
+    auto assemble = [&]() -> int {
+        if (g_fault_phase == 1) { g_fault_phase = 0; return dkmc_fail(90, "injected fault (assembly of X)", __FILE__, __LINE__); }
+        if (sharded) { xbuf = (double *)scratch(S_CG_XCHG, (size_t)(ns + 2) * 8); if (!xbuf) return e.err_code; if (ns > 0) { rc = xt_side_init(); if (rc) return rc; } }
+        // ---- sparse part Xs: neighbour pattern of every row + values (same kernels as the CSR path, all rows) ----
+        cnt = (int *)scratch(S_X_CNT, (size_t)(Nsub + 4) * 4);
+        rp = (xrp_t *)scratch(S_X_ROWPTR, (size_t)(Nsub + 4) * sizeof(xrp_t));
+        dpos = (xrp_t *)scratch(S_XT_DPOS, (size_t)(Nsub + 4) * sizeof(xrp_t));
+        nsrank = (int *)scratch(S_X_SCB, (size_t)(Nsub + 4) * 4);
+        if (!cnt || !rp || !dpos || !nsrank) return e.err_code;
+        hipLaunchKernelGGL((k_xpat_plain<0>), dim3(nbr), dim3(256), 0, st, P, (const int *)nullptr, aneigh, ancnt, cnt, (const xrp_t *)nullptr, (int *)nullptr);
+        rc = dkmc_exclusive_scan_i32_i64(cnt, rp, Nsub, rp + Nsub); if (rc) return rc;
+        HIPCHK(hipMemcpyAsync(&xs_nnz, rp + Nsub, sizeof(long long), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (xs_nnz <= 0) return dkmc_fail(10, "update_power: empty X", __FILE__, __LINE__);
+        X.xs_nnz = xs_nnz;
+        col = (int *)scratch(S_X_COL, (size_t)xs_nnz * 4);
+        val = (double *)scratch(S_X_DATA, (size_t)xs_nnz * 8);
+        if (!col || !val) return e.err_code;
+        hipLaunchKernelGGL((k_xpat_plain<1>), dim3(nbr), dim3(256), 0, st, P, (const int *)nullptr, aneigh, ancnt, cnt, (const xrp_t *)rp, col);
+        hipLaunchKernelGGL((k_xval<16>), dim3((Nsub + 15) / 16), dim3(256), 0, st, P, Nsub, (const SEntry *)nullptr, 0, (const int *)nullptr, (const xrp_t *)rp,
+                           (const int *)col, (const double *)buf->atom_x, (const double *)buf->atom_y, (const double *)buf->atom_z, aflag,
+                           (const double *)buf->atom_CB_edge, val, TC, atom_site, dpos);
+        hipLaunchKernelGGL(k_xt_node_srank, dim3(nbr), dim3(256), 0, st, Nsub, srank, nsrank);
+        KCHK();
+        g_xb.rp = rp; g_xb.dpos = dpos; g_xb.ci = col; g_xb.val = val; g_xb.nsrank = nsrank;
 
-    // ---- this rank's share of the work items (contiguous in the strip-major tile list, balanced by stored bytes) ----
-    X.item_lo = sh.item_lo; X.item_n = sh.item_n; X.tile_lo = sh.tile_lo; X.tile_n = sh.tile_n; X.sub_base = sh.sub_base; X.sub_n = sh.sub_n;
-    X.w_lo = sh.w_lo; X.w_hi = sh.w_hi;
-    e.stats.comm_ranks = sharded ? comm_nranks() : 0;
-    e.stats.comm_count_per_rank = sharded ? ns + 1 : 0;
-    e.stats.comm_local_segments = X.item_n;
+        // ---- S in solver order ----
+        sd = (double *)scratch(S_XT_SNODE_D, (size_t)ns_pad * 4 * 8);
+        si = (int *)scratch(S_XT_SNODE_I, (size_t)ns_pad * 4 * 4);
+        if (!sd || !si) return e.err_code;
+        SN.x = sd; SN.y = sd + ns_pad; SN.z = sd + 2 * (size_t)ns_pad; SN.cb = sd + 3 * (size_t)ns_pad;
+        SN.flag = si; SN.slot = si + ns_pad; SN.mr = si + 2 * (size_t)ns_pad;
+        srow = si + 3 * (size_t)ns_pad;
+        hipLaunchKernelGGL(k_xt_snodes, dim3((ns_pad + 255) / 256), dim3(256), 0, st, ns, ns_pad, S, (const double *)buf->atom_x, (const double *)buf->atom_y,
+                           (const double *)buf->atom_z, atom_site, TC, sd, sd + ns_pad, sd + 2 * (size_t)ns_pad, sd + 3 * (size_t)ns_pad,
+                           si, si + ns_pad, si + 2 * (size_t)ns_pad, srow);
+        g_xb.S = SN; g_xb.srow = srow;
 
-    // ---- storage + fill ----
-    double *tval = (double *)scratch(S_XT_TVAL, (size_t)(X.sub_n + 1) * XT_SUB * 8);
-    double *rowpart = (double *)scratch(S_XT_ROWPART, (size_t)(ncell + 1) * XT_R * 8);
-    double *colpart = (double *)scratch(S_XT_COLPART, (size_t)X.maxchunk * ns_pad * 8);
-    unsigned long long *d_cnt = (unsigned long long *)scratch(S_XT_CNT, 16);
-    if (!tval || !rowpart || !colpart || !d_cnt) return e.err_code;
-    HIPCHK(hipMemsetAsync(rowpart, 0, (size_t)(ncell + 1) * XT_R * 8, st));
-    HIPCHK(hipMemsetAsync(colpart, 0, (size_t)X.maxchunk * ns_pad * 8, st));
-    HIPCHK(hipMemsetAsync(d_cnt, 0, 16, st));
-    if (X.tile_n > 0)
-        hipLaunchKernelGGL(k_xt_fill, dim3(X.tile_n), dim3(XT_NT), 0, st, P, ns, (const XTile *)tiles + X.tile_lo, (int)X.sub_base, SN, TC, tval, d_cnt);
-    KCHK();
-    g_xb.tval = tval; g_xb.rowpart = rowpart; g_xb.colpart = colpart;
-    X.valid = true;
+        // ---- census -> tile list -> work items ----
+        X.ntiles = 0; X.nitems = 0; X.nsub_total = 0; X.t_upper = 0; X.kc = 1;
+        unsigned *cmask = nullptr; int *is_tile = nullptr, *nsubc = nullptr, *toff = nullptr, *soff = nullptr;
+        if (ncell > 0) {
+            cmask = (unsigned *)scratch(S_XT_CMASK, (size_t)(ncell + 4) * 4);
+            is_tile = (int *)scratch(S_XT_ISTILE, (size_t)(ncell + 4) * 4);
+            nsubc = (int *)scratch(S_XT_NSUBC, (size_t)(ncell + 4) * 4);
+            toff = (int *)scratch(S_XT_TOFF, (size_t)(ncell + 4) * 4);
+            soff = (int *)scratch(S_XT_SOFF, (size_t)(ncell + 4) * 4);
+            if (!cmask || !is_tile || !nsubc || !toff || !soff) return e.err_code;
+            hipLaunchKernelGGL(k_xt_census, dim3((unsigned)((ncell + 3) / 4)), dim3(XT_NT), 0, st, P, ns, nK, nW, SN, cmask);
+            hipLaunchKernelGGL(k_xt_cell_counts, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, ncell, (const unsigned *)cmask, is_tile, nsubc);
+            rc = dkmc_exclusive_scan_i32(is_tile, toff, (int)ncell, toff + ncell); if (rc) return rc;
+            rc = dkmc_exclusive_scan_i32(nsubc, soff, (int)ncell, soff + ncell); if (rc) return rc;
+            int h2[2] = {0, 0};
+            HIPCHK(hipMemcpyAsync(&h2[0], toff + ncell, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(&h2[1], soff + ncell, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            X.ntiles = h2[0]; X.nsub_total = h2[1];
+            if (h2[1] < 0) return dkmc_fail(47, "update_power: more than 2^31 sub-blocks", __FILE__, __LINE__);
+        }
+        ntiles = X.ntiles;
+        // tiles per work item: ~4 k items per GPU.  Measured at 234 975 sites (19 372 tiles): 2 / 4 / 8 / 16 tiles per item -> 198 / 188 / 206 /
+        // 222 us per launch (more items: ~2 us of start-up chain per wave round; fewer: the last waves stream alone, latency-bound)
+        X.kc = std::max(1, std::min(XT_MAXKC, ntiles / nr / 4096));
+        tiles = (XTile *)scratch(S_XT_TILES, (size_t)(ntiles + 1) * sizeof(XTile));
+        wrange = (int2 *)scratch(S_XT_WRANGE, (size_t)(nK + 4) * sizeof(int2));
+        if (!tiles || !wrange) return e.err_code;
+        if (ncell > 0) {
+            hipLaunchKernelGGL(k_xt_tile_list, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, nK, ncell, (const unsigned *)cmask, (const int *)toff, (const int *)soff, tiles);
+            hipLaunchKernelGGL(k_xt_wrange, dim3((nK + 255) / 256), dim3(256), 0, st, nK, nW, (const unsigned *)cmask, wrange);
+        }
+        XShare sh{};
+        rc = xt_build_items(nK, nW, X.kc, ntiles, X.nsub_total, toff, tiles, nr, me, S_XT_NITEMW, S_XT_ITEMS, S_XT_SPLIT, &sh); if (rc) return rc;
+        X.nitems = sh.nitems; X.maxchunk = sh.maxchunk;
+        items = sh.items; nitem_w = sh.nitem_w;
+        KCHK();
+        g_xb.tiles = tiles; g_xb.items = items; g_xb.wrange = wrange; g_xb.nitem_w = nitem_w; g_xb.cmask = cmask; g_xb.toff = toff;
 
-    // ---- vectors ----
-    const int m = Nsub;
-    double *sc = (double *)scratch(S_CG_S, (size_t)m * 8), *r = (double *)scratch(S_CG_R, (size_t)m * 8);
-    double *p = (double *)scratch(S_CG_P, (size_t)m * 8), *t = (double *)scratch(S_CG_T, (size_t)m * 8);
-    double *q = (double *)scratch(S_XT_Q, (size_t)m * 8);
-    double *vS = (double *)scratch(S_CG_PS, (size_t)ns_pad * 3 * 8);       // qS | sS | scratch of the tile-sum passes (padding stays zero)
-    double *part = (double *)scratch(S_CG_PART, (size_t)3 * 8192 * 8);
-    XCtrl *ctrl = (XCtrl *)scratch(S_CG_CTRL, sizeof(XCtrl));
-    if (!sc || !r || !p || !t || !q || !vS || !part || !ctrl) return e.err_code;
-    double *qS = vS, *sS = vS + ns_pad, *xS = vS + 2 * (size_t)ns_pad;
-    HIPCHK(hipMemsetAsync(vS, 0, (size_t)ns_pad * 3 * 8, st));
-    double *part_pt = part, *part_rr = part + 4096;          // p.t | r.t | t.t partials (XT_PSTRIDE apart); r.r partials, double-buffered (512 apart)
+        // ---- this rank's share of the work items (contiguous in the strip-major tile list, balanced by stored bytes) ----
+        X.item_lo = sh.item_lo; X.item_n = sh.item_n; X.tile_lo = sh.tile_lo; X.tile_n = sh.tile_n; X.sub_base = sh.sub_base; X.sub_n = sh.sub_n;
+        X.w_lo = sh.w_lo; X.w_hi = sh.w_hi;
+        e.stats.comm_ranks = sharded ? comm_nranks() : 0;
+        e.stats.comm_count_per_rank = sharded ? ns + 2 : 0;
+        e.stats.comm_local_segments = X.item_n;
+
+        // ---- storage + fill ----
+        tval = (double *)scratch(S_XT_TVAL, (size_t)(X.sub_n + 1) * XT_SUB * 8);
+        rowpart = (double *)scratch(S_XT_ROWPART, (size_t)(ncell + 1) * XT_R * 8);
+        colpart = (double *)scratch(S_XT_COLPART, (size_t)X.maxchunk * ns_pad * 8);
+        d_cnt = (unsigned long long *)scratch(S_XT_CNT, 16);
+        if (!tval || !rowpart || !colpart || !d_cnt) return e.err_code;
+        HIPCHK(hipMemsetAsync(rowpart, 0, (size_t)(ncell + 1) * XT_R * 8, st));
+        HIPCHK(hipMemsetAsync(colpart, 0, (size_t)X.maxchunk * ns_pad * 8, st));
+        HIPCHK(hipMemsetAsync(d_cnt, 0, 16, st));
+        if (X.tile_n > 0)
+            hipLaunchKernelGGL(k_xt_fill, dim3(X.tile_n), dim3(XT_NT), 0, st, P, ns, (const XTile *)tiles + X.tile_lo, (int)X.sub_base, SN, TC, tval, d_cnt);
+        KCHK();
+        g_xb.tval = tval; g_xb.rowpart = rowpart; g_xb.colpart = colpart;
+        X.valid = true;
+
+        // ---- vectors ----
+        sc = (double *)scratch(S_CG_S, (size_t)m * 8); r = (double *)scratch(S_CG_R, (size_t)m * 8);
+        p = (double *)scratch(S_CG_P, (size_t)m * 8); t = (double *)scratch(S_CG_T, (size_t)m * 8);
+        q = (double *)scratch(S_XT_Q, (size_t)m * 8);
+        vS = (double *)scratch(S_CG_PS, (size_t)ns_pad * 3 * 8);       // qS | sS | scratch of the tile-sum passes (padding stays zero)
+        part = (double *)scratch(S_CG_PART, (size_t)3 * 8192 * 8);
+        ctrl = (XCtrl *)scratch(S_CG_CTRL, sizeof(XCtrl));
+        if (!sc || !r || !p || !t || !q || !vS || !part || !ctrl) return e.err_code;
+        qS = vS; sS = vS + ns_pad; xS = vS + 2 * (size_t)ns_pad;
+        HIPCHK(hipMemsetAsync(vS, 0, (size_t)ns_pad * 3 * 8, st));
+        part_pt = part; part_rr = part + 4096;          // p.t | r.t | t.t partials (XT_PSTRIDE apart); r.r partials, double-buffered (512 apart)
+        return 0;
+    };
+    rc = assemble();
+    if (sharded) rc = comm_agree(rc, "assembly of X");
+    if (rc) return rc;
+
     const double tol2 = e.cg_tol * e.cg_tol;
 
     // ---- diagonal: -(row sums of T), one pass with the vector of ones ----
@@ -1054,19 +1078,21 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
     const int gv = xt_grid(m, XT_NT * 4, 256);
     const int np_pt = n2b;
     const bool nt_loads = (size_t)X.sub_n * XT_SUB * 8 > ((size_t)200 << 20);
-    double *xbuf = nullptr;
-    if (sharded) { xbuf = (double *)scratch(S_CG_XCHG, (size_t)(ns + 2) * 8); if (!xbuf) return e.err_code; }
 
     const bool split = sharded && ns > 0;                 // tile pass + exchange on the engine's stream, neighbour part on the side stream
     const bool seq_neigh = !split && (size_t)X.sub_n * XT_SUB * 8 > ((size_t)2 << 30);
-    if (split) { rc = xt_side_init(); if (rc) return rc; }
     e.stats.xt_split_launch = (split || seq_neigh) ? 1 : 0;  // the timed apply launch carries the tiles only
+    int cur_it = -1, local_fail = 0;        // iteration being enqueued; first host-side failure of this rank inside the loop
     auto matvec = [&](hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3, hipEvent_t ec) -> int {
 #define XT_APPLY_ARGS(NI, NTB, NSB) NI, (const XItem *)items + X.item_lo, (const XTile *)tiles, (int)X.sub_base, (const double *)tval, (const double *)qS, nW, ns_pad, \
                       rowpart, colpart, (const XCtrl *)ctrl, NTB, NSB, m, (const xrp_t *)rp, (const int *)col, (const double *)val, (const double *)q, \
                       (const double *)sc, (const int *)nsrank, t
         if (split) {
             XSide &S = g_side; const int sl = (int)(S.seq++ % XT_SIDE_RING);
+            // Host-side failures between two collectives must not leave the peers in the all-reduce: the local part runs in `local`;
+            // if it fails, this rank still joins the all-reduce, with the abort word set, and every rank leaves the loop together.
+            auto local = [&]() -> int {
+            if (g_fault_phase == 2 && cur_it >= g_fault_iter) { g_fault_phase = 0; return dkmc_fail(91, "injected fault (CG iteration)", __FILE__, __LINE__); }
             if (ntb > 0) {
                 if (nt_loads) hipExtLaunchKernelGGL((k_xt_apply<1>), dim3(ntb), dim3(XT_NT), 0, st, e0, e1, 0, XT_APPLY_ARGS(X.item_n, ntb, 0), 2);
                 else hipExtLaunchKernelGGL((k_xt_apply<0>), dim3(ntb), dim3(XT_NT), 0, st, e0, e1, 0, XT_APPLY_ARGS(X.item_n, ntb, 0), 2);
@@ -1081,7 +1107,15 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
             hipLaunchKernelGGL((k_xt_rows<1>), dim3(std::max(nK, 1)), dim3(XT_NT), 0, st, ns, nK, nW, ns_pad, (const int2 *)wrange, (const int *)nitem_w, (const double *)rowpart,
                                (const double *)colpart, (const int *)srow, (const double *)sS, (const double *)p, t, part_pt, (const XCtrl *)ctrl, xbuf,
                                m, (const int *)nsrank, comm_rank() == 0 ? 1 : 0, (const double *)r, X.w_lo, X.w_hi);   // no partial arrays here: one workgroup per row block
-            if (int rcx = comm_allreduce_sum_f64(xbuf, (size_t)ns + 1)) return rcx;          // |S| row sums + rank 0's stop decision
+            KCHK();
+            return 0;
+            };
+            if (int lrc = local()) {
+                if (!local_fail) local_fail = lrc;
+                (void)hipGetLastError();
+                hipLaunchKernelGGL(k_xt_abort_word, dim3(1), dim3(1), 0, st, ctrl, xbuf, ns);
+            }
+            if (int rcx = comm_allreduce_sum_f64(xbuf, (size_t)ns + 2)) return rcx;          // |S| row sums + rank 0's stop decision + the abort word
             if (ec) HIPCHK(hipEventRecord(ec, st));
             HIPCHK(hipStreamWaitEvent(st, S.b[sl], 0));                                       // the neighbour sums are in t
             hipExtLaunchKernelGGL(k_xt_rows_apply, dim3(n2b), dim3(XT_NT), 0, st, e2, e3, 0, ns, nK, (const double *)xbuf, (const int *)srow, (const double *)sS,
@@ -1140,6 +1174,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         if (h.done || loop_rc) break;
         if (it >= 200000) { dkmc_fail(4, "CG: no convergence after 200000 iterations", __FILE__, __LINE__); break; }
         for (int b = 0; b < batch; ++b, ++it) {
+            cur_it = it;
             const bool pb = prof && b < 64 && (b % XT_PROF_STRIDE == 0);
             loop_rc = matvec(pb ? evs[4 * b] : nullptr, pb ? evs[4 * b + 1] : nullptr, pb ? evs[4 * b + 2] : nullptr, pb ? evs[4 * b + 3] : nullptr,
                              pb ? evc[b / XT_PROF_STRIDE] : nullptr);
@@ -1152,6 +1187,8 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         if (e.x_iter_hint > 24) batch = 8; else if (batch < 64) batch *= 2;
     }
     if (loop_rc) return loop_rc;
+    if (local_fail) return local_fail;                                                     // this rank failed between two collectives: the peers were told (abort word)
+    if (h.aborted) return dkmc_fail(46, "a peer rank aborted the sharded current solve", __FILE__, __LINE__);
     hipLaunchKernelGGL(k_xt_vec_mul, dim3(nbr), dim3(256), 0, st, m, y, (const double *)sc);
     KCHK();
     if (sharded) { rc = comm_bcast0_f64(y, (size_t)m); if (rc) return rc; }        // the solution every later phase starts from: rank 0's bits
@@ -1173,7 +1210,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
     }
     e.stats.X_nnz = xs_nnz + 2 * t_upper;
     e.stats.spmv_tiles = ntiles; e.stats.spmv_tile_entries = t_upper;
-    e.stats.xt_subblocks = X.nsub_total; e.stats.xt_local_subblocks = X.sub_n; e.stats.xt_items = nitems; e.stats.xt_kc = X.kc;
+    e.stats.xt_subblocks = X.nsub_total; e.stats.xt_local_subblocks = X.sub_n; e.stats.xt_items = X.nitems; e.stats.xt_kc = X.kc;
     e.stats.xt_sparse_nnz = xs_nnz; e.stats.xt_ns = ns;
     e.stats.spmv_segments = 0; e.stats.spmv_segment_entries = 0;
     e.stats.spmv_long_rows = ns; e.stats.spmv_short_rows = m - ns; e.stats.spmv_long_nnz = 2 * t_upper; e.stats.spmv_short_nnz = xs_nnz;

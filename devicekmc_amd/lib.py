@@ -92,6 +92,7 @@ SYMBOLS = {
                                            C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), c_dbl_p]),
     "dkmc_xt_time_share": (_I, [_I, _I, _I, c_dbl_p, c_dbl_p, c_int_p, C.POINTER(C.c_longlong)]),
     "dkmc_xt_check_shares": (_I, [_I, c_dbl_p, c_dbl_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), c_int_p]),
+    "dkmc_debug_inject_fault": (None, [_I, _I]),
     "dkmc_comm_unique_id": (_I, [C.c_char_p]),
     "dkmc_comm_init_rccl": (_I, [_I, _I, C.c_char_p]),
     "dkmc_comm_init_host": (_I, [_I, _I, ALLGATHER_FN, vp]),

@@ -267,6 +267,11 @@ int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_us, double 
  * the rank's windows) and compares the sum of the ranks' results with the one-GPU pass.  subblocks_sum / items_sum: totals over the
  * shares (must equal the stored sub-blocks / items_total: every tile in exactly one share). */
 int dkmc_xt_check_shares(int nranks, double *max_abs_diff, double *max_abs, long long *subblocks_sum, long long *items_sum, int *items_total);
+/* Test aid for the error path of a sharded current solve (no counterpart in the reference): the calling rank fails ONCE, in the
+ * assembly of X (phase 1) or on the host side of CG iteration `iteration` (phase 2).  Every rank's dkmc_update_power_gpu_sparse then
+ * returns non-zero (the failing rank its own code, the others 46) instead of blocking in a collective: the ranks agree on the
+ * outcome of the local set-up before the first collective, and inside the loop an abort word travels with every all-reduce. */
+void dkmc_debug_inject_fault(int phase, int iteration);
 
 /* ---- multi-GPU: one simulation advanced in lockstep by N processes, one GPU each (no reference counterpart) ----
  * While a communicator is attached, update_power_gpu_sparse generates, stores and streams the tunnelling block of X in per-rank

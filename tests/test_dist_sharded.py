@@ -116,6 +116,60 @@ def test_two_ranks_lockstep_bit_identical():
     assert abs(got0[3]["comm_local_segments"] - got1[3]["comm_local_segments"]) <= 64      # balanced up to one row
 
 
+def _fault_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    from devicekmc_amd import host, lib, parallel, params, structure
+    from devicekmc_amd.lib import DeviceKMCError
+    parallel.init("gloo")
+    torch.cuda.set_device(0)
+    assert parallel.attach_solver_comm() == "host"
+    L = lib.load()
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    s = structure.load_structure(os.path.join(g, "device_2.5nm.npz"))
+    p = params.KMCParameters(); p.solve_heating_global = True
+    dev = host.Device(s, p); sim = host.KMCProcess(dev, p.freq)
+    gb = dev.make_gpubuf("cuda:0")
+    dev.setLaplacePotential(gb, p, Vd); gb.sync_HostToGPU(dev)
+    seen = []
+    for phase, it in ((1, 0), (2, 5), (0, 0)):                  # fault in the assembly, fault on the host side of CG iteration 5, clean step
+        dev.updateCharge(gb); dev.updatePotential(gb, p, Vd, 0)
+        sim.executeKMCStep(gb, dev)
+        if rank == 1 and phase:
+            L.dkmc_debug_inject_fault(phase, it)
+        try:
+            dev.updatePower(gb, p, Vd)
+            seen.append((0, dev.imacro))
+        except DeviceKMCError as exc:
+            seen.append((1, str(exc)))
+            L.dkmc_clear_error()
+        parallel.barrier()
+    parallel.detach_solver_comm()
+    q.put((rank, seen))
+    parallel.finalize()
+
+
+def test_sharded_error_path_returns_on_every_rank():
+    """A rank-local failure inside a sharded current solve must not leave the peers blocked in a collective.  Rank 1 fails once in the
+    assembly of X (before the first collective: the ranks agree on the outcome of the set-up, comm_agree) and once on the host side of a
+    CG iteration (the abort word travels with the next all-reduce): both times BOTH ranks return an error from update_power -- the
+    failing rank its own, the peer "a peer rank ..." -- and the next, clean superstep runs on both and gives the same current."""
+    import __graft_entry__ as g
+    g.build()
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fault_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    out = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
+    for p in procs: p.join(60); assert p.exitcode == 0
+    (_, s0), (_, s1) = out
+    assert [k for k, _ in s0] == [1, 1, 0] and [k for k, _ in s1] == [1, 1, 0], (s0, s1)
+    assert "peer rank" in s0[0][1] and "injected fault (assembly" in s1[0][1]
+    assert "peer rank" in s0[1][1] and "injected fault (CG iteration" in s1[1][1]
+    assert s0[2][1] == s1[2][1] and s0[2][1] != 0.0
+
+
 def _solo_worker(rank, q, nsteps):
     import torch
     torch.cuda.set_device(0)

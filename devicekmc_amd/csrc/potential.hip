@@ -237,7 +237,7 @@ __global__ void k_charge_scatter(int N, const int *__restrict__ charge, const in
 
 #define PW_NT 256
 #define PW_SITES 64             // sites per workgroup: one per lane; the four waves split the charged list
-#define PW_CUT 6.5              // pairs with r / (sigma sqrt 2) beyond this are not evaluated: erfc(6.5) = 3.8e-20
+#define PW_CUT 6.5              // default of dkmc_set_pair_cutoff: pairs with r / (sigma sqrt 2) beyond this are not evaluated, erfc(6.5) = 3.8e-20
 // Each workgroup owns 64 sites; wave w adds the charged sites c = w, w + 4, ... of every LDS tile (all lanes of a wave read the
 // same list entry: an LDS broadcast), two independent accumulators per lane; the four partial sums of a site are combined in a
 // fixed order.  Four times the waves of a thread-per-site launch (85 k sites: 21 waves per CU instead of 5) and twice the
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(PW_NT) void k_pairwise(int N, const double *__restr
                                                     const double *__restrict__ z, const double *__restrict__ lattice, int pbc,
                                                     const double *__restrict__ sigma_p, const double *__restrict__ k_p,
                                                     const ChargedSite *__restrict__ list, const int *__restrict__ ncharged,
-                                                    double *__restrict__ out, unsigned long long *__restrict__ nevaluated, int i0)
+                                                    double *__restrict__ out, unsigned long long *__restrict__ nevaluated, int i0, double xcut)
 {
     __shared__ ChargedSite tile[PW_NT];
     __shared__ double partial[PW_NT / 64][PW_SITES];
@@ -273,8 +273,8 @@ __global__ __launch_bounds__(PW_NT) void k_pairwise(int N, const double *__restr
     const int i = i0 + blockIdx.x * PW_SITES + lane;               // sites [i0, N): all of them on one GPU, this rank's slab in a sharded run
     const int nc = *ncharged;
     const double sigma = *sigma_p, kk = *k_p, laty = lattice[1], latz = lattice[2];
-    const double rc = PW_CUT * sigma * sqrt(2.0) * 1e10;           // [A]
-    const double cut2 = rc * rc;
+    const double rc = xcut * sigma * sqrt(2.0) * 1e10;             // [A]; xcut = 0: every pair, as the reference sums (dkmc_set_pair_cutoff)
+    const double cut2 = xcut > 0.0 ? rc * rc : 1.0e300;
     const double xi = i < N ? x[i] : 0.0, yi = i < N ? y[i] : 0.0, zi = i < N ? z[i] : 0.0;
     double v0 = 0.0, v1 = 0.0;
     int neval = 0;
@@ -330,12 +330,12 @@ extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, 
         if (!xbuf) return e.err_code;
         const int lo = std::min(N, me * chunk), hi = std::min(N, lo + chunk);
         if (hi > lo)
-            hipLaunchKernelGGL(k_pairwise, dim3((hi - lo + PW_SITES - 1) / PW_SITES), dim3(PW_NT), 0, st, hi, x, y, z, lattice, pbc, sigma, k, list, cnt, xbuf, d_ne, lo);
+            hipLaunchKernelGGL(k_pairwise, dim3((hi - lo + PW_SITES - 1) / PW_SITES), dim3(PW_NT), 0, st, hi, x, y, z, lattice, pbc, sigma, k, list, cnt, xbuf, d_ne, lo, e.pair_cut);
         KCHK();
         rc = comm_allgather_f64(xbuf, (size_t)chunk); if (rc) return rc;
         HIPCHK(hipMemcpyAsync(out, xbuf, (size_t)N * 8, hipMemcpyDeviceToDevice, st));
     } else {
-        hipLaunchKernelGGL(k_pairwise, dim3((N + PW_SITES - 1) / PW_SITES), dim3(PW_NT), 0, st, N, x, y, z, lattice, pbc, sigma, k, list, cnt, out, d_ne, 0);
+        hipLaunchKernelGGL(k_pairwise, dim3((N + PW_SITES - 1) / PW_SITES), dim3(PW_NT), 0, st, N, x, y, z, lattice, pbc, sigma, k, list, cnt, out, d_ne, 0, e.pair_cut);
         KCHK();
     }
     e.stats.pair_ms = 0.0;

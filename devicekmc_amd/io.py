@@ -93,27 +93,28 @@ def write_host_bundle(path, structure, p, Vd, element, neigh, nn, layer):
 
 
 class StepLog:
-    """Accumulates the per-superstep block of output.txt (kmc_main.cpp:177-278)."""
+    """Accumulates the per-superstep block of output.txt (kmc_main.cpp:177-278), byte for byte: a step opens with 14 dashes and a newline
+    (:177) and closes with 38 dashes and NO newline (:278), so the next step's opening runs on in the same line -- the 52-dash lines of
+    the reference's logs (structures/single_devices/timing_7.5nm/output_noguess.txt)."""
 
     def __init__(self):
-        self.lines = []
+        self.buf = []
 
     def bias_header(self, Vd, folder):
-        self.lines += ["--------------------------------", "Applied Voltage = %s V" % _g6(Vd),
-                       "--------------------------------", "Created folder: " + folder]
+        self.buf.append("--------------------------------\nApplied Voltage = %s V\n--------------------------------\nCreated folder: %s\n" % (_g6(Vd), folder))
 
     def step(self, kmc_step_count, V_vcm, kmc_time, result_map, t_fields=None, t_log=None, t_superstep=None):
-        self.lines += ["--------------", "KMC step count: %d" % kmc_step_count, "V_vcm: %s" % _g6(V_vcm),
-                       "KMC time is: %s" % _g6(kmc_time)]
+        out = ["--------------\n", "KMC step count: %d\n" % kmc_step_count, "V_vcm: %s\n" % _g6(V_vcm), "KMC time is: %s\n" % _g6(kmc_time)]
         for key in sorted(result_map):                       # std::map iterates in key order
-            self.lines.append("%s: %s" % (key, _g6(result_map[key])))
+            out.append("%s: %s\n" % (key, _g6(result_map[key])))
         if t_fields is not None:
-            self.lines.append("Z - calculation time - all fields [s]: %s" % _g6(t_fields))
+            out.append("Z - calculation time - all fields [s]: %s\n" % _g6(t_fields))
         if t_log is not None:
-            self.lines.append("Z - calculation time - logging results [s]: %s" % _g6(t_log))
+            out.append("Z - calculation time - logging results [s]: %s\n" % _g6(t_log))
         if t_superstep is not None:
-            self.lines.append("Z - calculation time - KMC superstep [s]: %s" % _g6(t_superstep))
-        self.lines.append("--------------------------------------")
+            out.append("Z - calculation time - KMC superstep [s]: %s\n" % _g6(t_superstep))
+        out.append("--------------------------------------")
+        self.buf.append("".join(out))
 
     def text(self):
-        return "\n".join(self.lines) + "\n"
+        return "".join(self.buf)

@@ -58,6 +58,8 @@ SYMBOLS = {
     "dkmc_synchronize": (_I, []),
     "dkmc_set_cg_tolerance": (None, [_D]),
     "dkmc_set_cb_edge_domain": (None, [_I]),
+    "dkmc_set_x_loop": (None, [_I]),
+    "dkmc_set_pair_cutoff": (None, [_D]),
     "dkmc_set_current_warm_start": (None, [_I]),
     "dkmc_set_profiling": (None, [_I]),
     "dkmc_set_x_format": (None, [_I]),

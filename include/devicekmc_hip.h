@@ -116,6 +116,18 @@ void dkmc_set_cg_tolerance(double tol);
  * written by a revision that solved on atoms (its host twin still shows `gesv(.., &N_atom, ..)` as a comment, potential_solver.cpp:98):
  * with 1 they are reproduced to every entry / printed digit, with 0 the current is 0.83 % lower. */
 void dkmc_set_cb_edge_domain(int atoms_only);
+/* Screening cut-off of poisson_gridless_gpu.  A term of the pair sum is q erfc(x) k Q / r with x = r / (sigma sqrt 2); terms beyond
+ * x_cut are not evaluated.  Default 6.5 (erfc < 3.8e-20: all omitted terms of a 1e6-site stack together stay below 2e-17 V, under the
+ * rounding of the sum and under the last-bit noise of the reference's atomicAdd order).  0: every pair, exactly the terms the reference
+ * sums (potential_solver_gpu.cu:908-958) -- for a parity run. */
+void dkmc_set_pair_cutoff(double x_cut);
+/* CG loop of the current solve on the tiled X, single GPU.  0 (default): three launches per iteration (product, row sums + dots, vector
+ * step), which a sharded solve always uses.  1: two launches -- the matrix-vector product forms its vector on the fly (q = beta S p - S r)
+ * and emits the partials of p.Ap as a bilinear form; one kernel folds the tile partial sums into the S rows and does every vector
+ * update; both dot products are direct sums like the reference's.  Same algorithm (solve_sparse_CG_Jacobi, iterative_solvers_gpu.cu:
+ * 405-455), results equal to rounding.  Kept as a tested alternative: on MI355X it is SLOWER (85 071 sites, same box: 32.2 + 13.4 us
+ * per iteration against 24.0 + 6.3 + 5.4 us; the saved kernel boundary costs less than the longer dependent chains). */
+void dkmc_set_x_loop(int two_launch);
 /* 0 (default): warm-start the current solve from gpubuf.atom_virtual_potentials exactly as the
  * reference does (the buffer holds G0*m of the previous step, current_solver_gpu.cu:1015-1016);
  * 1: warm-start from a private unscaled copy of the previous solution. */

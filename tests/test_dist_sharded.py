@@ -110,7 +110,7 @@ def test_two_ranks_lockstep_bit_identical():
     tot = gt0[3]["xt_subblocks"]
     assert tot == gt1[3]["xt_subblocks"] > 0 and gt0[3]["xt_local_subblocks"] + gt1[3]["xt_local_subblocks"] == tot
     assert abs(gt0[3]["xt_local_subblocks"] - gt1[3]["xt_local_subblocks"]) <= 8 * 16          # balanced up to one work item
-    assert gt0[3]["comm_count_per_rank"] == gt0[3]["xt_ns"] + 1                                 # |S| row sums + the stop decision per all-reduce
+    assert gt0[3]["comm_count_per_rank"] == gt0[3]["xt_ns"] + 2                                 # |S| row sums + the stop decision + the abort word per all-reduce
     nseg = got0[3]["spmv_segments"]
     assert got0[3]["comm_local_segments"] + got1[3]["comm_local_segments"] == nseg > 0      # the ranks split the segments
     assert abs(got0[3]["comm_local_segments"] - got1[3]["comm_local_segments"]) <= 64      # balanced up to one row

@@ -137,8 +137,10 @@ def test_current_solve(pair_2p5, hip, golden_dir):
     assert abs(dev.imacro / oi - 1) <= 1e-7                                        # CG to 1e-10 on both sides
     pw = get(gb, "site_power")
     assert np.abs(pw - o.power).max() <= 1e-6 * np.abs(o.power).max()
-    # the reference's own sparsity dump (after the step-0 event), every row: identical except 60 entries (40 only in the dump, 20
-    # only here), all of them vacancy-vacancy pairs (the dump's revision used another energy for those: DESIGN.md section 2)
+    # the reference's own sparsity dump (after the step-0 event; needs test_event_table_and_loop_exact to have run on this fixture), every
+    # row: identical except 60 entries (40 only in the dump, 20 only here), all of them vacancy-vacancy pairs -- the dump's revision
+    # solved the CB edge on atoms only; with that domain the dump is reproduced entry for entry (test_x_pattern_dump_log_revision below,
+    # tests/test_oracle_golden.py)
     g = np.load(os.path.join(golden_dir, "x_pattern_2.5nm_step0.npz"))
     assert len(g["row_ptr"]) == len(rp)
     ael = X["ael"]
@@ -171,6 +173,22 @@ def test_current_solve(pair_2p5, hip, golden_dir):
     o.T_bg = 300.0
     To2 = o.update_temperature_global(1e-13, mode=1)
     assert abs(float(gb.T_bg.item()) - To2) <= 1e-9
+
+
+def test_x_pattern_dump_log_revision(cell_2p5, hip, golden_dir):
+    """The reference's own X-pattern dump (timing_2.5nm/fullmatrix_assembly, 467 336 entries, state after the first executed event), HIP
+    path under `log_revision()` (CB edge solved on atoms, CG 1e-12): row pointers and column indices IDENTICAL."""
+    from devicekmc_amd import params as pm
+    host, L = hip
+    g = np.load(os.path.join(golden_dir, "x_pattern_2.5nm_step0.npz"))
+    p = pm.KMCParameters().log_revision(); p.solve_heating_global = False
+    dev, sim, gb, _ = _fresh_device(cell_2p5, p, hip)
+    dev.updateCharge(gb); dev.updatePotential(gb, p, Vd, 0)
+    sim.executeKMCStep(gb, dev)
+    dev.updatePower(gb, p, Vd)
+    rp, ci, _ = host.get_last_X()
+    assert len(ci) == 467336 and np.array_equal(rp, g["row_ptr"]) and np.array_equal(ci, g["col_idx"])
+    L.dkmc_set_cb_edge_domain(0)
 
 
 def test_superstep_sequence_2p5(cell_2p5, hip, ref_logs):
@@ -691,6 +709,45 @@ def test_tiled_X_agrees_with_csr_X(dev_7p5, hip):
     n = min(len(a["m"]), len(b["m"]))
     assert np.abs(b["m"][:n] - a["m"][:n]).max() <= 1e-8 * np.abs(a["m"][:n]).max()
     assert np.abs(b["power"] - a["power"]).max() <= 1e-8 * np.abs(a["power"]).max()
+
+
+def test_two_launch_loop_agrees_with_three_launch_loop(dev_7p5, cell_2p5, hip):
+    """The two CG loops on the tiled X (dkmc_set_x_loop): two launches per iteration (direction formed on the fly inside the product,
+    p.Ap as a bilinear form of what the product holds, fold + vector step in one kernel; opt-in, measured slower) against three
+    (product, row sums + dots, vector step; the default).  Same algorithm: both solutions meet the stop test in the TRUE scaled residual of the
+    CSR matrix, agree to 1e-8 relative, and need the same number of iterations to within a few per cent (the three-launch loop forms
+    r'.r' by a recurrence, the two-launch loop by direct summation like the reference).  85 071 sites at 1e-10 and at the default 1e-6; the
+    2.5 nm device (few tiles, launch-bound); run-to-run bit identity of the two-launch loop."""
+    from devicekmc_amd import params as pm
+    host, L = hip
+    for structure, p0, tols in ((dev_7p5, params_7p5(), (1e-10, 1e-6)), (cell_2p5, pm.KMCParameters(), (1e-10,))):
+        L.dkmc_set_x_format(0)
+        p0.cg_tol = 1e-10; p0.solve_heating_global = False
+        dev, sim, gb, _ = _fresh_device(structure, p0, hip)
+        dev.updateCharge(gb); dev.updatePotential(gb, p0, Vd, 0); dev.updatePower(gb, p0, Vd)
+        rp, ci, data = host.get_last_X()
+        L.dkmc_set_x_format(1)
+        for tol in tols:
+            rec = {}
+            for loop in (0, 1, 1):
+                L.dkmc_set_x_loop(loop)
+                p0.cg_tol = tol
+                L.dkmc_set_cg_tolerance(tol)
+                put(gb, "atom_virtual_potentials", np.zeros(dev.N_atom + 2))
+                dev.updatePower(gb, p0, Vd)
+                st = host.get_stats()
+                cur = dict(m=get(gb, "atom_virtual_potentials").copy(), im=dev.imacro, iters=st["cg_iters_X"])
+                assert _scaled_residual(rp, ci, data, cur["m"], p0.G0, p0.X_loop_G) <= 10 * tol, (loop, tol, cur["iters"])
+                if loop == 1 and 1 in rec:
+                    assert np.array_equal(cur["m"], rec[1]["m"]) and cur["iters"] == rec[1]["iters"] and cur["im"] == rec[1]["im"]
+                rec[loop] = cur
+            L.dkmc_set_x_loop(0)
+            a, b = rec[0], rec[1]
+            assert abs(a["iters"] - b["iters"]) <= max(3, 0.06 * a["iters"]), (a["iters"], b["iters"])      # 790 vs 761 at 85 k sites, 1e-10 (the oracle: 760 ... 799)
+            if tol <= 1e-9:
+                assert abs(b["im"] / a["im"] - 1) <= 1e-8
+                n = min(len(a["m"]), len(b["m"]))
+                assert np.abs(b["m"][:n] - a["m"][:n]).max() <= 1e-8 * np.abs(a["m"][:n]).max()
 
 
 def test_default_tolerance_superstep_7p5(dev_7p5, hip):

@@ -37,6 +37,10 @@ def test_step_log_matches_reference_layout(ref_logs):
     assert t[5:9] == ["KMC step count: 0", "V_vcm: 5", "KMC time is: 2.05754e-14", "Current [uA]: 11.8834"]
     assert t[9] == "Z - calculation time - charge [s]: 0.000136599"
     assert t[13] == "Z - calculation time - potential from charges [s]: 0.000513108"
+    # a step closes with 38 dashes and no newline (kmc_main.cpp:278); the next step's 14 dashes (:177) run on in the same line
+    log.step(1, 5, 1.8113e-13, {"Current [uA]": 11.8869}, t_superstep=4.82018)
+    t = log.text().splitlines()
+    assert t[15] == "-" * 52 and t[16] == "KMC step count: 1" and log.text().endswith("-" * 38)
     # the parser used for the golden fixture reads it back
     assert float(t[7].split(":")[1]) == ref_logs["timing_7.5nm/output_noguess.txt"]["steps"][0]["KMC time"]
 

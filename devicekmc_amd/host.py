@@ -307,17 +307,22 @@ class KMCProcess:
         return {"Z - calculation time - kmc events [s]": time.perf_counter() - t0}, et.value
 
 
-def save_restart(path, device: Device, sim: KMCProcess, gpubuf: GPUBuffers, kmc_time=0.0, kmc_step_count=0):
+def save_restart(path, device: Device, sim: KMCProcess, gpubuf: GPUBuffers, kmc_time=0.0, kmc_step_count=0, current_warm_start=0):
     """Device::writeSnapshot (Device.cpp:236-252) + the state it drops (io.write_restart): after load_restart the run continues with
-    the same event sequence, bit for bit."""
+    the same event sequence, bit for bit.  That holds for the reference's start vector of the current solve (dkmc_set_current_warm_start(0):
+    gpubuf.atom_virtual_potentials, saved here).  Mode 1 keeps a private unscaled copy inside the library that the C ABI does not export:
+    a run in that mode states it (current_warm_start=1), and load_restart refuses the sidecar rather than continue on another iterate."""
     from . import io
+    if current_warm_start not in (0, 1):
+        raise ValueError("current_warm_start must be 0 or 1")
     gpubuf.sync_GPUToHost(device)
     state = dict(site_charge=device.site_charge, site_potential_boundary=device.site_potential_boundary,
                  site_potential_charge=device.site_potential_charge, site_power=device.site_power,
                  site_temperature=device.site_temperature, site_CB_edge=device.site_CB_edge,
                  atom_virtual_potentials=gpubuf.atom_virtual_potentials.cpu().numpy(),
                  T_bg=float(device.T_bg), kmc_time=float(kmc_time), kmc_step_count=int(kmc_step_count),
-                 rnd_seed_kmc=int(sim.random_generator.seed), kmc_rng_raw_draws=int(sim.random_generator.n_raw))
+                 rnd_seed_kmc=int(sim.random_generator.seed), kmc_rng_raw_draws=int(sim.random_generator.n_raw),
+                 current_warm_start=int(current_warm_start), N_atom_buffer=int(gpubuf.N_atom_))
     io.write_restart(path, device.site_element, device.site_x, device.site_y, device.site_z, state)
 
 
@@ -340,8 +345,17 @@ def load_restart(path, p: KMCParameters, device="cuda:0", gpu_neighbors=None):
         dev.site_CB_edge = np.asarray(state["site_CB_edge"], dtype=np.float64)
         dev.T_bg = float(state["T_bg"])
         gb.sync_HostToGPU(dev)
+        if int(state.get("current_warm_start", 0)) != 0:
+            raise ValueError("restart sidecar was written by a run with dkmc_set_current_warm_start(1): its private start vector is not in "
+                             "the sidecar, a bit-identical continuation is not possible")
+        # the start vector of the next current solve: entries [0, Na + 1) of the saved buffer are read (Na = atoms of the snapshot).  The
+        # buffer of the saved run was sized for ITS initial atom count, this one for the snapshot's: the used part must fit both.
         m = np.asarray(state["atom_virtual_potentials"], dtype=np.float64)
+        need = dev.N_atom + 1
+        if len(m) < need or gb.atom_virtual_potentials.numel() < need:
+            raise ValueError("restart sidecar holds %d virtual potentials, the snapshot needs %d" % (len(m), need))
         n = min(len(m), gb.atom_virtual_potentials.numel())
+        gb.atom_virtual_potentials.zero_()
         gb.atom_virtual_potentials[:n].copy_(torch.as_tensor(m[:n]))
         sim.random_generator = StdMT19937.at_position(int(state["rnd_seed_kmc"]), int(state["kmc_rng_raw_draws"]))
     return dev, sim, gb, state

@@ -90,6 +90,40 @@ def test_potential_fields(pair_2p5, hip):
     assert np.abs(res).max() <= 1e-9
 
 
+def test_pair_sum_all_pairs_switch(cell_2p5, hip):
+    """dkmc_set_pair_cutoff(0): every (site, charged site) pair is evaluated, exactly the terms the reference sums
+    (potential_solver_gpu.cu:908-958); the default screening cut-off (erfc < 3.8e-20 beyond 6.5 sigma sqrt 2) changes no potential by
+    more than 1e-15 of the largest one.  Randomised charges so that most sites see charged sites on both sides of the cut-off."""
+    from devicekmc_amd import params as pm
+    from devicekmc_amd.host import _ptr
+    from devicekmc_amd.lib import check
+    from oracle import oracle as oc
+    host, L = hip
+    p = pm.KMCParameters()
+    dev, sim, gb, o = make_pair(cell_2p5, p, hip)
+    rng = np.random.default_rng(11)
+    q = np.where(rng.random(dev.N) < 0.08, rng.choice([-2, 2], dev.N), 0).astype(np.int32)
+    put(gb, "site_charge", q); o.charge[:] = q
+    oc.lib().okmc_poisson_gridless(o.N, oc._p(o.x), oc._p(o.y), oc._p(o.z), oc._p(o.lattice), 0, C.c_double(p.sigma), C.c_double(p.k),
+                                   oc._p(o.charge), oc._p(o.pot_charge))
+    got = {}
+    try:
+        for cut in (0.0, 6.5):
+            L.dkmc_set_pair_cutoff(cut)
+            L.dkmc_set_profiling(1)
+            check(L.dkmc_poisson_gridless_gpu(0, 0, gb.N_, _ptr(gb.lattice), _ptr(gb.sigma), _ptr(gb.k), _ptr(gb.site_x), _ptr(gb.site_y),
+                                              _ptr(gb.site_z), _ptr(gb.site_charge), _ptr(gb.site_potential_charge)))
+            got[cut] = (get(gb, "site_potential_charge").copy(), host.get_stats()["pair_evaluated"])
+    finally:
+        L.dkmc_set_pair_cutoff(6.5); L.dkmc_set_profiling(0)
+    scale = np.abs(o.pot_charge).max()
+    nq = int((q != 0).sum())
+    assert got[0.0][1] == dev.N * nq - nq                                  # every pair but the self terms
+    assert 0 < got[6.5][1] < got[0.0][1]
+    assert np.abs(got[0.0][0] - o.pot_charge).max() <= 1e-12 * scale
+    assert np.abs(got[6.5][0] - got[0.0][0]).max() <= 1e-15 * scale
+
+
 def test_event_table_and_loop_exact(pair_2p5, hip):
     host, L = hip
     from devicekmc_amd.host import _ptr

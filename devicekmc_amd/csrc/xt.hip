@@ -39,7 +39,7 @@
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
 struct __attribute__((aligned(16))) XTile { int k, w; unsigned mask; int soff; };   // cell (k, w); present sub-blocks; first sub-block slot
-struct __attribute__((aligned(32))) XItem { int t0, t1, w, c, k0; unsigned mask0; int soff0, pad; };   // tiles [t0, t1) of strip w; c = position of the run in its strip; descriptor of tile t0
+struct __attribute__((aligned(32))) XItem { int t0, t1, w, c, k0; unsigned mask0; int soff0, pad; };   // tiles [t0, t1) of strip w; c = position of the run in its strip; descriptor of tile t0; pad = index of the run in the item list (= ioff[w] + c: its 256 column sums live at colpart[pad * 256])
 struct XCtrl { double rr[2]; int done_local, sharded; int done; int iters; int abort_local, aborted; int pad[2]; };
 // `done` (non-zero) gates every kernel of the loop; see k_xt_step for its iteration stamp.  Single GPU: set by the step kernel.  Sharded solve: the direction kernel only sets
 // done_local; rank 0's done_local travels in the all-reduced buffer (slot ns) and k_xt_rows_apply turns it into `done` on every
@@ -180,7 +180,7 @@ __global__ void k_xt_items(int nK, int nW, int kc, int ntiles, const int *__rest
     int o = MODE ? ioff[w] : 0, c = 0;
     for (int t = t0; t < t1; ++c) {
         const int len = xt_run_len(t, t1, kc, sp);
-        if (MODE) { const XTile f = tiles[t]; XItem it; it.t0 = t; it.t1 = t + len; it.w = w; it.c = c; it.k0 = f.k; it.mask0 = f.mask; it.soff0 = f.soff; it.pad = 0; items[o + c] = it; }
+        if (MODE) { const XTile f = tiles[t]; XItem it; it.t0 = t; it.t1 = t + len; it.w = w; it.c = c; it.k0 = f.k; it.mask0 = f.mask; it.soff0 = f.soff; it.pad = o + c; items[o + c] = it; }
         t += len;
     }
     if (!MODE) { nitem_w[w] = c; atomicMax(&sp->max_items_per_strip, c); }
@@ -372,7 +372,7 @@ __device__ __forceinline__ void xt_tile_role(const XItem it, const XTile *__rest
 #undef XT_LD
 #undef XT_SUBBLOCK
     if (rr == 0) {
-        double *cp = colpart + (size_t)it.c * ns_pad + (size_t)it.w * XT_C + 2 * cc;
+        double *cp = colpart + (size_t)it.pad * XT_C + 2 * cc;            // one 256-entry record per run, runs of a strip consecutive
 #pragma unroll
         for (int q = 0; q < 8; ++q) *reinterpret_cast<dbl2 *>(cp + XT_SBW * q) = *reinterpret_cast<const dbl2 *>(lcol + XT_SBW * q + 2 * cc);
     }
@@ -648,18 +648,24 @@ __device__ __forceinline__ int xt_row_block_runs(int k, const int *__restrict__ 
     const int wk = k / (XT_C / XT_R);
     return (wk >= w_lo && wk < w_hi) ? nitem_w[wk] : 0;
 }
+// index of the first run of row block k's strip in the item list (the exclusive scan of nitem_w sits behind it: xt_build_items)
+__device__ __forceinline__ int xt_row_block_cbase(int k, int nW, const int *__restrict__ nitem_w)
+{
+    return nitem_w[nW + 2 + k / (XT_C / XT_R)];
+}
 // wr = wrange[k], nc = xt_row_block_runs(k, ...): fetched by the caller, with whatever else starts its chain
-__device__ __forceinline__ double xt_row_block_sum(int k, int nW, int ns_pad, int2 wr, int nc,
+__device__ __forceinline__ double xt_row_block_sum(int k, int nW, int cbase, int2 wr, int nc,
                                                    const double *__restrict__ rowpart, const double *__restrict__ colpart, double (*sl_sum)[XT_R],
                                                    int w_lo, int w_hi)
 {
+    const int ns_pad = XT_C;                                          // distance between the records of consecutive runs of the strip
     const int r = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int s = XT_R * k + r;
     wr.x = max(wr.x, w_lo); wr.y = min(wr.y, w_hi);
     if (wr.x >= wr.y && nc == 0) return 0.0;                          // nothing of this row block on this rank (uniform over the workgroup)
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     const double *rpp = rowpart + (size_t)k * nW * XT_R + r;
-    const double *cpp = colpart + s;
+    const double *cpp = colpart + (size_t)cbase * XT_C + (s - XT_C * (k / (XT_C / XT_R)));
     int w = wr.x + sl, c = sl;
     // four independent loads in flight per list (the lists hold up to nK / 8 terms per slice)
     for (; c + 56 < nc; c += 64) {                                    // tapered shares end in strips of single-tile items: up to nK terms
@@ -735,7 +741,8 @@ __global__ __launch_bounds__(XT_NT) void k_xt_rows(int ns, int nK, int nW, int n
     }
     // ... and the extent of the first row block's partial lists: one dependent level less behind the flag
     int2 wr0 = make_int2(0, 0); int nc0 = 0;
-    if ((int)blockIdx.x < nK) { wr0 = wrange[blockIdx.x]; nc0 = xt_row_block_runs(blockIdx.x, nitem_w, w_lo, w_hi); }
+    int cb0 = 0;
+    if ((int)blockIdx.x < nK) { wr0 = wrange[blockIdx.x]; nc0 = xt_row_block_runs(blockIdx.x, nitem_w, w_lo, w_hi); cb0 = xt_row_block_cbase(blockIdx.x, nW, nitem_w); }
     if (ctrl) {
         if (threadIdx.x == 0) sdone = ctrl->done;
         __syncthreads();
@@ -743,7 +750,7 @@ __global__ __launch_bounds__(XT_NT) void k_xt_rows(int ns, int nK, int nW, int n
     }
     for (int k = blockIdx.x; k < nK; k += gridDim.x) {
         const bool own = k == (int)blockIdx.x;
-        const double sum = xt_row_block_sum(k, nW, ns_pad, own ? wr0 : wrange[k], own ? nc0 : xt_row_block_runs(k, nitem_w, w_lo, w_hi), rowpart, colpart, sl_sum, w_lo, w_hi);
+        const double sum = xt_row_block_sum(k, nW, own ? cb0 : xt_row_block_cbase(k, nW, nitem_w), own ? wr0 : wrange[k], own ? nc0 : xt_row_block_runs(k, nitem_w, w_lo, w_hi), rowpart, colpart, sl_sum, w_lo, w_hi);
         const int s = XT_R * k + (int)threadIdx.x;
         if (threadIdx.x < XT_R && s < ns) {
             if (MODE == 1) xout[s] = sum;
@@ -785,7 +792,8 @@ __global__ __launch_bounds__(XT_NT) void k_xt_fold_step(int ns, int nK, int nW, 
         if ((int)blockIdx.x < nK && threadIdx.x < XT_R && s < ns) { row0 = srow[s]; s0 = sS[s]; t0 = t[row0]; P0 = P[row0]; R0 = R[row0]; y0 = y[row0]; sc0 = sc[row0]; }
     }
     int2 wr0 = make_int2(0, 0); int nc0 = 0;
-    if ((int)blockIdx.x < nK) { wr0 = wrange[blockIdx.x]; nc0 = xt_row_block_runs(blockIdx.x, nitem_w, 0, nW); }
+    int cb0 = 0;
+    if ((int)blockIdx.x < nK) { wr0 = wrange[blockIdx.x]; nc0 = xt_row_block_runs(blockIdx.x, nitem_w, 0, nW); cb0 = xt_row_block_cbase(blockIdx.x, nW, nitem_w); }
     if (threadIdx.x < 64) {
         double beta, rr; bool stop;
         xt_iter_head(part_rr, it, n_cur, n_prev, tol2, beta, rr, stop, ctrl);
@@ -808,7 +816,7 @@ __global__ __launch_bounds__(XT_NT) void k_xt_fold_step(int ns, int nK, int nW, 
     }
     for (int k = blockIdx.x; k < nK; k += gridDim.x) {
         const bool own = k == (int)blockIdx.x;
-        const double sum = xt_row_block_sum(k, nW, ns_pad, own ? wr0 : wrange[k], own ? nc0 : xt_row_block_runs(k, nitem_w, 0, nW), rowpart, colpart, sl_sum, 0, nW);
+        const double sum = xt_row_block_sum(k, nW, own ? cb0 : xt_row_block_cbase(k, nW, nitem_w), own ? wr0 : wrange[k], own ? nc0 : xt_row_block_runs(k, nitem_w, 0, nW), rowpart, colpart, sl_sum, 0, nW);
         const int s = XT_R * k + (int)threadIdx.x;
         if (threadIdx.x < XT_R && s < ns) {
             if (own) { const double tv = s0 * (t0 + sum); XT_UPDATE(row0, P0, R0, y0, tv, sc0, s) }
@@ -1252,11 +1260,11 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         // ---- storage + fill ----
         tval = (double *)scratch(S_XT_TVAL, (size_t)(X.sub_n + 1) * XT_SUB * 8);
         rowpart = (double *)scratch(S_XT_ROWPART, (size_t)(ncell + 1) * XT_R * 8);
-        colpart = (double *)scratch(S_XT_COLPART, (size_t)X.maxchunk * ns_pad * 8);
+        colpart = (double *)scratch(S_XT_COLPART, (size_t)(X.nitems + 1) * XT_C * 8);       // one 256-entry record per run (32 MB at 9.4e5 sites; [run position][S rank] took 1.8 GB)
         d_cnt = (unsigned long long *)scratch(S_XT_CNT, 16);
         if (!tval || !rowpart || !colpart || !d_cnt) return e.err_code;
         HIPCHK(hipMemsetAsync(rowpart, 0, (size_t)(ncell + 1) * XT_R * 8, st));
-        HIPCHK(hipMemsetAsync(colpart, 0, (size_t)X.maxchunk * ns_pad * 8, st));
+        HIPCHK(hipMemsetAsync(colpart, 0, (size_t)(X.nitems + 1) * XT_C * 8, st));
         HIPCHK(hipMemsetAsync(d_cnt, 0, 16, st));
         if (X.tile_n > 0)
             hipLaunchKernelGGL(k_xt_fill, dim3(X.tile_n), dim3(XT_NT), 0, st, P, ns, (const XTile *)tiles + X.tile_lo, (int)X.sub_base, SN, TC, tval, d_cnt);
@@ -1518,9 +1526,9 @@ extern "C" int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_
     if (rc) return rc;
     const int item_n = sh.item_n, i0 = sh.item_lo;
     const XItem *items = sh.items; const int *nitem_w = sh.nitem_w;
-    double *colpart = (double *)scratch(S_XT_T_COLPART, (size_t)sh.maxchunk * ns_pad * 8);
+    double *colpart = (double *)scratch(S_XT_T_COLPART, (size_t)(sh.nitems + 1) * XT_C * 8);
     if (!colpart) return e.err_code;
-    HIPCHK(hipMemsetAsync(colpart, 0, (size_t)sh.maxchunk * ns_pad * 8, st));
+    HIPCHK(hipMemsetAsync(colpart, 0, (size_t)(sh.nitems + 1) * XT_C * 8, st));
     if (items_out) *items_out = item_n;
     if (subblocks_out) *subblocks_out = sh.sub_n;
     // scratch vectors of the last solve (their contents do not matter) + a private y and control block
@@ -1638,9 +1646,9 @@ extern "C" int dkmc_xt_check_shares(int nranks, double *max_abs_diff, double *ma
         if (rc) return rc;
         if (items_total) *items_total = sh.nitems;
         sb_sum += sh.sub_n; it_sum += sh.item_n;
-        double *colpart = (double *)scratch(S_XT_T_COLPART, (size_t)sh.maxchunk * ns_pad * 8);
+        double *colpart = (double *)scratch(S_XT_T_COLPART, (size_t)(sh.nitems + 1) * XT_C * 8);
         if (!colpart) return e.err_code;
-        HIPCHK(hipMemsetAsync(colpart, 0, (size_t)sh.maxchunk * ns_pad * 8, st));      // what a rank's assembly does: cells of tiles it does not own stay zero
+        HIPCHK(hipMemsetAsync(colpart, 0, (size_t)(sh.nitems + 1) * XT_C * 8, st));      // what a rank's assembly does: cells of tiles it does not own stay zero
         HIPCHK(hipMemsetAsync(g_xb.rowpart, 0, rowpart_bytes, st));
         if (sh.item_n > 0)
             hipLaunchKernelGGL((k_xt_tiles_only<0>), dim3((sh.item_n + 3) / 4), dim3(XT_NT), 0, st, sh.item_n, (const XItem *)sh.items + sh.item_lo,

@@ -177,6 +177,7 @@ class Device:
         n = p.num_atoms_first_layer
         gpubuf.sync_HostToGPU(self)
         _use_stream(gpubuf.dev)
+        _lib.load().dkmc_set_cg_tolerance(p.cg_tol)            # the parameters are authoritative for every solve (the engine's tolerance is process-wide)
         _lib.load().dkmc_set_cb_edge_domain(1 if p.cb_edge_domain == "atoms" else 0)
         check(_lib.load().dkmc_update_CB_edge_gpu_sparse(C.byref(gpubuf.c), self.N, n, n, Vd, int(self.pbc), p.high_G, p.low_G,
                                                          self.nn_dist, len(p.metals)))
@@ -195,6 +196,7 @@ class Device:
         L = _lib.load()
         n = p.num_atoms_first_layer
         _use_stream(gpubuf.dev)
+        L.dkmc_set_cg_tolerance(p.cg_tol)
         t0 = time.perf_counter()
         check(L.dkmc_background_potential_gpu_sparse(C.byref(gpubuf.c), self.N, n, n, Vd, int(self.pbc), p.high_G, p.low_G,
                                                      self.nn_dist, len(p.metals), kmc_step_count))
@@ -216,6 +218,7 @@ class Device:
         _use_stream(gpubuf.dev)
         imacro = C.c_double(0.0)
         n = p.num_atoms_first_layer
+        _lib.load().dkmc_set_cg_tolerance(p.cg_tol)
         check(_lib.load().dkmc_update_power_gpu_sparse(C.byref(gpubuf.c), n, n, p.num_layers_contact, Vd, int(self.pbc),
                                                        p.X_high_G, p.X_low_G, p.X_loop_G, p.G0, p.X_tol, self.nn_dist, p.m_e, p.V0,
                                                        len(p.metals), C.byref(imacro), int(p.solve_heating_local),

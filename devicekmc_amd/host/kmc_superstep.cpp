@@ -98,6 +98,15 @@ int main(int argc, char **argv)
         printf("TIMING steps=%d seconds=%.6f\n", steps, sec);
         gpubuf.sync_GPUToHost(dev);
     }
+    // the split entry point of the reference's header (gpu_solvers.h:167-172; its call is commented out at current_solver.cpp:32-35):
+    // same state, once through each name
+    double I_sparse = 0.0, I_split = 0.0;
+    if (argc <= 4) {
+        update_power_gpu_sparse(h, h, gpubuf, n_first, n_first, n_lay_contact, Vd, pbc, X_high_G, X_low_G, X_loop_G, G0, tol, nn_dist, m_e, V0,
+                                (int)metals.size(), &I_sparse, false, false, 1.0);
+        update_power_gpu_split(h, h, gpubuf, n_first, n_first, n_lay_contact, Vd, pbc, X_high_G, X_low_G, X_loop_G, G0, tol, nn_dist, m_e, V0,
+                               (int)metals.size(), &I_split, false, false, 1.0);
+    }
     const double next_u = rng.getRandomNumber();       // proves the stream position
     f = fopen(argv[2], "wb");
     if (!f) { perror(argv[2]); return 1; }
@@ -105,6 +114,7 @@ int main(int argc, char **argv)
     for (int i = 0; i < N; ++i) el[i] = (int)dev.site_element[i];
     wr(f, el.data(), N); wr(f, dev.site_charge.data(), N);
     wr(f, dev.site_potential_boundary.data(), N); wr(f, dev.site_potential_charge.data(), N);
+    wr(f, &I_sparse, 1); wr(f, &I_split, 1);
     fclose(f);
     gpubuf.freeGPUmemory();
     return 0;

@@ -63,6 +63,7 @@ SYMBOLS = {
     "dkmc_set_current_warm_start": (None, [_I]),
     "dkmc_set_profiling": (None, [_I]),
     "dkmc_set_x_format": (None, [_I]),
+    "dkmc_get_x_format": (_I, []),
     "dkmc_gpubuf_create": (_I, [C.POINTER(dkmc_gpubuf), _I, _I, _I, _I, vp, vp, vp, vp, vp, vp, _D, _D, _D, vp]),
     "dkmc_gpubuf_free": (_I, [C.POINTER(dkmc_gpubuf)]),
     "dkmc_gpubuf_sync_host_to_gpu": (_I, [C.POINTER(dkmc_gpubuf), vp, vp, vp, vp, vp, vp, vp, vp, _D]),

@@ -141,6 +141,7 @@ void dkmc_set_profiling(int on);
  * (Assemble_X_sparsity / Assemble_X2), solved by reading every stored entry; both agree to rounding.  dkmc_get_last_X
  * returns the same column-sorted CSR in both modes. */
 void dkmc_set_x_format(int tiled);
+int dkmc_get_x_format(void);
 
 /* ---- GPUBuffers (gpu_buffers.h:73-158, gpu_buffers.cpp:10-118) ---------------------------- */
 /* allocates every array of the struct with hipMalloc and uploads the constant ones */

@@ -7,8 +7,8 @@
  *   - execute_kmc_step_gpu draws its random numbers in batches: it copies the generator, hands a batch of numbers
  *     to the device loop, then advances the caller's generator by exactly the 2 numbers per executed event the
  *     reference would have drawn (kmc_events.cu:221,348), so the stream position afterwards is identical;
- *   - dense / split variants (background_potential_gpu, update_power_gpu, update_power_gpu_split) are not provided:
- *     they are unreachable in the reference (potential_solver.cpp:238, current_solver.cpp:21 hard-code the sparse path).
+ *   - the dense variants (background_potential_gpu, update_power_gpu) are not provided: they are unreachable in the reference
+ *     (potential_solver.cpp:238, current_solver.cpp:21 hard-code the sparse path); update_power_gpu_split IS provided (below).
  */
 #pragma once
 #include <vector>
@@ -111,6 +111,24 @@ DKMC_SHIM_API void update_power_gpu_sparse(dkmc_handle_t, dkmc_handle_t, GPUBuff
 {
     GPUBuffers::report(dkmc_update_power_gpu_sparse(&gpubuf, num_source_inj, num_ground_ext, num_layers_contact, Vd, pbc, high_G, low_G, loop_G,
                                                     G0, tol, nn_dist, m_e, V0, num_metals, imacro, solve_heating_local, solve_heating_global, alpha_disp));
+}
+
+// update_power_gpu_split (gpu_solvers.h:167-172 of the reference; current_solver_gpu.cu:475-776): "mixed sparse neighbor matrix + dense
+// tunneling submatrix".  In the reference the call is commented out (current_solver.cpp:32-35) and its solver ends in exit(1)
+// (iterative_solvers_gpu.cu:656-821).  Here the split form IS the default layout of X -- neighbour part as a small CSR, tunnelling block
+// as symmetric tiles (csrc/xt.hip) -- so the entry point is provided with the reference's argument list: it forces that layout for the
+// call and restores the caller's dkmc_set_x_format afterwards.  Same results as update_power_gpu_sparse.
+DKMC_SHIM_API void update_power_gpu_split(dkmc_handle_t, dkmc_handle_t, GPUBuffers &gpubuf, const int num_source_inj, const int num_ground_ext,
+                                   const int num_layers_contact, const double Vd, const int pbc, const double high_G, const double low_G,
+                                   const double loop_G, const double G0, const double tol, const double nn_dist, const double m_e,
+                                   const double V0, int num_metals, double *imacro, const bool solve_heating_local,
+                                   const bool solve_heating_global, const double alpha_disp)
+{
+    const int fmt = dkmc_get_x_format();
+    dkmc_set_x_format(1);
+    GPUBuffers::report(dkmc_update_power_gpu_sparse(&gpubuf, num_source_inj, num_ground_ext, num_layers_contact, Vd, pbc, high_G, low_G, loop_G,
+                                                    G0, tol, nn_dist, m_e, V0, num_metals, imacro, solve_heating_local, solve_heating_global, alpha_disp));
+    dkmc_set_x_format(fmt);
 }
 
 DKMC_SHIM_API void update_temperatureglobal_gpu(const double *site_power, double *T_bg, const int N, const double a_coeff, const double b_coeff,

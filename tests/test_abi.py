@@ -60,5 +60,5 @@ def test_shim_library_exports_the_reference_names():
     names = {l.split()[-1] for l in out.splitlines() if l.strip()}
     for n in ("get_gpu_info", "set_gpu", "copytoConstMemory", "initialize_sparsity", "update_CB_edge_gpu_sparse", "update_charge_gpu",
               "background_potential_gpu_sparse", "poisson_gridless_gpu", "solve_sparse_CG_Jacobi", "execute_kmc_step_gpu",
-              "update_power_gpu_sparse", "update_temperatureglobal_gpu"):
+              "update_power_gpu_sparse", "update_power_gpu_split", "update_temperatureglobal_gpu"):
         assert n in names, n

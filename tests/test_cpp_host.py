@@ -34,6 +34,7 @@ def test_cpp_driver_matches_oracle(cell_2p5, tmp_path):
     dt, I, T, next_u = take(np.float64, steps), take(np.float64, steps), take(np.float64, steps), take(np.float64, 1)[0]
     el, q = take(np.int32, N), take(np.int32, N)
     pb, pc = take(np.float64, N), take(np.float64, N)
+    I_sparse, I_split = take(np.float64, 1)[0], take(np.float64, 1)[0]
     o = oc.OracleKMC(cell_2p5.element, cell_2p5.x, cell_2p5.y, cell_2p5.z, p)
     o.set_laplace_potential(Vd)
     for k in range(steps):
@@ -44,3 +45,5 @@ def test_cpp_driver_matches_oracle(cell_2p5, tmp_path):
     assert np.array_equal(el, o.element) and np.array_equal(q, o.charge)      # same events executed
     assert next_u == o.rng_kmc.uniform()                                       # caller's RNG left where the reference leaves it
     assert np.abs(pc - o.pot_charge).max() <= 1e-12 * np.abs(o.pot_charge).max()
+    # update_power_gpu_split (declared by the reference, gpu_solvers.h:167-172) on the final state agrees with update_power_gpu_sparse
+    assert I_sparse > 0 and abs(I_split / I_sparse - 1) <= 1e-4 and abs(I_sparse / I[-1] - 1) <= 1e-3

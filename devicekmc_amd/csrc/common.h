@@ -133,7 +133,7 @@ inline MetalSet load_metals(const int *d_metals, int num_metals) { MetalSet ms; 
 enum {
     S_CG_S = 0, S_CG_R, S_CG_P, S_CG_T, S_CG_PART, S_CG_CTRL, S_CG_RUNS, S_CG_REM, S_CG_NRUNS, S_CG_PS, S_CG_SEGOFF, S_CG_SEGS, S_CG_SEGPART, S_CG_XCHG, S_CG_PARTS,
     S_K_DATA, S_K_RHS,
-    S_PW_LIST, S_PW_CNT,
+    S_PW_LIST, S_PW_CNT, S_PW_CELLS, S_PW_PERM, S_PW_LIST2,
     S_EV_PROB, S_EV_ROWSUM, S_EV_G2, S_EV_G3, S_EV_CTRL, S_EV_UNI, S_EV_LOG,
     S_SCAN_TMP, S_SCAN_TMP2, S_SCAN_OFF64, S_SCAN_INTILE,
     S_AT_FLAG, S_AT_SITE, S_AT_OFSITE, S_AT_NEIGH,

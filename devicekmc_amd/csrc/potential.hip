@@ -265,8 +265,10 @@ __global__ __launch_bounds__(PW_NT) void k_pairwise(int N, const double *__restr
                                                     const double *__restrict__ z, const double *__restrict__ lattice, int pbc,
                                                     const double *__restrict__ sigma_p, const double *__restrict__ k_p,
                                                     const ChargedSite *__restrict__ list, const int *__restrict__ ncharged,
-                                                    double *__restrict__ out, unsigned long long *__restrict__ nevaluated, int i0, double xcut)
+                                                    double *__restrict__ out, unsigned long long *__restrict__ nevaluated, int i0, double xcut,
+                                                    const int *__restrict__ cells_in_use)
 {
+    if (*cells_in_use) return;                                     // the cell-list kernel (k_pairwise_cells, below) does this call
     __shared__ ChargedSite tile[PW_NT];
     __shared__ double partial[PW_NT / 64][PW_SITES];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(PW_NT) void k_pairwise(int N, const double *__restr
     const double cut2 = xcut > 0.0 ? rc * rc : 1.0e300;
     const double xi = i < N ? x[i] : 0.0, yi = i < N ? y[i] : 0.0, zi = i < N ? z[i] : 0.0;
     double v0 = 0.0, v1 = 0.0;
-    int neval = 0;
+    int neval = 0, ntest = 0;
     for (int base = 0; base < nc; base += PW_NT) {
         const int n = min(PW_NT, nc - base);
         __syncthreads();
@@ -285,6 +287,7 @@ __global__ __launch_bounds__(PW_NT) void k_pairwise(int N, const double *__restr
         __syncthreads();
         if (i < N) {
             int c = w;
+            ntest += (n - w + 3) / 4;                                // entries w, w + 4, ... of this tile
             for (; c + 4 < n; c += 8) {
                 v0 += pw_term(xi, yi, zi, tile[c], i, laty, latz, pbc, sigma, kk, cut2, neval);
                 v1 += pw_term(xi, yi, zi, tile[c + 4], i, laty, latz, pbc, sigma, kk, cut2, neval);
@@ -293,10 +296,208 @@ __global__ __launch_bounds__(PW_NT) void k_pairwise(int N, const double *__restr
         }
     }
     partial[w][lane] = v0 + v1;
-    neval = wave_sum_all_i(neval);
+    neval = wave_sum_all_i(neval); ntest = wave_sum_all_i(ntest);
     if (lane == 0 && neval) atomicAdd(nevaluated, (unsigned long long)neval);
+    if (lane == 0 && ntest) atomicAdd(nevaluated + 1, (unsigned long long)ntest);
     __syncthreads();
     if (w == 0 && i < N) out[i] = (partial[0][lane] + partial[1][lane]) + (partial[2][lane] + partial[3][lane]);
+}
+
+// ---- pair sum over a cell list of the charged sites ---------------------------------------------------------------------------
+// With the screening cut-off on, a site only needs the charged sites within rc = x_cut sigma sqrt 2 (32 A).  The charged sites (all
+// of them lie in the oxide: one cell in x) are binned into (y, z) columns of edge >= rc; a site sums over the 3 x 3 columns around its
+// own.  Workgroups own 64 sites OF ONE COLUMN (sites grouped by column through a permutation; their order inside a column does not
+// matter, every site is summed independently), so the four waves still sweep one LDS tile with broadcast reads, now over ~9 / (ny nz)
+// of the list.  Determinism: the charged sites of a column keep their ascending site order (a stable, atomic-free partition: one
+// workgroup per column walks the compacted list), columns are visited in a fixed order, the four partial sums are combined as before.
+// 9.4e5 sites (8 x 8 columns): 1.8 % of all pairs are inside the cut-off; the all-list kernel tests 7.9e9 distances, this one ~1.1e9.
+// Everything that depends on the lattice is decided on the device (no host read of the box per call): the kernels of the path not taken
+// find `use` cleared and return.
+#define PW_MAXDIM 32
+#define PW_MAXCELL (PW_MAXDIM * PW_MAXDIM)
+#define PW_MIN_CHARGED 512
+struct PwGrid { int use, ny, nz, pbc; double hy, hz, ly, lz; int nchunks, rebuild; };
+__device__ __forceinline__ int pw_axis_cell(double v, double L, double h, int n, int pbc)
+{
+    if (pbc) { double f = v / L; f -= floor(f); return min((int)(f * n), n - 1); }
+    return min(max((int)floor(v / h), 0), n - 1);              // clamping is monotone: points within h of each other stay in adjacent cells
+}
+// The grid of this call.  The grouping of the SITES by column depends only on positions, box and cut-off, which do not change between
+// calls: it is rebuilt when the host sees other position arrays / N / pbc / cut-off (host_rebuild) or when the box or sigma read here
+// differ from those of the cached grouping; otherwise only the charged sites are binned per call.
+__global__ void k_pw_grid(const double *__restrict__ lattice, const double *__restrict__ sigma_p, double xcut, int pbc, const int *__restrict__ ncharged,
+                          PwGrid *g, int *__restrict__ tcount, int *__restrict__ ccount, int *__restrict__ cursor, int host_rebuild)
+{
+    __shared__ int rebuild_s;
+    const int t = threadIdx.x;
+    if (t == 0) {
+        const double rc = xcut * *sigma_p * sqrt(2.0) * 1e10;
+        const PwGrid old = *g;
+        PwGrid G{};
+        G.pbc = pbc; G.ly = lattice[1]; G.lz = lattice[2];
+        G.ny = xcut > 0.0 ? max(1, min(PW_MAXDIM, (int)floor(G.ly / rc))) : 1;
+        G.nz = xcut > 0.0 ? max(1, min(PW_MAXDIM, (int)floor(G.lz / rc))) : 1;
+        G.hy = G.ly / G.ny; G.hz = G.lz / G.nz;
+        G.use = xcut > 0.0 && (G.ny >= 3 || G.nz >= 3) && *ncharged >= PW_MIN_CHARGED;
+        G.rebuild = host_rebuild || old.ny != G.ny || old.nz != G.nz || old.pbc != G.pbc || old.ly != G.ly || old.lz != G.lz;
+        G.nchunks = G.rebuild ? 0 : old.nchunks;
+        *g = G;
+        rebuild_s = G.rebuild;
+    }
+    __syncthreads();
+    for (int i = t; i <= PW_MAXCELL; i += blockDim.x) { ccount[i] = 0; if (rebuild_s) { tcount[i] = 0; cursor[i] = 0; } }
+}
+// column of every charged site (every call) and of every site (rebuild only); counts through an LDS histogram per workgroup, then one
+// global integer atomic per (workgroup, occupied column): the counts do not depend on any order
+__global__ __launch_bounds__(256) void k_pw_bin(int N, const double *__restrict__ y, const double *__restrict__ z, const PwGrid *__restrict__ g,
+                                                const ChargedSite *__restrict__ list, const int *__restrict__ ncharged, int *__restrict__ site_cell,
+                                                int *__restrict__ ccell, int *__restrict__ tcount, int *__restrict__ ccount)
+{
+    const PwGrid G = *g;
+    const int nc = *ncharged;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nc) {                                                 // charged sites: few (1 % of the sites), plain atomics
+        const ChargedSite cs = list[i];
+        const int c = pw_axis_cell(cs.z, G.lz, G.hz, G.nz, G.pbc) * G.ny + pw_axis_cell(cs.y, G.ly, G.hy, G.ny, G.pbc);
+        ccell[i] = c; atomicAdd(&ccount[c], 1);
+    }
+    if (!G.rebuild) return;
+    __shared__ int hist[PW_MAXCELL];
+    const int ncell = G.ny * G.nz;
+    for (int k = threadIdx.x; k < ncell; k += 256) hist[k] = 0;
+    __syncthreads();
+    if (i < N) {
+        const int c = pw_axis_cell(z[i], G.lz, G.hz, G.nz, G.pbc) * G.ny + pw_axis_cell(y[i], G.ly, G.hy, G.ny, G.pbc);
+        site_cell[i] = c; atomicAdd(&hist[c], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < ncell; k += 256) if (hist[k]) atomicAdd(&tcount[k], hist[k]);
+}
+// prefix sums over the (at most 1024) columns: cstart every call; tstart and the first chunk of 64 sites of every column on a rebuild
+__global__ __launch_bounds__(PW_MAXCELL) void k_pw_offsets(PwGrid *g, const int *__restrict__ tcount, const int *__restrict__ ccount, int *__restrict__ tstart,
+                                                          int *__restrict__ cstart, int *__restrict__ chunk0)
+{
+    __shared__ int a[PW_MAXCELL], b[PW_MAXCELL], c[PW_MAXCELL];
+    const int t = threadIdx.x, n = g->ny * g->nz, rebuild = g->rebuild;
+    a[t] = t < n ? tcount[t] : 0; b[t] = t < n ? ccount[t] : 0; c[t] = t < n ? (tcount[t] + PW_SITES - 1) / PW_SITES : 0;
+    __syncthreads();
+    for (int off = 1; off < PW_MAXCELL; off <<= 1) {                 // inclusive scans (Hillis-Steele; 1024 entries)
+        const int va = t >= off ? a[t - off] : 0, vb = t >= off ? b[t - off] : 0, vc = t >= off ? c[t - off] : 0;
+        __syncthreads();
+        a[t] += va; b[t] += vb; c[t] += vc;
+        __syncthreads();
+    }
+    if (t < n) { cstart[t + 1] = b[t]; if (rebuild) { tstart[t + 1] = a[t]; chunk0[t + 1] = c[t]; } }
+    if (t == 0) { cstart[0] = 0; if (rebuild) { tstart[0] = 0; chunk0[0] = 0; g->nchunks = c[n - 1]; } }
+}
+// sites grouped by column (any order inside a column): a workgroup reserves one range per occupied column, ranks inside it from LDS
+__global__ __launch_bounds__(256) void k_pw_perm(int N, const PwGrid *__restrict__ g, const int *__restrict__ site_cell, const int *__restrict__ tstart,
+                                                 int *__restrict__ cursor, int *__restrict__ perm)
+{
+    if (!g->rebuild) return;
+    __shared__ int hist[PW_MAXCELL], base[PW_MAXCELL];
+    const int ncell = g->ny * g->nz;
+    for (int k = threadIdx.x; k < ncell; k += 256) hist[k] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int c = -1, r = 0;
+    if (i < N) { c = site_cell[i]; r = atomicAdd(&hist[c], 1); }
+    __syncthreads();
+    for (int k = threadIdx.x; k < ncell; k += 256) if (hist[k]) base[k] = tstart[k] + atomicAdd(&cursor[k], hist[k]);
+    __syncthreads();
+    if (c >= 0) perm[base[c] + r] = i;
+}
+// charged sites grouped by column, ascending site order kept: workgroup = column, a stable partition of the compacted list
+__global__ __launch_bounds__(256) void k_pw_partition(const PwGrid *__restrict__ g, const ChargedSite *__restrict__ list, const int *__restrict__ ncharged,
+                                                      const int *__restrict__ ccell, const int *__restrict__ cstart, ChargedSite *__restrict__ out)
+{
+    if (!g->use) return;
+    const int c = blockIdx.x;
+    if (c >= g->ny * g->nz) return;
+    __shared__ int wcnt[4];
+    __shared__ int base_s;
+    const int nc = *ncharged, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = cstart[c];
+    __syncthreads();
+    for (int b0 = 0; b0 < nc; b0 += 256) {
+        const int i = b0 + threadIdx.x;
+        const bool mine = i < nc && ccell[i] == c;
+        const unsigned long long bal = __ballot(mine);
+        if (lane == 0) wcnt[w] = __popcll(bal);
+        __syncthreads();
+        int off = base_s;
+        for (int u = 0; u < w; ++u) off += wcnt[u];
+        if (mine) out[off + __popcll(bal & ((1ull << lane) - 1ull))] = list[i];
+        __syncthreads();
+        if (threadIdx.x == 0) base_s += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+    }
+}
+// the sum itself: block -> (column, chunk of 64 of its sites); columns cy-1..cy+1 x cz-1..cz+1 in a fixed order
+__global__ __launch_bounds__(PW_NT) void k_pairwise_cells(int N, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
+                                                          int pbc, const double *__restrict__ sigma_p, const double *__restrict__ k_p,
+                                                          const PwGrid *__restrict__ g, const int *__restrict__ tstart, const int *__restrict__ cstart,
+                                                          const int *__restrict__ chunk0, const int *__restrict__ perm, const ChargedSite *__restrict__ clist,
+                                                          double *__restrict__ out, unsigned long long *__restrict__ nevaluated, int i_lo, int i_hi, double xcut)
+{
+    if (!g->use) return;
+    const PwGrid G = *g;
+    if ((int)blockIdx.x >= G.nchunks) return;
+    __shared__ ChargedSite tile[PW_NT];
+    __shared__ double partial[PW_NT / 64][PW_SITES];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int ncell = G.ny * G.nz;
+    int lo = 0, hi = ncell;                                           // column of this chunk: last c with chunk0[c] <= blockIdx.x
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
+    const int c = lo, cy = c % G.ny, cz = c / G.ny;
+    const int t = tstart[c] + ((int)blockIdx.x - chunk0[c]) * PW_SITES + lane;
+    int i = t < tstart[c + 1] ? perm[t] : -1;
+    if (i >= 0 && (i < i_lo || i >= i_hi)) i = -1;                     // sharded run: this rank's slab of sites only
+    const double sigma = *sigma_p, kk = *k_p;
+    const double rc = xcut * sigma * sqrt(2.0) * 1e10, cut2 = rc * rc;
+    const double xi = i >= 0 ? x[i] : 0.0, yi = i >= 0 ? y[i] : 0.0, zi = i >= 0 ? z[i] : 0.0;
+    double v0 = 0.0, v1 = 0.0;
+    int neval = 0, ntest = 0;
+    // offsets along an axis with n columns: all three when n >= 3; with two columns -1 and +1 are the same column under pbc
+    const int dy0 = G.ny >= 2 ? ((G.ny == 2 && pbc) ? 0 : -1) : 0, dy1 = G.ny >= 2 ? 1 : 0;
+    const int dz0 = G.nz >= 2 ? ((G.nz == 2 && pbc) ? 0 : -1) : 0, dz1 = G.nz >= 2 ? 1 : 0;
+    for (int dz = dz0; dz <= dz1; ++dz) {
+        int nz_ = cz + dz;
+        if (pbc) nz_ = (nz_ + G.nz) % G.nz; else if (nz_ < 0 || nz_ >= G.nz) continue;
+        // the columns cy + dy0 .. cy + dy1 of one z row are neighbours in the list (cell = cz ny + cy): one segment unless pbc wraps them
+        int seg_lo[3], seg_hi[3], nseg = 0;
+        for (int dy = dy0; dy <= dy1; ++dy) {
+            int ny_ = cy + dy;
+            if (pbc) ny_ = (ny_ + G.ny) % G.ny; else if (ny_ < 0 || ny_ >= G.ny) continue;
+            const int cc = nz_ * G.ny + ny_;
+            const int s0 = cstart[cc], s1 = cstart[cc + 1];
+            if (nseg > 0 && seg_hi[nseg - 1] == s0) seg_hi[nseg - 1] = s1; else { seg_lo[nseg] = s0; seg_hi[nseg] = s1; ++nseg; }
+        }
+        for (int sg = 0; sg < nseg; ++sg) {
+            const int s0 = seg_lo[sg], s1 = seg_hi[sg];
+            for (int base = s0; base < s1; base += PW_NT) {
+                const int n = min(PW_NT, s1 - base);
+                __syncthreads();
+                if ((int)threadIdx.x < n) tile[threadIdx.x] = clist[base + threadIdx.x];
+                __syncthreads();
+                if (i >= 0) {
+                    int q = w;
+                    ntest += (n - w + 3) / 4;
+                    for (; q + 4 < n; q += 8) {
+                        v0 += pw_term(xi, yi, zi, tile[q], i, G.ly, G.lz, pbc, sigma, kk, cut2, neval);
+                        v1 += pw_term(xi, yi, zi, tile[q + 4], i, G.ly, G.lz, pbc, sigma, kk, cut2, neval);
+                    }
+                    if (q < n) v0 += pw_term(xi, yi, zi, tile[q], i, G.ly, G.lz, pbc, sigma, kk, cut2, neval);
+                }
+            }
+        }
+    }
+    partial[w][lane] = v0 + v1;
+    neval = wave_sum_all_i(neval); ntest = wave_sum_all_i(ntest);
+    if (lane == 0 && neval) atomicAdd(nevaluated, (unsigned long long)neval);
+    if (lane == 0 && ntest) atomicAdd(nevaluated + 1, (unsigned long long)ntest);
+    __syncthreads();
+    if (w == 0 && i >= 0) out[i] = (partial[0][lane] + partial[1][lane]) + (partial[2][lane] + partial[3][lane]);
 }
 
 extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, const double *lattice, const double *sigma,
@@ -318,8 +519,30 @@ extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, 
         if (!evp_ready) { HIPCHK(hipEventCreate(&evp[0])); HIPCHK(hipEventCreate(&evp[1])); evp_ready = true; }
         HIPCHK(hipEventRecord(evp[0], st));
     }
-    unsigned long long *d_ne = (unsigned long long *)(cnt + 4);
-    HIPCHK(hipMemsetAsync(d_ne, 0, 8, st));
+    unsigned long long *d_ne = (unsigned long long *)(cnt + 4);          // [0] pairs evaluated (inside the cut-off), [1] pairs tested
+    HIPCHK(hipMemsetAsync(d_ne, 0, 16, st));
+    // cell list over the charged sites (taken on the device when the cut-off is on, the box has >= 3 columns along y or z and
+    // enough sites are charged; otherwise these launches return at once and k_pairwise sums over the whole list)
+    int *cells = (int *)scratch(S_PW_CELLS, (size_t)(8 * (PW_MAXCELL + 1)) * 4 + sizeof(PwGrid));
+    int *pperm = (int *)scratch(S_PW_PERM, (size_t)N * 4 * 3);
+    ChargedSite *clist2 = (ChargedSite *)scratch(S_PW_LIST2, (size_t)N * sizeof(ChargedSite));
+    if (!cells || !pperm || !clist2) return e.err_code;
+    int *tcount = cells, *ccount = cells + (PW_MAXCELL + 1), *cursor = cells + 2 * (PW_MAXCELL + 1);
+    int *tstart = cells + 4 * (PW_MAXCELL + 1), *cstart = cells + 5 * (PW_MAXCELL + 1), *chunk0 = cells + 6 * (PW_MAXCELL + 1);
+    PwGrid *grid = (PwGrid *)(cells + 8 * (PW_MAXCELL + 1));
+    int *site_cell = pperm + N, *ccell = pperm + 2 * (size_t)N;
+    // the grouping of the sites by column is kept between calls (positions, box and cut-off do not change); what the host can see of its key:
+    static struct { const void *x, *y, *z, *perm, *cells; int N, pbc; double cut; } key = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, -1.0};
+    const int host_rebuild = key.x != x || key.y != y || key.z != z || key.perm != pperm || key.cells != cells || key.N != N || key.pbc != pbc || key.cut != e.pair_cut;
+    if (host_rebuild) { HIPCHK(hipMemsetAsync(grid, 0, sizeof(PwGrid), st)); key = {x, y, z, pperm, cells, N, pbc, e.pair_cut}; }
+    hipLaunchKernelGGL(k_pw_grid, dim3(1), dim3(256), 0, st, lattice, sigma, e.pair_cut, pbc, (const int *)cnt, grid, tcount, ccount, cursor, host_rebuild);
+    hipLaunchKernelGGL(k_pw_bin, dim3(blocks), dim3(256), 0, st, N, y, z, (const PwGrid *)grid, (const ChargedSite *)list, (const int *)cnt, site_cell, ccell, tcount, ccount);
+    hipLaunchKernelGGL(k_pw_offsets, dim3(1), dim3(PW_MAXCELL), 0, st, grid, (const int *)tcount, (const int *)ccount, tstart, cstart, chunk0);
+    hipLaunchKernelGGL(k_pw_perm, dim3(blocks), dim3(256), 0, st, N, (const PwGrid *)grid, (const int *)site_cell, (const int *)tstart, cursor, pperm);
+    hipLaunchKernelGGL(k_pw_partition, dim3(PW_MAXCELL), dim3(256), 0, st, (const PwGrid *)grid, (const ChargedSite *)list, (const int *)cnt, (const int *)ccell,
+                       (const int *)cstart, clist2);
+    const int cell_blocks = (N + PW_SITES - 1) / PW_SITES + PW_MAXCELL;       // upper bound of the chunks of 64 sites of one column
+    const int *cells_in_use = &grid->use;
     if (comm_attached() && comm_nranks() > 1) {
         // SURVEY 8(e), "pairwise Poisson": the rows are independent -- every rank holds the (replicated) charged list and sums the
         // sites of its slab; one in-place all-gather hands every rank every potential.  Same arithmetic per site as on one GPU:
@@ -330,12 +553,17 @@ extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, 
         if (!xbuf) return e.err_code;
         const int lo = std::min(N, me * chunk), hi = std::min(N, lo + chunk);
         if (hi > lo)
-            hipLaunchKernelGGL(k_pairwise, dim3((hi - lo + PW_SITES - 1) / PW_SITES), dim3(PW_NT), 0, st, hi, x, y, z, lattice, pbc, sigma, k, list, cnt, xbuf, d_ne, lo, e.pair_cut);
+            hipLaunchKernelGGL(k_pairwise, dim3((hi - lo + PW_SITES - 1) / PW_SITES), dim3(PW_NT), 0, st, hi, x, y, z, lattice, pbc, sigma, k, list, cnt, xbuf, d_ne, lo, e.pair_cut, cells_in_use);
+        if (hi > lo)
+            hipLaunchKernelGGL(k_pairwise_cells, dim3(cell_blocks), dim3(PW_NT), 0, st, N, x, y, z, pbc, sigma, k, (const PwGrid *)grid, (const int *)tstart, (const int *)cstart,
+                               (const int *)chunk0, (const int *)pperm, (const ChargedSite *)clist2, xbuf, d_ne, lo, hi, e.pair_cut);
         KCHK();
         rc = comm_allgather_f64(xbuf, (size_t)chunk); if (rc) return rc;
         HIPCHK(hipMemcpyAsync(out, xbuf, (size_t)N * 8, hipMemcpyDeviceToDevice, st));
     } else {
-        hipLaunchKernelGGL(k_pairwise, dim3((N + PW_SITES - 1) / PW_SITES), dim3(PW_NT), 0, st, N, x, y, z, lattice, pbc, sigma, k, list, cnt, out, d_ne, 0, e.pair_cut);
+        hipLaunchKernelGGL(k_pairwise, dim3((N + PW_SITES - 1) / PW_SITES), dim3(PW_NT), 0, st, N, x, y, z, lattice, pbc, sigma, k, list, cnt, out, d_ne, 0, e.pair_cut, cells_in_use);
+        hipLaunchKernelGGL(k_pairwise_cells, dim3(cell_blocks), dim3(PW_NT), 0, st, N, x, y, z, pbc, sigma, k, (const PwGrid *)grid, (const int *)tstart, (const int *)cstart,
+                           (const int *)chunk0, (const int *)pperm, (const ChargedSite *)clist2, out, d_ne, 0, N, e.pair_cut);
         KCHK();
     }
     e.stats.pair_ms = 0.0;
@@ -345,9 +573,9 @@ extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, 
         float ms = 0.f;
         HIPCHK(hipEventElapsedTime(&ms, evp[0], evp[1]));
         e.stats.pair_ms = ms;
-        unsigned long long ne = 0;
-        HIPCHK(hipMemcpy(&ne, d_ne, 8, hipMemcpyDeviceToHost));
-        e.stats.pair_evaluated = (long long)ne;
+        unsigned long long ne[2] = {0, 0};
+        HIPCHK(hipMemcpy(ne, d_ne, 16, hipMemcpyDeviceToHost));
+        e.stats.pair_evaluated = (long long)ne[0]; e.stats.pair_tested = (long long)ne[1];
     }
     return 0;
 }

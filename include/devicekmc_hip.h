@@ -96,6 +96,7 @@ typedef struct dkmc_stats {
     int kcg_iters_timed, kcg_pad;
     double pair_ms;
     long long pair_evaluated;              /* (site, charged site) pairs inside the screening cut-off of the last pair sum (profiling on) */
+    long long pair_tested;                 /* pairs whose distance was tested (all N x N_charged without the cell list; the 3 x 3 columns with it) */
 } dkmc_stats;
 
 const char *dkmc_last_error(void);

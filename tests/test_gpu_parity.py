@@ -124,6 +124,56 @@ def test_pair_sum_all_pairs_switch(cell_2p5, hip):
     assert np.abs(got[6.5][0] - got[0.0][0]).max() <= 1e-15 * scale
 
 
+@pytest.mark.parametrize("pbc", [0, 1])
+def test_pair_sum_cell_list(cell_2p5, hip, pbc):
+    """The cell-list path of the pair sum (taken on the device when the box has >= 3 columns of the cut-off radius along y or z and
+    >= 512 sites are charged): the 2.5 nm cell tiled 6 x 6 (338 364 sites, 153 A = 4 columns each way), 2 % of the oxygen / vacancy sites
+    charged at random.  Against the all-pairs sum of the same call (dkmc_set_pair_cutoff(0)) to 1e-15 of the largest potential, against the
+    oracle to 1e-12; 39 % of the pairs are distance-tested without pbc (edge columns see 2 of 4, inner ones 3 of 4, per axis), 56 % with
+    pbc (the columns wrap: 3 of 4); two runs give the same bits."""
+    from devicekmc_amd import params as pm, structure
+    from devicekmc_amd.host import _ptr
+    from devicekmc_amd.lib import check
+    from oracle import oracle as oc
+    host, L = hip
+    k = 6
+    s = structure.tile_structure(cell_2p5, k, 25.575, 25.575, 1440)
+    p = pm.KMCParameters().for_tiling(k); p.pbc = bool(pbc)
+    dev = host.Device(s, p, gpu_neighbors="cuda:0")
+    gb = dev.make_gpubuf("cuda:0")
+    rng = np.random.default_rng(5 + pbc)
+    # charges only where the model puts them (oxygen / vacancy sites): the shipped cell holds one pair of coincident Ti sites per tile
+    ok = (dev.site_element == pm.O_EL) | (dev.site_element == pm.VACANCY)
+    q = np.where(ok & (rng.random(dev.N) < 0.02), rng.choice([-2, 2], dev.N), 0).astype(np.int32)
+    put(gb, "site_charge", q)
+    nq = int((q != 0).sum())
+    assert nq >= 512
+    want = np.zeros(dev.N)
+    lat = np.asarray(p.lattice, dtype=np.float64)
+    oc.lib().okmc_poisson_gridless(dev.N, oc._p(dev.site_x), oc._p(dev.site_y), oc._p(dev.site_z), oc._p(lat), int(pbc), C.c_double(p.sigma),
+                                   C.c_double(p.k), oc._p(q), oc._p(want))
+    got = {}
+    try:
+        for cut in (0.0, 6.5, 6.5):
+            L.dkmc_set_pair_cutoff(cut)
+            L.dkmc_set_profiling(1)
+            check(L.dkmc_poisson_gridless_gpu(0, int(pbc), gb.N_, _ptr(gb.lattice), _ptr(gb.sigma), _ptr(gb.k), _ptr(gb.site_x), _ptr(gb.site_y),
+                                              _ptr(gb.site_z), _ptr(gb.site_charge), _ptr(gb.site_potential_charge)))
+            st = host.get_stats()
+            cur = (get(gb, "site_potential_charge").copy(), st["pair_evaluated"], st["pair_tested"])
+            if cut in got:
+                assert np.array_equal(cur[0], got[cut][0]) and cur[1:] == got[cut][1:]          # run-to-run: same bits
+            got[cut] = cur
+    finally:
+        L.dkmc_set_pair_cutoff(6.5); L.dkmc_set_profiling(0)
+    scale = np.abs(want).max()
+    assert got[0.0][2] == dev.N * nq and got[0.0][1] == dev.N * nq - nq             # all pairs: every one tested, every one but the self terms evaluated
+    assert got[6.5][2] < (0.62 if pbc else 0.45) * dev.N * nq, got[6.5][2] / (dev.N * nq)      # the cell list was taken
+    assert got[6.5][1] <= got[6.5][2]
+    assert np.abs(got[0.0][0] - want).max() <= 1e-12 * scale
+    assert np.abs(got[6.5][0] - got[0.0][0]).max() <= 1e-15 * scale
+
+
 def test_event_table_and_loop_exact(pair_2p5, hip):
     host, L = hip
     from devicekmc_amd.host import _ptr

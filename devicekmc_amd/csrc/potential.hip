@@ -532,16 +532,27 @@ extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, 
     PwGrid *grid = (PwGrid *)(cells + 8 * (PW_MAXCELL + 1));
     int *site_cell = pperm + N, *ccell = pperm + 2 * (size_t)N;
     // the grouping of the sites by column is kept between calls (positions, box and cut-off do not change); what the host can see of its key:
-    static struct { const void *x, *y, *z, *perm, *cells; int N, pbc; double cut; } key = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, -1.0};
+    // `possible`: the box has >= 3 columns along y or z, read back ONCE per key (one 64-byte copy); a box without (85 k sites: 2 x 2) skips
+    // every launch of the cell path from then on
+    static struct { const void *x, *y, *z, *perm, *cells; int N, pbc; double cut; int possible, ncell; } key = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, -1.0, 0, 0};
     const int host_rebuild = key.x != x || key.y != y || key.z != z || key.perm != pperm || key.cells != cells || key.N != N || key.pbc != pbc || key.cut != e.pair_cut;
-    if (host_rebuild) { HIPCHK(hipMemsetAsync(grid, 0, sizeof(PwGrid), st)); key = {x, y, z, pperm, cells, N, pbc, e.pair_cut}; }
-    hipLaunchKernelGGL(k_pw_grid, dim3(1), dim3(256), 0, st, lattice, sigma, e.pair_cut, pbc, (const int *)cnt, grid, tcount, ccount, cursor, host_rebuild);
-    hipLaunchKernelGGL(k_pw_bin, dim3(blocks), dim3(256), 0, st, N, y, z, (const PwGrid *)grid, (const ChargedSite *)list, (const int *)cnt, site_cell, ccell, tcount, ccount);
-    hipLaunchKernelGGL(k_pw_offsets, dim3(1), dim3(PW_MAXCELL), 0, st, grid, (const int *)tcount, (const int *)ccount, tstart, cstart, chunk0);
-    hipLaunchKernelGGL(k_pw_perm, dim3(blocks), dim3(256), 0, st, N, (const PwGrid *)grid, (const int *)site_cell, (const int *)tstart, cursor, pperm);
-    hipLaunchKernelGGL(k_pw_partition, dim3(PW_MAXCELL), dim3(256), 0, st, (const PwGrid *)grid, (const ChargedSite *)list, (const int *)cnt, (const int *)ccell,
-                       (const int *)cstart, clist2);
-    const int cell_blocks = (N + PW_SITES - 1) / PW_SITES + PW_MAXCELL;       // upper bound of the chunks of 64 sites of one column
+    if (host_rebuild) { HIPCHK(hipMemsetAsync(grid, 0, sizeof(PwGrid), st)); key = {x, y, z, pperm, cells, N, pbc, e.pair_cut, 1, PW_MAXCELL}; }
+    if (key.possible) hipLaunchKernelGGL(k_pw_grid, dim3(1), dim3(256), 0, st, lattice, sigma, e.pair_cut, pbc, (const int *)cnt, grid, tcount, ccount, cursor, host_rebuild);
+    if (host_rebuild) {
+        PwGrid hg{};
+        HIPCHK(hipMemcpyAsync(&hg, grid, sizeof(PwGrid), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        key.possible = e.pair_cut > 0.0 && (hg.ny >= 3 || hg.nz >= 3); key.ncell = std::max(1, hg.ny * hg.nz);
+        if (!key.possible) HIPCHK(hipMemsetAsync(grid, 0, sizeof(PwGrid), st));          // use = 0 for good: k_pairwise does every call
+    }
+    const int cell_blocks = (N + PW_SITES - 1) / PW_SITES + key.ncell;        // upper bound of the chunks of 64 sites of one column
+    if (key.possible) {
+        hipLaunchKernelGGL(k_pw_bin, dim3(blocks), dim3(256), 0, st, N, y, z, (const PwGrid *)grid, (const ChargedSite *)list, (const int *)cnt, site_cell, ccell, tcount, ccount);
+        hipLaunchKernelGGL(k_pw_offsets, dim3(1), dim3(PW_MAXCELL), 0, st, grid, (const int *)tcount, (const int *)ccount, tstart, cstart, chunk0);
+        hipLaunchKernelGGL(k_pw_perm, dim3(blocks), dim3(256), 0, st, N, (const PwGrid *)grid, (const int *)site_cell, (const int *)tstart, cursor, pperm);
+        hipLaunchKernelGGL(k_pw_partition, dim3(key.ncell), dim3(256), 0, st, (const PwGrid *)grid, (const ChargedSite *)list, (const int *)cnt, (const int *)ccell,
+                           (const int *)cstart, clist2);
+    }
     const int *cells_in_use = &grid->use;
     if (comm_attached() && comm_nranks() > 1) {
         // SURVEY 8(e), "pairwise Poisson": the rows are independent -- every rank holds the (replicated) charged list and sums the
@@ -554,7 +565,7 @@ extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, 
         const int lo = std::min(N, me * chunk), hi = std::min(N, lo + chunk);
         if (hi > lo)
             hipLaunchKernelGGL(k_pairwise, dim3((hi - lo + PW_SITES - 1) / PW_SITES), dim3(PW_NT), 0, st, hi, x, y, z, lattice, pbc, sigma, k, list, cnt, xbuf, d_ne, lo, e.pair_cut, cells_in_use);
-        if (hi > lo)
+        if (hi > lo && key.possible)
             hipLaunchKernelGGL(k_pairwise_cells, dim3(cell_blocks), dim3(PW_NT), 0, st, N, x, y, z, pbc, sigma, k, (const PwGrid *)grid, (const int *)tstart, (const int *)cstart,
                                (const int *)chunk0, (const int *)pperm, (const ChargedSite *)clist2, xbuf, d_ne, lo, hi, e.pair_cut);
         KCHK();
@@ -562,8 +573,9 @@ extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, 
         HIPCHK(hipMemcpyAsync(out, xbuf, (size_t)N * 8, hipMemcpyDeviceToDevice, st));
     } else {
         hipLaunchKernelGGL(k_pairwise, dim3((N + PW_SITES - 1) / PW_SITES), dim3(PW_NT), 0, st, N, x, y, z, lattice, pbc, sigma, k, list, cnt, out, d_ne, 0, e.pair_cut, cells_in_use);
-        hipLaunchKernelGGL(k_pairwise_cells, dim3(cell_blocks), dim3(PW_NT), 0, st, N, x, y, z, pbc, sigma, k, (const PwGrid *)grid, (const int *)tstart, (const int *)cstart,
-                           (const int *)chunk0, (const int *)pperm, (const ChargedSite *)clist2, out, d_ne, 0, N, e.pair_cut);
+        if (key.possible)
+            hipLaunchKernelGGL(k_pairwise_cells, dim3(cell_blocks), dim3(PW_NT), 0, st, N, x, y, z, pbc, sigma, k, (const PwGrid *)grid, (const int *)tstart, (const int *)cstart,
+                               (const int *)chunk0, (const int *)pperm, (const ChargedSite *)clist2, out, d_ne, 0, N, e.pair_cut);
         KCHK();
     }
     e.stats.pair_ms = 0.0;

@@ -667,7 +667,16 @@ __device__ __forceinline__ double xt_row_block_sum(int k, int nW, int cbase, int
     const double *rpp = rowpart + (size_t)k * nW * XT_R + r;
     const double *cpp = colpart + (size_t)cbase * XT_C + (s - XT_C * (k / (XT_C / XT_R)));
     int w = wr.x + sl, c = sl;
-    // four independent loads in flight per list (the lists hold up to nK / 8 terms per slice)
+    // independent loads in flight per list: 16 while the list is long (the strips at the tapered end of a share hold thousands of
+    // single-tile runs: 300 terms per slice, whose latency rounds are what this kernel costs at 9.4e5 sites), then 8, 4, 1.  Term j of a
+    // slice always goes to accumulator j % 4, whatever the unrolling: the sum is the same bits.
+    for (; c + 120 < nc; c += 128) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = cpp[(size_t)(c + 8 * u) * ns_pad];
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) { a0 += v[u]; a1 += v[u + 1]; a2 += v[u + 2]; a3 += v[u + 3]; }
+    }
     for (; c + 56 < nc; c += 64) {                                    // tapered shares end in strips of single-tile items: up to nK terms
         const double v0 = cpp[(size_t)c * ns_pad], v1 = cpp[(size_t)(c + 8) * ns_pad], v2 = cpp[(size_t)(c + 16) * ns_pad], v3 = cpp[(size_t)(c + 24) * ns_pad];
         const double v4 = cpp[(size_t)(c + 32) * ns_pad], v5 = cpp[(size_t)(c + 40) * ns_pad], v6 = cpp[(size_t)(c + 48) * ns_pad], v7 = cpp[(size_t)(c + 56) * ns_pad];

@@ -601,8 +601,28 @@ def main():
                           "cg_iters_X": s1.cnt["cg_iters_X"] / max(s1.cnt["steps"], 1), "trace": [list(t) for t in s1.trace[:n1]]}
                 s1.close()
             parallel.barrier()
+        transport_note = None
         if args.mode == "sharded":
-            transport = parallel.attach_solver_comm()          # every rank advances the same simulation (same seeds); X is sharded
+            # every rank advances the same simulation (same seeds); X is sharded.  RCCL over xGMI when the process group is nccl.  Should
+            # the in-library communicator fail to come up on ANY rank (no multi-GPU node was available to try it on), all ranks fall back
+            # together to the host-callback transport over a gloo group: slower exchanges, same results -- and the line says so.
+            import torch.distributed as dist
+            ok, why = 1.0, ""
+            try:
+                if os.environ.get("DKMC_BENCH_FORCE_COMM_FAIL"):
+                    raise RuntimeError("DKMC_BENCH_FORCE_COMM_FAIL")
+                transport = parallel.attach_solver_comm()
+            except Exception as exc:
+                ok, why = 0.0, repr(exc)[:200]
+            tok = torch.tensor([ok], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(tok, op=dist.ReduceOp.MIN)
+            if tok.item() == 0.0:
+                try:
+                    parallel.detach_solver_comm()
+                except Exception:
+                    pass
+                transport = parallel.attach_solver_comm("host", group=dist.new_group(backend="gloo"))
+                transport_note = "in-library RCCL communicator failed to attach (%s); exchanges go through pinned host memory + gloo" % (why or "on a peer rank")
             sim = Sim(name, devname, x_format=1)
         else:
             transport = "none"
@@ -635,7 +655,7 @@ def main():
                            "phases": "charge+potential+rates+current+heat",
                            "parallelism": ("one simulation; X generated/stored/streamed in %d per-rank shares, 1 all-reduce of |S| doubles per CG iteration"
                                            if sharded else "replicas x%d") % world,
-                           "transport": transport, "x_format": "tiled", "current_warm_start": 0, "cg_tol": sim.p.cg_tol},
+                           "transport": transport, "transport_note": transport_note, "x_format": "tiled", "current_warm_start": 0, "cg_tol": sim.p.cg_tol},
                 "split_ms": res["split_ms"], "per_step": res["per_step"], "cpu_baseline": None,
                 "sharding": {"ranks_agree_bitwise": bool(agree) if sharded else None, "subblocks_total": int(st["xt_subblocks"]),
                              "subblocks_rank0": int(st["xt_local_subblocks"]), "rank0_share": round(share, 4),

@@ -104,6 +104,7 @@ struct Engine {
     int current_warm_start = 0;
     int profiling = 0;
     int cb_edge_domain = 0;        // 0: CB-edge system over every site (snapshot source); 1: over atoms only (dkmc_set_cb_edge_domain)
+    long long tcache_budget = -1;  // bytes the tunnelling-coefficient cache may take; -1 = a third of the free device memory, 8-128 GiB (dkmc_set_tcache_budget)
     double pair_cut = 6.5;         // screening cut-off of the pair sum in units of sigma sqrt 2 (dkmc_set_pair_cutoff; 0 = all pairs like the reference)
     int x_loop = 0;                // CG loop on the tiled X, one GPU: 0 = three launches per iteration (apply, rows, step; default), 1 = two (k_xt_apply2 + k_xt_fold_step: measured slower)
     int x_format = 1;              // 1: tiled X (xt.hip, default); 0: CSR X as the reference stores it (current.hip + cg.hip)

@@ -158,7 +158,8 @@ static int tc_reset(const XParams &P, int N, const int *aflag, const double *acb
     // 3.8e6 sites 106 GB; the tiles of a rank's share come on top)
     size_t mem_free = 0, mem_total = 0;
     if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 0;
-    const size_t budget = std::min((size_t)128 << 30, std::max((size_t)8 << 30, mem_free / 3));
+    size_t budget = std::min((size_t)128 << 30, std::max((size_t)8 << 30, mem_free / 3));
+    if (e.tcache_budget >= 0) budget = (size_t)e.tcache_budget;        // dkmc_set_tcache_budget (tests: force the uncached path)
     if (cap * nM * 8 > budget) cap = budget / ((size_t)nM * 8);
     if (cap < (size_t)n_vacancies + 16) { g_tc.valid = 0; return 0; }         // does not fit: run uncached
     g_tc.N = N; g_tc.Na = Na; g_tc.nM = nM; g_tc.cap = (int)cap;

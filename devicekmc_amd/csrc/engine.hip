@@ -44,6 +44,7 @@ void dkmc_set_current_warm_start(int mode) { eng().current_warm_start = mode; }
 void dkmc_set_profiling(int on) { eng().profiling = on; }
 void dkmc_set_x_format(int tiled) { eng().x_format = tiled ? 1 : 0; }
 int dkmc_get_x_format(void) { return eng().x_format; }
+void dkmc_set_tcache_budget(long long bytes) { eng().tcache_budget = bytes; }
 void dkmc_set_pair_cutoff(double x_cut) { eng().pair_cut = x_cut > 0.0 ? x_cut : 0.0; }
 void dkmc_set_x_loop(int two_launch) { eng().x_loop = two_launch ? 1 : 0; }
 void dkmc_set_cb_edge_domain(int atoms_only) { eng().cb_edge_domain = atoms_only ? 1 : 0; }

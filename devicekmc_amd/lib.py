@@ -60,6 +60,7 @@ SYMBOLS = {
     "dkmc_set_cb_edge_domain": (None, [_I]),
     "dkmc_set_x_loop": (None, [_I]),
     "dkmc_set_pair_cutoff": (None, [_D]),
+    "dkmc_set_tcache_budget": (None, [C.c_longlong]),
     "dkmc_set_current_warm_start": (None, [_I]),
     "dkmc_set_profiling": (None, [_I]),
     "dkmc_set_x_format": (None, [_I]),

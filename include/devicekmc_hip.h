@@ -117,6 +117,11 @@ void dkmc_set_cg_tolerance(double tol);
  * written by a revision that solved on atoms (its host twin still shows `gesv(.., &N_atom, ..)` as a comment, potential_solver.cpp:98):
  * with 1 they are reproduced to every entry / printed digit, with 0 the current is 0.83 % lower. */
 void dkmc_set_cb_edge_domain(int atoms_only);
+/* Memory the tunnelling-coefficient cache of the current solve may take (one row per vacancy site x one column per inner-contact
+ * metal, 8 B each: 27 GB at 9.4e5 sites).  -1 (default): a third of the device memory that is free when the cache is (re)built, between
+ * 8 and 128 GiB.  When one row per vacancy does not fit, the contact->trap integrals are evaluated directly while the tiles are filled,
+ * every step -- same function, same bits, slower assembly.  Takes effect at the next rebuild of the cache (new bias point / structure). */
+void dkmc_set_tcache_budget(long long bytes);
 /* Screening cut-off of poisson_gridless_gpu.  A term of the pair sum is q erfc(x) k Q / r with x = r / (sigma sqrt 2); terms beyond
  * x_cut are not evaluated.  Default 6.5 (erfc < 3.8e-20: all omitted terms of a 1e6-site stack together stay below 2e-17 V, under the
  * rounding of the sum and under the last-bit noise of the reference's atomicAdd order).  0: every pair, exactly the terms the reference

@@ -834,6 +834,33 @@ def test_two_launch_loop_agrees_with_three_launch_loop(dev_7p5, cell_2p5, hip):
                 assert np.abs(b["m"][:n] - a["m"][:n]).max() <= 1e-8 * np.abs(a["m"][:n]).max()
 
 
+def test_uncached_coefficients_same_bits(dev_7p5, hip):
+    """The tunnelling-coefficient cache against its fallback (a device whose cache does not fit evaluates the contact->trap integrals
+    directly while the tiles are filled): with the budget forced to zero the same two supersteps give the same bits -- solution, current,
+    dissipated power -- as with the cache, on the tiled and on the CSR form of X."""
+    host, L = hip
+    out = {}
+    try:
+        for fmt in (1, 0):
+            for budget in (-1, 0):
+                L.dkmc_set_x_format(fmt)
+                L.dkmc_set_tcache_budget(budget)
+                p = params_7p5(); p.cg_tol = 1e-8; p.solve_heating_global = True
+                dev, sim, gb, _ = _fresh_device(dev_7p5, p, hip)          # setLaplacePotential invalidates the cache: rebuilt with this budget
+                rec = []
+                for k in range(2):
+                    dev.updateCharge(gb); dev.updatePotential(gb, p, Vd, k)
+                    sim.executeKMCStep(gb, dev)
+                    dev.updatePower(gb, p, Vd)
+                    rec.append((dev.imacro, get(gb, "atom_virtual_potentials").copy(), get(gb, "site_power").copy(), host.get_stats()["cg_iters_X"]))
+                out[(fmt, budget)] = rec
+    finally:
+        L.dkmc_set_x_format(1); L.dkmc_set_tcache_budget(-1)
+    for fmt in (1, 0):
+        for (ia, ma, pa, na), (ib, mb, pb_, nb) in zip(out[(fmt, -1)], out[(fmt, 0)]):
+            assert ia == ib and na == nb and np.array_equal(ma, mb) and np.array_equal(pa, pb_), fmt
+
+
 def test_default_tolerance_superstep_7p5(dev_7p5, hip):
     """The configuration bench.py times: 85 071 sites at the library's DEFAULT CG tolerance 1e-6 (the snapshot's hard-coded value,
     iterative_solvers_gpu.cu:322).  At a loose tolerance two correct CG implementations stop on different iterates (cond(K) ~ 1e8,

@@ -16,10 +16,13 @@ Workloads (config.workload):
 
 Contract: python bench.py --gpus N --steps K --warmup W ; prints ONE JSON line on rank 0.
 
-N = 1: `value` = steps/s of the default workload; the same line carries `scale_points` -- tile:5 and tile:10 measured in the same
-run (a few steps each: a tile:10 step takes seconds) with their own ms/step split, CG iteration counts, HIP-event roofline of the
-dominant kernel and a CPU baseline (the oracle's CG iteration timed at that size x the GPU run's iteration count); the tile:10 point
-also carries `strong_scaling_model`: the kernels one rank of a 2/4/8-way sharded solve runs, timed on this GPU on that rank's share.
+N = 1: `value` = steps/s of the default workload at the library's default CG tolerance (1e-6, the snapshot's); the same line carries
+`at_log_tolerance` -- the same workload under KMCParameters.log_revision() (1e-12, CB edge on atoms), the configuration in which the
+reference's own log is reproduced, with the timed steps checked against that log -- and `scale_points`: tile:5 and tile:10 measured in
+the same run (tile:10: the cold step + 3 steady steps, reported separately) with their own ms/step split, CG iteration counts, HIP-event
+roofline of the dominant kernel incl. PMC `traffic` at that size, K-CG roofline on the bytes moved, pair-sum entry and a CPU baseline (the
+oracle's CG iteration timed at that size x the GPU run's iteration count); the tile:10 point also carries `strong_scaling_model`: the
+kernels one rank of a 2/4/8-way sharded solve runs, timed on this GPU on that rank's share (all-reduce latency ASSUMED).
 
 N > 1 (launched with torch.distributed.run; the reference has no multi-GPU path): STRONG scaling of ONE simulation of the ~1e6-site
 stack (tile:10): every rank advances the same simulation in lockstep, the tunnelling block of X -- > 95 % of a step -- is generated,

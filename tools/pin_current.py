@@ -2,7 +2,9 @@
 """CPU experiment behind DESIGN.md section 2 (pin of the current solve): the oracle on the reference's 85 071-site device at several
 CG tolerances, against the reference's own CUDA-path log (timing_7.5nm/output_noguess.txt: KMC time 2.05754e-14 s, Current 11.8834 uA
 at step 0).  Also: how many tunnelling pairs sit within the CB-edge solve's error band of the 0.01 eV threshold
-(iterative_solvers_gpu.cu:903-908), and what the current becomes when those pairs flip.
+(iterative_solvers_gpu.cu:903-908), and what the current becomes when those pairs flip.  Runs the snapshot's source (CB edge over
+every site): the KMC time answers which tolerance wrote the log (1e-12); the current stays 0.83 % low at every tolerance -- that gap is
+the CB-edge domain, not a tolerance or a constant (tools/pin_current_constants.py).
 usage: OMP_NUM_THREADS=8 python tools/pin_current.py [tol ...]"""
 import json
 import os

@@ -190,7 +190,8 @@ def rooflines(sim, local_share=1.0):
             # 8 B result, 8 B scale, 4 B class).  In a sharded solve these are THIS rank's tiles.
             kname = "k_xt_apply2" if (X_LOOP and not st["comm_ranks"]) else "k_xt_apply"
             bytes_per_launch = (8192.0 * st["xt_local_subblocks"] + (16.0 + 256.0) * st["spmv_tiles"] * local_share
-                                + (32.0 + 2048.0) * (st["comm_local_segments"] if st["comm_ranks"] else st["xt_items"])
+                                + 32.0 * (st["comm_local_segments"] if st["comm_ranks"] else st["xt_items"])
+                                + 2048.0 * (st["comm_local_segments"] if st["comm_ranks"] else (st["xt_records"] or st["xt_items"]))
                                 + (0.0 if st["xt_split_launch"] else 12.0 * st["xt_sparse_nnz"] + 28.0 * rows_all))
             # (sharded solve: the timed launch is the tile pass alone; the neighbour part runs on a second stream beside the exchange)
         elif st["spmv_segments"] > 0:

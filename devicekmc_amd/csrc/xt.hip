@@ -39,7 +39,7 @@
 typedef double dbl2 __attribute__((ext_vector_type(2)));
 
 struct __attribute__((aligned(16))) XTile { int k, w; unsigned mask; int soff; };   // cell (k, w); present sub-blocks; first sub-block slot
-struct __attribute__((aligned(32))) XItem { int t0, t1, w, c, k0; unsigned mask0; int soff0, pad; };   // tiles [t0, t1) of strip w; c = position of the run in its strip; descriptor of tile t0; pad = index of the run in the item list (= ioff[w] + c: its 256 column sums live at colpart[pad * 256])
+struct __attribute__((aligned(32))) XItem { int t0, t1, w, c, k0; unsigned mask0; int soff0, pad; };   // tiles [t0, t1) of strip w; c = position of the run in its strip; descriptor of tile t0; pad = record of its column sums, colpart[pad * 256]: the run's own (c = 0; pad = its index in the item list) or, on one GPU, one record per aligned group of four runs -- the four waves of a workgroup (c = 1; pad = index / 4; every strip's run count padded to a multiple of four with empty runs)
 struct XCtrl { double rr[2]; int done_local, sharded; int done; int iters; int abort_local, aborted; int pad[2]; };
 // `done` (non-zero) gates every kernel of the loop; see k_xt_step for its iteration stamp.  Single GPU: set by the step kernel.  Sharded solve: the direction kernel only sets
 // done_local; rank 0's done_local travels in the all-reduced buffer (slot ns) and k_xt_rows_apply turns it into `done` on every
@@ -170,20 +170,25 @@ __device__ __forceinline__ int xt_run_len(int t, int t1, int kc, const XSplit *s
     return max(1, min(len, min(end, t1) - t));
 }
 // MODE 0: items per strip (+ the largest count); MODE 1: write them at ioff[w]
+// rec_shift = 2 (one GPU): the run count of every strip is padded to a multiple of four with empty runs, so that the four waves of a
+// workgroup always hold runs of ONE strip and can leave one combined record of column sums (a quarter of the records the row kernel folds)
 template <int MODE>
 __global__ void k_xt_items(int nK, int nW, int kc, int ntiles, const int *__restrict__ toff, const int *__restrict__ ioff, const XTile *__restrict__ tiles,
-                           XSplit *sp, int *__restrict__ nitem_w, XItem *__restrict__ items)
+                           XSplit *sp, int *__restrict__ nitem_w, XItem *__restrict__ items, int rec_shift)
 {
     const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w == 0 && !MODE) nitem_w[2 * (nW + 2)] = rec_shift;             // read by the row kernels (xt_row_block_runs)
     if (w >= nW) return;
     const int t0 = toff[(long long)w * nK], t1 = (w + 1 < nW) ? toff[(long long)(w + 1) * nK] : ntiles;
     int o = MODE ? ioff[w] : 0, c = 0;
     for (int t = t0; t < t1; ++c) {
         const int len = xt_run_len(t, t1, kc, sp);
-        if (MODE) { const XTile f = tiles[t]; XItem it; it.t0 = t; it.t1 = t + len; it.w = w; it.c = c; it.k0 = f.k; it.mask0 = f.mask; it.soff0 = f.soff; it.pad = o + c; items[o + c] = it; }
+        if (MODE) { const XTile f = tiles[t]; XItem it; it.t0 = t; it.t1 = t + len; it.w = w; it.c = rec_shift ? 1 : 0; it.k0 = f.k; it.mask0 = f.mask; it.soff0 = f.soff; it.pad = (o + c) >> rec_shift; items[o + c] = it; }
         t += len;
     }
-    if (!MODE) { nitem_w[w] = c; atomicMax(&sp->max_items_per_strip, c); }
+    const int m = (1 << rec_shift) - 1, cpad = (c + m) & ~m;
+    if (MODE) for (; c < cpad; ++c) { XItem it; it.t0 = t1; it.t1 = t1; it.w = w; it.c = 1; it.k0 = 0; it.mask0 = 0; it.soff0 = 0; it.pad = (o + c) >> rec_shift; items[o + c] = it; }
+    if (!MODE) { nitem_w[w] = cpad; atomicMax(&sp->max_items_per_strip, cpad); }
 }
 // first item of every rank's share (items are in tile order and never cross a share boundary) + what the host needs of the boundary tiles
 __global__ void k_xt_rank_items(const int *__restrict__ nitems_dev, int ntiles, long long nsub_total, const XItem *__restrict__ items,
@@ -196,6 +201,7 @@ __global__ void k_xt_rank_items(const int *__restrict__ nitems_dev, int ntiles, 
     const int tb = sp->tb[r];
     int lo = 0, hi = nitems;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (items[mid].t0 < tb) lo = mid + 1; else hi = mid; }
+    if (r == sp->n) lo = nitems;                                      // the empty runs that pad the last strip (t0 = ntiles) belong to the last share
     sp->item_lo[r] = lo;
     sp->soff[r] = tb < ntiles ? tiles[tb].soff : (int)nsub_total;
     sp->w_first[r] = tb < ntiles ? tiles[tb].w : 0;
@@ -270,6 +276,8 @@ __device__ __forceinline__ void xt_tile_role(const XItem it, const XTile *__rest
                                              double *__restrict__ colpart, bool vpos, double *lcol, double *lq,
                                              const double *__restrict__ vS2 = nullptr, double beta = 0.0, double *ptacc = nullptr)
 {
+    // it.c != 0: the four waves of this workgroup hold runs of one strip and write ONE record (lcol = this wave's 512 doubles of
+    // lcol_all[4][512]; the caller guarantees that all four waves get here: the item count is a multiple of four)
     const int lane = threadIdx.x & 63, cc = lane & 15, rr = lane >> 4;
     XTile td; td.k = it.k0; td.w = it.w; td.mask = it.mask0; td.soff = it.soff0;
 #define XT_LD(dst, slot) _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) dst[j_] = NTL ? __builtin_nontemporal_load(base + (size_t)(8 * (slot) + j_) * 64) : base[(size_t)(8 * (slot) + j_) * 64];
@@ -371,10 +379,24 @@ __device__ __forceinline__ void xt_tile_role(const XItem it, const XTile *__rest
     }
 #undef XT_LD
 #undef XT_SUBBLOCK
-    if (rr == 0) {
-        double *cp = colpart + (size_t)it.pad * XT_C + 2 * cc;            // one 256-entry record per run, runs of a strip consecutive
+    if (it.c == 0) {
+        if (rr == 0) {
+            double *cp = colpart + (size_t)it.pad * XT_C + 2 * cc;        // one 256-entry record per run, runs of a strip consecutive
 #pragma unroll
-        for (int q = 0; q < 8; ++q) *reinterpret_cast<dbl2 *>(cp + XT_SBW * q) = *reinterpret_cast<const dbl2 *>(lcol + XT_SBW * q + 2 * cc);
+            for (int q = 0; q < 8; ++q) *reinterpret_cast<dbl2 *>(cp + XT_SBW * q) = *reinterpret_cast<const dbl2 *>(lcol + XT_SBW * q + 2 * cc);
+        }
+        return;
+    }
+    // one record per workgroup: wave v adds the four waves' column sums of sub-blocks 2v, 2v + 1 in a fixed order
+    __syncthreads();
+    if (lane < 32) {
+        const int wv = (int)(threadIdx.x >> 6);
+        const double *all = lcol - (size_t)wv * (2 * XT_C);                // lcol[0][..] of the workgroup
+        const int off = XT_SBW * (2 * wv + (lane >> 4)) + 2 * (lane & 15);
+        const dbl2 a = *reinterpret_cast<const dbl2 *>(all + off), b = *reinterpret_cast<const dbl2 *>(all + 2 * XT_C + off);
+        const dbl2 c2 = *reinterpret_cast<const dbl2 *>(all + 4 * XT_C + off), d = *reinterpret_cast<const dbl2 *>(all + 6 * XT_C + off);
+        dbl2 o; o.x = (a.x + b.x) + (c2.x + d.x); o.y = (a.y + b.y) + (c2.y + d.y);
+        *reinterpret_cast<dbl2 *>(colpart + (size_t)it.pad * XT_C + off) = o;
     }
 }
 
@@ -643,15 +665,16 @@ __global__ __launch_bounds__(XT_NT) void k_xt_tiles_only(int nitems, const XItem
 // only (this rank's share in the sharded solve; the diagonal and power passes).
 // [w_lo, w_hi): windows that can hold partial sums in this launch -- all of them on one GPU; in a sharded solve the windows of this
 // rank's tiles (every other cell of the partial arrays is zero on this rank: not reading it saves 7/8 of this kernel at 8 ranks)
-__device__ __forceinline__ int xt_row_block_runs(int k, const int *__restrict__ nitem_w, int w_lo, int w_hi)
+// records of column sums of row block k's strip: count and first index.  nitem_w: [runs per strip | their exclusive scan | rec_shift]
+// (xt_build_items); with rec_shift = 2 four runs share a record
+__device__ __forceinline__ int xt_row_block_runs(int k, const int *__restrict__ nitem_w, int w_lo, int w_hi, int nW)
 {
     const int wk = k / (XT_C / XT_R);
-    return (wk >= w_lo && wk < w_hi) ? nitem_w[wk] : 0;
+    return (wk >= w_lo && wk < w_hi) ? nitem_w[wk] >> nitem_w[2 * (nW + 2)] : 0;
 }
-// index of the first run of row block k's strip in the item list (the exclusive scan of nitem_w sits behind it: xt_build_items)
 __device__ __forceinline__ int xt_row_block_cbase(int k, int nW, const int *__restrict__ nitem_w)
 {
-    return nitem_w[nW + 2 + k / (XT_C / XT_R)];
+    return nitem_w[nW + 2 + k / (XT_C / XT_R)] >> nitem_w[2 * (nW + 2)];
 }
 // wr = wrange[k], nc = xt_row_block_runs(k, ...): fetched by the caller, with whatever else starts its chain
 __device__ __forceinline__ double xt_row_block_sum(int k, int nW, int cbase, int2 wr, int nc,
@@ -751,7 +774,7 @@ __global__ __launch_bounds__(XT_NT) void k_xt_rows(int ns, int nK, int nW, int n
     // ... and the extent of the first row block's partial lists: one dependent level less behind the flag
     int2 wr0 = make_int2(0, 0); int nc0 = 0;
     int cb0 = 0;
-    if ((int)blockIdx.x < nK) { wr0 = wrange[blockIdx.x]; nc0 = xt_row_block_runs(blockIdx.x, nitem_w, w_lo, w_hi); cb0 = xt_row_block_cbase(blockIdx.x, nW, nitem_w); }
+    if ((int)blockIdx.x < nK) { wr0 = wrange[blockIdx.x]; nc0 = xt_row_block_runs(blockIdx.x, nitem_w, w_lo, w_hi, nW); cb0 = xt_row_block_cbase(blockIdx.x, nW, nitem_w); }
     if (ctrl) {
         if (threadIdx.x == 0) sdone = ctrl->done;
         __syncthreads();
@@ -759,7 +782,7 @@ __global__ __launch_bounds__(XT_NT) void k_xt_rows(int ns, int nK, int nW, int n
     }
     for (int k = blockIdx.x; k < nK; k += gridDim.x) {
         const bool own = k == (int)blockIdx.x;
-        const double sum = xt_row_block_sum(k, nW, own ? cb0 : xt_row_block_cbase(k, nW, nitem_w), own ? wr0 : wrange[k], own ? nc0 : xt_row_block_runs(k, nitem_w, w_lo, w_hi), rowpart, colpart, sl_sum, w_lo, w_hi);
+        const double sum = xt_row_block_sum(k, nW, own ? cb0 : xt_row_block_cbase(k, nW, nitem_w), own ? wr0 : wrange[k], own ? nc0 : xt_row_block_runs(k, nitem_w, w_lo, w_hi, nW), rowpart, colpart, sl_sum, w_lo, w_hi);
         const int s = XT_R * k + (int)threadIdx.x;
         if (threadIdx.x < XT_R && s < ns) {
             if (MODE == 1) xout[s] = sum;
@@ -802,7 +825,7 @@ __global__ __launch_bounds__(XT_NT) void k_xt_fold_step(int ns, int nK, int nW, 
     }
     int2 wr0 = make_int2(0, 0); int nc0 = 0;
     int cb0 = 0;
-    if ((int)blockIdx.x < nK) { wr0 = wrange[blockIdx.x]; nc0 = xt_row_block_runs(blockIdx.x, nitem_w, 0, nW); cb0 = xt_row_block_cbase(blockIdx.x, nW, nitem_w); }
+    if ((int)blockIdx.x < nK) { wr0 = wrange[blockIdx.x]; nc0 = xt_row_block_runs(blockIdx.x, nitem_w, 0, nW, nW); cb0 = xt_row_block_cbase(blockIdx.x, nW, nitem_w); }
     if (threadIdx.x < 64) {
         double beta, rr; bool stop;
         xt_iter_head(part_rr, it, n_cur, n_prev, tol2, beta, rr, stop, ctrl);
@@ -825,7 +848,7 @@ __global__ __launch_bounds__(XT_NT) void k_xt_fold_step(int ns, int nK, int nW, 
     }
     for (int k = blockIdx.x; k < nK; k += gridDim.x) {
         const bool own = k == (int)blockIdx.x;
-        const double sum = xt_row_block_sum(k, nW, own ? cb0 : xt_row_block_cbase(k, nW, nitem_w), own ? wr0 : wrange[k], own ? nc0 : xt_row_block_runs(k, nitem_w, 0, nW), rowpart, colpart, sl_sum, 0, nW);
+        const double sum = xt_row_block_sum(k, nW, own ? cb0 : xt_row_block_cbase(k, nW, nitem_w), own ? wr0 : wrange[k], own ? nc0 : xt_row_block_runs(k, nitem_w, 0, nW, nW), rowpart, colpart, sl_sum, 0, nW);
         const int s = XT_R * k + (int)threadIdx.x;
         if (threadIdx.x < XT_R && s < ns) {
             if (own) { const double tv = s0 * (t0 + sum); XT_UPDATE(row0, P0, R0, y0, tv, sc0, s) }
@@ -1054,7 +1077,7 @@ __global__ __launch_bounds__(XT_NT) void k_xt_power_rows(int Nsub, const xrp_t *
 // ---- host side -----------------------------------------------------------------------------------------------------------------
 struct XTState {
     // shape of the last assembly
-    int Nsub = 0, ns = 0, ns_pad = 0, nK = 0, nW = 0, ntiles = 0, nitems = 0, kc = 1, maxchunk = 1;
+    int Nsub = 0, ns = 0, ns_pad = 0, nK = 0, nW = 0, ntiles = 0, nitems = 0, kc = 1, maxchunk = 1, rec_shift = 0;
     long long nsub_total = 0, xs_nnz = 0;
     unsigned long long t_upper = 0;
     // this rank's share
@@ -1100,26 +1123,27 @@ static int xt_tile_sums(const double *vS, double *out, int vpos)
 
 // Builds the work items for an nranks-way split and reports rank `me`'s share.  Slots: where the item arrays go (the resident ones of
 // an assembly, or temporary ones of dkmc_xt_time_share).
-struct XShare { int nitems, maxchunk, item_lo, item_n, tile_lo, tile_n, w_lo, w_hi; long long sub_base, sub_n; XItem *items; int *nitem_w; };
+struct XShare { int nitems, maxchunk, item_lo, item_n, tile_lo, tile_n, w_lo, w_hi; long long sub_base, sub_n; XItem *items; int *nitem_w; int rec_shift; };
 static int xt_build_items(int nK, int nW, int kc, int ntiles, long long nsub_total, const int *toff, const XTile *tiles, int nranks, int me,
-                          int slot_nitemw, int slot_items, int slot_split, XShare *out)
+                          int slot_nitemw, int slot_items, int slot_split, XShare *out, int rec_shift = 0)
 {
+    if (nranks > 1) rec_shift = 0;                 // shares are cut at tile boundaries: a rank's first run need not start a group of four
     Engine &e = eng(); hipStream_t st = e.stream;
     if (nranks > XT_MAXRANKS) return dkmc_fail(46, "update_power: more ranks than XT_MAXRANKS", __FILE__, __LINE__);
-    int *nitem_w = (int *)scratch(slot_nitemw, (size_t)(nW + 4) * 4 * 2);
+    int *nitem_w = (int *)scratch(slot_nitemw, (size_t)(nW + 4) * 4 * 3);
     XSplit *sp = (XSplit *)scratch(slot_split, sizeof(XSplit));
     if (!nitem_w || !sp) return e.err_code;
     int *ioff = nitem_w + nW + 2;
     XSplit h{};
-    out->nitem_w = nitem_w; out->items = nullptr; out->nitems = 0; out->maxchunk = 1;
+    out->nitem_w = nitem_w; out->items = nullptr; out->nitems = 0; out->maxchunk = 1; out->rec_shift = rec_shift;
     out->item_lo = 0; out->item_n = 0; out->tile_lo = 0; out->tile_n = 0; out->sub_base = 0; out->sub_n = 0; out->w_lo = 0; out->w_hi = 0;
-    if (ntiles <= 0) { HIPCHK(hipMemsetAsync(nitem_w, 0, (size_t)(nW + 4) * 4 * 2, st)); return 0; }
+    if (ntiles <= 0) { HIPCHK(hipMemsetAsync(nitem_w, 0, (size_t)(nW + 4) * 4 * 3, st)); return 0; }
     hipLaunchKernelGGL(k_xt_split, dim3(1), dim3(XT_MAXRANKS + 1), 0, st, ntiles, nsub_total, tiles, nranks, sp);
-    hipLaunchKernelGGL((k_xt_items<0>), dim3((nW + 255) / 256), dim3(256), 0, st, nK, nW, kc, ntiles, toff, (const int *)nullptr, tiles, sp, nitem_w, (XItem *)nullptr);
+    hipLaunchKernelGGL((k_xt_items<0>), dim3((nW + 255) / 256), dim3(256), 0, st, nK, nW, kc, ntiles, toff, (const int *)nullptr, tiles, sp, nitem_w, (XItem *)nullptr, rec_shift);
     int rc = dkmc_exclusive_scan_i32(nitem_w, ioff, nW, ioff + nW); if (rc) return rc;
-    XItem *items = (XItem *)scratch(slot_items, (size_t)(ntiles + 1) * sizeof(XItem));      // an item holds at least one tile: no need to wait for the count
+    XItem *items = (XItem *)scratch(slot_items, (size_t)(ntiles + 4 * (size_t)nW + 4) * sizeof(XItem));      // an item holds at least one tile (+ up to 3 empty runs per strip): no need to wait for the count
     if (!items) return e.err_code;
-    hipLaunchKernelGGL((k_xt_items<1>), dim3((nW + 255) / 256), dim3(256), 0, st, nK, nW, kc, ntiles, toff, (const int *)ioff, tiles, sp, nitem_w, items);
+    hipLaunchKernelGGL((k_xt_items<1>), dim3((nW + 255) / 256), dim3(256), 0, st, nK, nW, kc, ntiles, toff, (const int *)ioff, tiles, sp, nitem_w, items, rec_shift);
     hipLaunchKernelGGL(k_xt_rank_items, dim3(1), dim3(XT_MAXRANKS + 1), 0, st, (const int *)(ioff + nW), ntiles, nsub_total, (const XItem *)items, tiles, sp);
     HIPCHK(hipMemcpyAsync(&h, sp, sizeof(XSplit), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1253,8 +1277,9 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
             hipLaunchKernelGGL(k_xt_wrange, dim3((nK + 255) / 256), dim3(256), 0, st, nK, nW, (const unsigned *)cmask, wrange);
         }
         XShare sh{};
-        rc = xt_build_items(nK, nW, X.kc, ntiles, X.nsub_total, toff, tiles, nr, me, S_XT_NITEMW, S_XT_ITEMS, S_XT_SPLIT, &sh); if (rc) return rc;
-        X.nitems = sh.nitems; X.maxchunk = sh.maxchunk;
+        rc = xt_build_items(nK, nW, X.kc, ntiles, X.nsub_total, toff, tiles, nr, me, S_XT_NITEMW, S_XT_ITEMS, S_XT_SPLIT, &sh, 2); if (rc) return rc;
+        if (nr == 1 && ((sh.item_lo | sh.item_n) & 3)) return dkmc_fail(48, "update_power: run list not padded to groups of four", __FILE__, __LINE__);
+        X.nitems = sh.nitems; X.maxchunk = sh.maxchunk; X.rec_shift = sh.rec_shift;
         items = sh.items; nitem_w = sh.nitem_w;
         KCHK();
         g_xb.tiles = tiles; g_xb.items = items; g_xb.wrange = wrange; g_xb.nitem_w = nitem_w; g_xb.cmask = cmask; g_xb.toff = toff;
@@ -1487,7 +1512,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
     }
     e.stats.X_nnz = xs_nnz + 2 * t_upper;
     e.stats.spmv_tiles = ntiles; e.stats.spmv_tile_entries = t_upper;
-    e.stats.xt_subblocks = X.nsub_total; e.stats.xt_local_subblocks = X.sub_n; e.stats.xt_items = X.nitems; e.stats.xt_kc = X.kc;
+    e.stats.xt_subblocks = X.nsub_total; e.stats.xt_local_subblocks = X.sub_n; e.stats.xt_items = X.nitems; e.stats.xt_kc = X.kc; e.stats.xt_records = X.nitems >> X.rec_shift;
     e.stats.xt_sparse_nnz = xs_nnz; e.stats.xt_ns = ns;
     e.stats.spmv_segments = 0; e.stats.spmv_segment_entries = 0;
     e.stats.spmv_long_rows = ns; e.stats.spmv_short_rows = m - ns; e.stats.spmv_long_nnz = 2 * t_upper; e.stats.spmv_short_nnz = xs_nnz;

@@ -97,6 +97,7 @@ typedef struct dkmc_stats {
     double pair_ms;
     long long pair_evaluated;              /* (site, charged site) pairs inside the screening cut-off of the last pair sum (profiling on) */
     long long pair_tested;                 /* pairs whose distance was tested (all N x N_charged without the cell list; the 3 x 3 columns with it) */
+    long long xt_records;                  /* records of column partial sums one matrix-vector product writes (= runs; runs / 4 on one GPU, where the four waves of a workgroup share one) */
 } dkmc_stats;
 
 const char *dkmc_last_error(void);

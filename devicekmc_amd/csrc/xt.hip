@@ -181,14 +181,22 @@ __global__ void k_xt_items(int nK, int nW, int kc, int ntiles, const int *__rest
     if (w >= nW) return;
     const int t0 = toff[(long long)w * nK], t1 = (w + 1 < nW) ? toff[(long long)(w + 1) * nK] : ntiles;
     int o = MODE ? ioff[w] : 0, c = 0;
-    for (int t = t0; t < t1; ++c) {
+    const int m = (1 << rec_shift) - 1;
+    for (int t = t0; t < t1;) {
         const int len = xt_run_len(t, t1, kc, sp);
         if (MODE) { const XTile f = tiles[t]; XItem it; it.t0 = t; it.t1 = t + len; it.w = w; it.c = rec_shift ? 1 : 0; it.k0 = f.k; it.mask0 = f.mask; it.soff0 = f.soff; it.pad = (o + c) >> rec_shift; items[o + c] = it; }
-        t += len;
+        t += len; ++c;
+        // the group of four is completed with empty runs at the end of the strip and where a rank's share ends inside it: the empty runs
+        // carry the index of the LAST tile before them (t0 = t1: no tile), so that they sort into the share they complete
+        bool cut = t >= t1;
+        if (!cut) for (int r = 1; r < sp->n; ++r) cut |= sp->tb[r] == t;
+        if (cut) {
+            const int cpad = (c + m) & ~m;
+            for (; c < cpad; ++c)
+                if (MODE) { XItem it; it.t0 = t - 1; it.t1 = t - 1; it.w = w; it.c = 1; it.k0 = 0; it.mask0 = 0; it.soff0 = 0; it.pad = (o + c) >> rec_shift; items[o + c] = it; }
+        }
     }
-    const int m = (1 << rec_shift) - 1, cpad = (c + m) & ~m;
-    if (MODE) for (; c < cpad; ++c) { XItem it; it.t0 = t1; it.t1 = t1; it.w = w; it.c = 1; it.k0 = 0; it.mask0 = 0; it.soff0 = 0; it.pad = (o + c) >> rec_shift; items[o + c] = it; }
-    if (!MODE) { nitem_w[w] = cpad; atomicMax(&sp->max_items_per_strip, cpad); }
+    if (!MODE) { nitem_w[w] = c; atomicMax(&sp->max_items_per_strip, c); }
 }
 // first item of every rank's share (items are in tile order and never cross a share boundary) + what the host needs of the boundary tiles
 __global__ void k_xt_rank_items(const int *__restrict__ nitems_dev, int ntiles, long long nsub_total, const XItem *__restrict__ items,
@@ -1127,7 +1135,6 @@ struct XShare { int nitems, maxchunk, item_lo, item_n, tile_lo, tile_n, w_lo, w_
 static int xt_build_items(int nK, int nW, int kc, int ntiles, long long nsub_total, const int *toff, const XTile *tiles, int nranks, int me,
                           int slot_nitemw, int slot_items, int slot_split, XShare *out, int rec_shift = 0)
 {
-    if (nranks > 1) rec_shift = 0;                 // shares are cut at tile boundaries: a rank's first run need not start a group of four
     Engine &e = eng(); hipStream_t st = e.stream;
     if (nranks > XT_MAXRANKS) return dkmc_fail(46, "update_power: more ranks than XT_MAXRANKS", __FILE__, __LINE__);
     int *nitem_w = (int *)scratch(slot_nitemw, (size_t)(nW + 4) * 4 * 3);
@@ -1141,7 +1148,7 @@ static int xt_build_items(int nK, int nW, int kc, int ntiles, long long nsub_tot
     hipLaunchKernelGGL(k_xt_split, dim3(1), dim3(XT_MAXRANKS + 1), 0, st, ntiles, nsub_total, tiles, nranks, sp);
     hipLaunchKernelGGL((k_xt_items<0>), dim3((nW + 255) / 256), dim3(256), 0, st, nK, nW, kc, ntiles, toff, (const int *)nullptr, tiles, sp, nitem_w, (XItem *)nullptr, rec_shift);
     int rc = dkmc_exclusive_scan_i32(nitem_w, ioff, nW, ioff + nW); if (rc) return rc;
-    XItem *items = (XItem *)scratch(slot_items, (size_t)(ntiles + 4 * (size_t)nW + 4) * sizeof(XItem));      // an item holds at least one tile (+ up to 3 empty runs per strip): no need to wait for the count
+    XItem *items = (XItem *)scratch(slot_items, (size_t)(ntiles + 4 * (size_t)(nW + nranks) + 4) * sizeof(XItem));      // an item holds at least one tile (+ up to 3 empty runs per strip and per share end): no need to wait for the count
     if (!items) return e.err_code;
     hipLaunchKernelGGL((k_xt_items<1>), dim3((nW + 255) / 256), dim3(256), 0, st, nK, nW, kc, ntiles, toff, (const int *)ioff, tiles, sp, nitem_w, items, rec_shift);
     hipLaunchKernelGGL(k_xt_rank_items, dim3(1), dim3(XT_MAXRANKS + 1), 0, st, (const int *)(ioff + nW), ntiles, nsub_total, (const XItem *)items, tiles, sp);
@@ -1278,7 +1285,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         }
         XShare sh{};
         rc = xt_build_items(nK, nW, X.kc, ntiles, X.nsub_total, toff, tiles, nr, me, S_XT_NITEMW, S_XT_ITEMS, S_XT_SPLIT, &sh, 2); if (rc) return rc;
-        if (nr == 1 && ((sh.item_lo | sh.item_n) & 3)) return dkmc_fail(48, "update_power: run list not padded to groups of four", __FILE__, __LINE__);
+        if ((sh.item_lo | sh.item_n) & 3) return dkmc_fail(48, "update_power: run list not padded to groups of four", __FILE__, __LINE__);
         X.nitems = sh.nitems; X.maxchunk = sh.maxchunk; X.rec_shift = sh.rec_shift;
         items = sh.items; nitem_w = sh.nitem_w;
         KCHK();
@@ -1556,7 +1563,8 @@ extern "C" int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_
     const int kc = std::max(1, std::min(XT_MAXKC, ntiles / nranks / 4096));
     XShare sh{};
     int rc = xt_build_items(nK, nW, kc, ntiles, X.nsub_total, (const int *)g_xb.toff, (const XTile *)g_xb.tiles, nranks, rank,
-                            S_XT_T_NITEMW, S_XT_T_ITEMS, S_XT_T_SPLIT, &sh);
+                            S_XT_T_NITEMW, S_XT_T_ITEMS, S_XT_T_SPLIT, &sh, 2);
+    if (!rc && ((sh.item_lo | sh.item_n) & 3)) rc = dkmc_fail(48, "xt_time_share: run list not padded to groups of four", __FILE__, __LINE__);
     if (rc) return rc;
     const int item_n = sh.item_n, i0 = sh.item_lo;
     const XItem *items = sh.items; const int *nitem_w = sh.nitem_w;
@@ -1676,8 +1684,9 @@ extern "C" int dkmc_xt_check_shares(int nranks, double *max_abs_diff, double *ma
     for (int r = 0; r < nranks; ++r) {
         XShare sh{};
         rc = xt_build_items(nK, nW, kc, ntiles, X.nsub_total, (const int *)g_xb.toff, (const XTile *)g_xb.tiles, nranks, r,
-                            S_XT_T_NITEMW, S_XT_T_ITEMS, S_XT_T_SPLIT, &sh);
+                            S_XT_T_NITEMW, S_XT_T_ITEMS, S_XT_T_SPLIT, &sh, 2);
         if (rc) return rc;
+        if ((sh.item_lo | sh.item_n) & 3) return dkmc_fail(48, "xt_check_shares: run list not padded to groups of four", __FILE__, __LINE__);
         if (items_total) *items_total = sh.nitems;
         sb_sum += sh.sub_n; it_sum += sh.item_n;
         double *colpart = (double *)scratch(S_XT_T_COLPART, (size_t)(sh.nitems + 1) * XT_C * 8);

@@ -216,7 +216,8 @@ def test_emulated_shares_cover_the_tunnelling_block():
     assert 0 < small[3]["spmv_tiles"] < 64
     md, ma, sb, its, itot = C.c_double(), C.c_double(), C.c_longlong(), C.c_longlong(), C.c_int()
     lib.check(L.dkmc_xt_check_shares(64, C.byref(md), C.byref(ma), C.byref(sb), C.byref(its), C.byref(itot)))
-    assert sb.value == small[3]["xt_subblocks"] and its.value == itot.value == small[3]["spmv_tiles"]
+    # work items = the 32 single-tile runs + the empty runs that complete every group of four at strip and share ends
+    assert sb.value == small[3]["xt_subblocks"] and its.value == itot.value >= small[3]["spmv_tiles"] and itot.value % 4 == 0
     assert md.value <= 1e-12 * ma.value
 
 

@@ -211,6 +211,9 @@ def rooflines(sim, local_share=1.0):
             "tiles": int(st["spmv_tiles"]), "tile_entries": int(st["spmv_tile_entries"]), "subblocks": int(st["xt_subblocks"]),
             "local_subblocks": int(st["xt_local_subblocks"]), "tile_runs": int(st["xt_items"]),
             "row_kernel_us": round(pr["short_ms"] / max(pr["short_n"], 1) * 1e3, 2)}
+        if bytes_per_launch >= 256.0 * 2 ** 20:
+            out["roofline"]["note"] = ("frac is against the 8 TB/s spec peak (the contract's ceiling); MI355X_MICROARCH.md measures 6.3 TB/s for a float4 copy and "
+                                       "6.5-6.8 TB/s for a non-temporal read stream: against 6.8 TB/s this launch is at %.2f" % (achieved / 6800.0))
         if bytes_per_launch < 256.0 * 2 ** 20:
             # the contract's ceiling is the HBM peak; a sweep this small is served by the 256 MiB Infinity Cache (MI355X_MICROARCH.md: 7.4-7.9 TB/s
             # gather rate measured), and the launch is one wave generation long: ramp and drain, not bandwidth, set its time

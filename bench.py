@@ -487,6 +487,19 @@ def main():
     ap.add_argument("--timeout", type=float, default=570.0, help="watchdog [s]: exit 3 if the run has not finished (a rank stuck in a collective cannot be unwound)")
     args = ap.parse_args()
 
+    # ---- `python bench.py --gpus N` with N > 1 and no rank environment: start the N ranks ourselves (one process per GPU), BEFORE anything
+    # touches the GPU in this process; relay rank 0's JSON line as the last line of stdout and leave with the child's exit code ----
+    if args.gpus > 1 and "RANK" not in os.environ:
+        from devicekmc_amd import launch
+        sys.exit(launch.run_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        # never a silent N = 1 line under --gpus N (or the reverse): the line would be read as an N-GPU measurement
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"metric": "KMC steps/sec", "value": None, "n_gpus": world_env,
+                              "error": "--gpus %d but the process group has WORLD_SIZE=%d ranks" % (args.gpus, world_env)}), flush=True)
+        sys.exit(5)
+
     import torch
     from devicekmc_amd import parallel
     # rehearsal on a one-GPU box: DKMC_BENCH_BACKEND=gloo DKMC_BENCH_SINGLE_DEVICE=1 lets several ranks share cuda:0
@@ -656,6 +669,12 @@ def main():
         roofs = rooflines(sim, local_share=share if args.mode == "sharded" else 1.0)
         traces = [None] * world
         dist.all_gather_object(traces, sim.trace)
+        # how many ranks the in-library communicator of the sharded solve actually holds (dkmc_comm_info), from every rank
+        import ctypes as _C
+        _n, _r, _t = _C.c_int(0), _C.c_int(0), _C.c_int(0)
+        sim.L.dkmc_comm_info(_C.byref(_n), _C.byref(_r), _C.byref(_t))
+        infos = [None] * world
+        dist.all_gather_object(infos, (_n.value, _r.value, _t.value))
         agree = all(t == traces[0] for t in traces)
         if rank == 0:
             sharded = args.mode == "sharded"
@@ -667,7 +686,9 @@ def main():
                            "phases": "charge+potential+rates+current+heat",
                            "parallelism": ("one simulation; X generated/stored/streamed in %d per-rank shares, 1 all-reduce of |S| doubles per CG iteration"
                                            if sharded else "replicas x%d") % world,
-                           "transport": transport, "transport_note": transport_note, "x_format": "tiled", "current_warm_start": 0, "cg_tol": sim.p.cg_tol},
+                           "transport": transport, "transport_note": transport_note, "x_format": "tiled", "current_warm_start": 0, "cg_tol": sim.p.cg_tol,
+                           "comm_ranks": min(i[0] for i in infos), "comm_rank_ids": sorted(i[1] for i in infos),
+                           "comm_transport_code": sorted(set(i[2] for i in infos)), "process_group_world": world, "process_group_backend": backend},
                 "split_ms": res["split_ms"], "per_step": res["per_step"], "cpu_baseline": None,
                 "sharding": {"ranks_agree_bitwise": bool(agree) if sharded else None, "subblocks_total": int(st["xt_subblocks"]),
                              "subblocks_rank0": int(st["xt_local_subblocks"]), "rank0_share": round(share, 4),
@@ -692,6 +713,8 @@ def main():
             out.update(roofs)
             if sharded and not agree:
                 out["error"] = "ranks disagree"
+            if sharded and min(i[0] for i in infos) != world:
+                out["error"] = "the solver communicator holds %d ranks, the process group %d" % (min(i[0] for i in infos), world)
         if args.mode == "sharded":
             parallel.detach_solver_comm()
         sim.close()

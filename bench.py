@@ -45,7 +45,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (half the 157.3 TF f32 vector rate of MI355X_MICROARCH.md)
 VD = 5.0
-X_LOOP = 0                     # dkmc_set_x_loop (set from --x-loop)
+X_BLOCK = 1                    # dkmc_set_x_block (set from --x-block)
 
 
 def make_workload(name):
@@ -188,7 +188,7 @@ def rooflines(sim, local_share=1.0):
             # read once for both triangles; 16 B descriptor and 32 row sums written per tile; 32 B descriptor and 256 column sums
             # per run) plus, in the same launch, the neighbour part Xs in CSR form (12 B per non-zero; per row 8 B row pointer,
             # 8 B result, 8 B scale, 4 B class).  In a sharded solve these are THIS rank's tiles.
-            kname = "k_xt_apply2" if (X_LOOP and not st["comm_ranks"]) else "k_xt_apply"
+            kname = "k_xt_apply"
             bytes_per_launch = (8192.0 * st["xt_local_subblocks"] + (16.0 + 256.0) * st["spmv_tiles"] * local_share
                                 + 32.0 * (st["comm_local_segments"] if st["comm_ranks"] else st["xt_items"])
                                 + 2048.0 * (st["comm_local_segments"] if st["comm_ranks"] else (st["xt_records"] or st["xt_items"]))
@@ -394,7 +394,7 @@ def pmc_traffic(workload, kernel_prefix, x_format, cg_tol=None):
         d = tempfile.mkdtemp(prefix="dkmc_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
                sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
-               "--scale-points", "none", "--no-alt", "--no-pmc", "--no-cpp-host", "--no-log-tolerance", "--x-format", str(x_format), "--x-loop", str(X_LOOP)]
+               "--scale-points", "none", "--no-alt", "--no-pmc", "--no-cpp-host", "--no-log-tolerance", "--x-format", str(x_format), "--x-block", str(X_BLOCK)]
         if cg_tol is not None:      # bytes per launch do not depend on how many iterations the solve takes: a loose tolerance shortens the (serialised) counter run
             cmd += ["--cg-tol", repr(cg_tol)]
         try:
@@ -481,7 +481,7 @@ def main():
     ap.add_argument("--no-cpp-host", action="store_true", help="N = 1: skip the cross-check line through the C++ host driver")
     ap.add_argument("--no-pmc", action="store_true", help="N = 1: do not measure roofline.traffic (two rocprofv3 --pmc child runs)")
     ap.add_argument("--no-log-tolerance", action="store_true", help="N = 1: skip the at_log_tolerance block")
-    ap.add_argument("--x-loop", type=int, default=0, help="dkmc_set_x_loop: 0 = three launches per CG iteration on X (default), 1 = two (measured slower)")
+    ap.add_argument("--x-block", type=int, default=1, help="dkmc_set_x_block: 1 = the reference's single-vector CG on X, 2..16 = block-CG width")
     ap.add_argument("--cg-tol", type=float, default=None, help="override the CG tolerance (default: the reference's 1e-6)")
     ap.add_argument("--budget", type=float, default=420.0, help="time budget [s] for the timed steps of seconds-per-step workloads")
     ap.add_argument("--timeout", type=float, default=570.0, help="watchdog [s]: exit 3 if the run has not finished (a rank stuck in a collective cannot be unwound)")
@@ -512,9 +512,9 @@ def main():
     red_dev = devname if backend == "nccl" else "cpu"
     wd = arm_watchdog(args.timeout, rank, "bench.py")
     from devicekmc_amd import lib as _dlib
-    global X_LOOP
-    X_LOOP = args.x_loop
-    _dlib.load().dkmc_set_x_loop(args.x_loop)
+    global X_BLOCK
+    X_BLOCK = args.x_block
+    _dlib.load().dkmc_set_x_block(args.x_block)
     ncores = min(16, os.cpu_count() or 1)         # the box's CPU share for one GPU; more threads only add contention
     out = None
 
@@ -547,7 +547,7 @@ def main():
             "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": name, "sites": res["sites"], "nn": res["nn"], "atoms": res["atoms"], "Vd": VD,
                        "phases": "charge+potential+rates+current+heat", "parallelism": "single GPU", "x_format": "tiled" if args.x_format else "csr",
-                       "current_warm_start": args.warm_start, "cg_tol": sim.p.cg_tol, "x_loop": "two launches per CG iteration" if args.x_loop else "three launches per CG iteration"},
+                       "current_warm_start": args.warm_start, "cg_tol": sim.p.cg_tol, "x_block": args.x_block},
             "split_ms": res["split_ms"], "per_step": res["per_step"], "cpu_baseline": cpu, "alt_warm_start": alt, "cpp_host_crosscheck": cpp,
         }
         if n != args.steps:

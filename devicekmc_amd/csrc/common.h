@@ -106,7 +106,7 @@ struct Engine {
     int cb_edge_domain = 0;        // 0: CB-edge system over every site (snapshot source); 1: over atoms only (dkmc_set_cb_edge_domain)
     long long tcache_budget = -1;  // bytes the tunnelling-coefficient cache may take; -1 = a third of the free device memory, 8-128 GiB (dkmc_set_tcache_budget)
     double pair_cut = 6.5;         // screening cut-off of the pair sum in units of sigma sqrt 2 (dkmc_set_pair_cutoff; 0 = all pairs like the reference)
-    int x_loop = 0;                // CG loop on the tiled X, one GPU: 0 = three launches per iteration (apply, rows, step; default), 1 = two (k_xt_apply2 + k_xt_fold_step: measured slower)
+    int x_block = 1;               // block-CG width of the current solve on the tiled X (dkmc_set_x_block): 1 = the reference's single-vector loop, 2 ... 16 = block-CG (xtb.hip)
     int x_format = 1;              // 1: tiled X (xt.hip, default); 0: CSR X as the reference stores it (current.hip + cg.hip)
     int x_iter_hint = 0;           // iteration count of the previous CG solve of X (sizes the first launch batch)
     dkmc_stats stats{};
@@ -144,7 +144,7 @@ enum {
     S_XT_DPOS, S_XT_SNODE_D, S_XT_SNODE_I, S_XT_CMASK, S_XT_ISTILE, S_XT_NSUBC, S_XT_TOFF, S_XT_SOFF, S_XT_TILES, S_XT_NITEMW, S_XT_WRANGE,
     S_XT_ITEMS, S_XT_SPLIT, S_XT_TVAL, S_XT_ROWPART, S_XT_COLPART, S_XT_CNT, S_XT_Q,
     S_XT_T_NITEMW, S_XT_T_ITEMS, S_XT_T_SPLIT, S_XT_T_COLPART, S_XT_T_MISC,
-    S_XT_UV, S_XT_UVS, S_XT_PPART,
+    S_XTB_PANELS, S_XTB_QS, S_XTB_ROWPART, S_XTB_COLPART, S_XTB_GRAM, S_XTB_SMALL,
     S_NSLOTS
 };
 

@@ -22,34 +22,11 @@
 // Multi-GPU (comm.hip): work items are dealt to the ranks in contiguous, byte-balanced shares (runs shrink towards the end of a
 // share); a rank generates, stores and streams only its tiles; one all-reduce of |S| + 1 doubles per matrix-vector product
 // completes the rows, with the neighbour part on a second stream beside it; results are re-published from rank 0.
-#include "xshared.h"
+#include "xtiles.h"
 #include <hip/hip_ext.h>
 #include <vector>
 #include <algorithm>
 #include <stdlib.h>
-
-#define XT_R 32                      // S-rows per tile
-#define XT_C 256                     // S-columns per tile
-#define XT_SBW 32                    // columns per sub-block
-#define XT_SUB (XT_R * XT_SBW)       // doubles per sub-block (8 KiB)
-#define XT_NT 256
-#define XT_MAXKC 16
-#define XT_PROF_STRIDE 8
-
-typedef double dbl2 __attribute__((ext_vector_type(2)));
-
-struct __attribute__((aligned(16))) XTile { int k, w; unsigned mask; int soff; };   // cell (k, w); present sub-blocks; first sub-block slot
-struct __attribute__((aligned(32))) XItem { int t0, t1, w, c, k0; unsigned mask0; int soff0, pad; };   // tiles [t0, t1) of strip w; c = position of the run in its strip; descriptor of tile t0; pad = record of its column sums, colpart[pad * 256]: the run's own (c = 0; pad = its index in the item list) or, on one GPU, one record per aligned group of four runs -- the four waves of a workgroup (c = 1; pad = index / 4; every strip's run count padded to a multiple of four with empty runs)
-struct XCtrl { double rr[2]; int done_local, sharded; int done; int iters; int abort_local, aborted; int pad[2]; };
-// `done` (non-zero) gates every kernel of the loop; see k_xt_step for its iteration stamp.  Single GPU: set by the step kernel.  Sharded solve: the direction kernel only sets
-// done_local; rank 0's done_local travels in the all-reduced buffer (slot ns) and k_xt_rows_apply turns it into `done` on every
-// rank in the same iteration -- all control flow derives from data every rank received from the same collective, so the ranks
-// cannot leave the loop at different iterations even if their arithmetic differed in a bit.
-
-struct SNodes {                      // S in rank order, padded to a multiple of XT_C (flag 0 = no entries)
-    const double *x, *y, *z, *cb;
-    const int *flag, *slot, *mr;     // class flags; row of the coefficient cache (vacancies) / column (metals), -1 if none
-};
 
 // value of the tunnelling entry between two members of S (0 = no entry); symmetric in its two atoms bit for bit
 __device__ __forceinline__ double xt_tvalue(const XParams &P, double prefac, const TCacheView &TC,
@@ -275,14 +252,10 @@ __device__ __forceinline__ void xt_acc(const dbl2 v, const double pcx, const dou
 // One work item.  Lane (rr = lane / 16, cc = lane % 16) owns rows 4 j + rr (j = 0..7) and the column pair 2 cc, 2 cc + 1 of every
 // sub-block.  Per sub-block: 8 loads of 1 KiB per wave (two sub-blocks in flight), row sums accumulate in registers over the
 // tile, the two column sums are combined over rr and added to the wave's 256 column accumulators in LDS (lcol).
-// UV = 1 (two-launch CG loop, k_xt_apply2): the vector is formed on the fly, q = beta * vS - vS2 (vS = S p of the previous direction, vS2 = S r),
-// and *ptacc collects this wave's share of q' T q (the tile part of p.Ap): sum over its tiles of q_row * (partial row sum), every entry
-// of the stored upper triangle counted once.
-template <int OP, int NTL, int UV = 0>
+template <int OP, int NTL>
 __device__ __forceinline__ void xt_tile_role(const XItem it, const XTile *__restrict__ tiles, int sub_base, const double *__restrict__ tval,
                                              const double *__restrict__ vS, int nW, int ns_pad, double *__restrict__ rowpart,
-                                             double *__restrict__ colpart, bool vpos, double *lcol, double *lq,
-                                             const double *__restrict__ vS2 = nullptr, double beta = 0.0, double *ptacc = nullptr)
+                                             double *__restrict__ colpart, bool vpos, double *lcol, double *lq)
 {
     // it.c != 0: the four waves of this workgroup hold runs of one strip and write ONE record (lcol = this wave's 512 doubles of
     // lcol_all[4][512]; the caller guarantees that all four waves get here: the item count is a multiple of four)
@@ -301,12 +274,7 @@ __device__ __forceinline__ void xt_tile_role(const XItem it, const XTile *__rest
     // lgkmcnt, so waiting for them never drains the tile stream (vmcnt)
     {
         const dbl2 *src = reinterpret_cast<const dbl2 *>(vS + (size_t)it.w * XT_C) + 2 * lane;
-        dbl2 q0 = src[0], q1 = src[1];
-        if (UV) {
-            const dbl2 *src2 = reinterpret_cast<const dbl2 *>(vS2 + (size_t)it.w * XT_C) + 2 * lane;
-            const dbl2 r0 = src2[0], r1 = src2[1];
-            q0.x = beta * q0.x - r0.x; q0.y = beta * q0.y - r0.y; q1.x = beta * q1.x - r1.x; q1.y = beta * q1.y - r1.y;
-        }
+        const dbl2 q0 = src[0], q1 = src[1];
         dbl2 z; z.x = 0.0; z.y = 0.0;
         reinterpret_cast<dbl2 *>(lcol)[2 * lane] = z; reinterpret_cast<dbl2 *>(lcol)[2 * lane + 1] = z;
         reinterpret_cast<dbl2 *>(lq)[2 * lane] = q0; reinterpret_cast<dbl2 *>(lq)[2 * lane + 1] = q1;
@@ -331,11 +299,6 @@ __device__ __forceinline__ void xt_tile_role(const XItem it, const XTile *__rest
         double pr[8], ra[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) { pr[j] = vr[4 * j]; ra[j] = 0.0; }
-        if (UV) {
-            const double *vr2 = vS2 + (size_t)td.k * XT_R + rr;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pr[j] = beta * pr[j] - vr2[4 * j];
-        }
         const dbl2 *base = reinterpret_cast<const dbl2 *>(tval + (size_t)(td.soff - sub_base) * XT_SUB) + lane;
         if (td.mask == 0xffu) {
             // full tile: 64 KiB contiguous, two sub-blocks (16 KiB) in flight per wave
@@ -361,12 +324,6 @@ __device__ __forceinline__ void xt_tile_role(const XItem it, const XTile *__rest
                 XT_SUBBLOCK(va, q)
                 ++sl;
             }
-        }
-        if (UV) {
-            double a_ = 0.0;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a_ += pr[j] * ra[j];
-            *ptacc += a_;
         }
         // 8 row sums per lane -> 32 row sums of the tile: butterfly over the 16 lanes that share rr (bits 3, 2, 1 of the lane
         // select which half survives, bit 0 completes the sum); fixed order
@@ -413,15 +370,11 @@ __device__ __forceinline__ void xt_tile_role(const XItem it, const XTile *__rest
 #endif
 // The neighbour part Xs of the product.  bid < nsb: atom rows, 8 lanes per row; bid = nsb, nsb + 1: the two driver rows (one
 // workgroup each).
-// UV = 1 (two-launch CG loop): q[c] = beta * q[c] - V[c] on the fly; ctrl is not read (the caller has taken the stop decision); the
-// return value is this thread's share of q' Xs q (q_row * unscaled row sum, lanes l == 0 / thread 0 only).
-template <int RPG, int UV = 0>
-__device__ __forceinline__ double xt_neigh_roles(int bid, int nsb, int Nsub, const xrp_t *__restrict__ rp, const int *__restrict__ ci,
+template <int RPG>
+__device__ __forceinline__ void xt_neigh_roles(int bid, int nsb, int Nsub, const xrp_t *__restrict__ rp, const int *__restrict__ ci,
                                                  const double *__restrict__ val, const double *__restrict__ q, const double *__restrict__ sc,
-                                                 const int *__restrict__ nsrank, const XCtrl *ctrl, double *__restrict__ t, double *red,
-                                                 const double *__restrict__ V = nullptr, double beta = 0.0)
+                                                 const int *__restrict__ nsrank, const XCtrl *ctrl, double *__restrict__ t, double *red)
 {
-    double pt = 0.0;
     if (bid < nsb) {
         // 8 lanes per row, RPG rows per lane group.  The first 32 entries of all RPG rows (every entry of an ordinary atom row) are
         // fetched together, each level of the dependent chain -- row pointers -> values / columns -> q -- issued for all rows
@@ -437,12 +390,7 @@ __device__ __forceinline__ double xt_neigh_roles(int bid, int nsb, int Nsub, con
             const bool ok = row < Nsub;
             p0[j] = ok ? rp[row] : 0; p1[j] = ok ? rp[row + 1] : 0; sr[j] = ok ? nsrank[row] : 0; scale[j] = ok ? sc[row] : 0.0;
         }
-        if (!UV && ctrl->done) return 0.0;
-        double qrow[RPG];
-        if (UV) {
-#pragma unroll
-            for (int j = 0; j < RPG; ++j) { const int row = base + j * (XT_NT / 8); qrow[j] = (l == 0 && row < Nsub) ? beta * q[row] - V[row] : 0.0; }
-        }
+        if (ctrl->done) return;
         double v[RPG][4]; int c[RPG][4];
 #pragma unroll
         for (int j = 0; j < RPG; ++j)
@@ -453,17 +401,6 @@ __device__ __forceinline__ double xt_neigh_roles(int bid, int nsb, int Nsub, con
         for (int j = 0; j < RPG; ++j)
 #pragma unroll
             for (int u = 0; u < 4; ++u) x[j][u] = q[c[j][u]];
-        if (UV) {
-            double x2[RPG][4];
-#pragma unroll
-            for (int j = 0; j < RPG; ++j)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) x2[j][u] = V[c[j][u]];
-#pragma unroll
-            for (int j = 0; j < RPG; ++j)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) x[j][u] = beta * x[j][u] - x2[j][u];
-        }
 #pragma unroll
         for (int j = 0; j < RPG; ++j) {
             const int row = base + j * (XT_NT / 8);
@@ -474,29 +411,23 @@ __device__ __forceinline__ double xt_neigh_roles(int bid, int nsb, int Nsub, con
                 for (int u = 0; u < 4; ++u) { const xrp_t p = pb + 8 * u; const bool ok = p < p1[j]; vv[u] = ok ? val[p] : 0.0; cc[u] = ok ? ci[p] : 0; }
                 double xx[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) xx[u] = UV ? beta * q[cc[u]] - V[cc[u]] : q[cc[u]];
+                for (int u = 0; u < 4; ++u) xx[u] = q[cc[u]];
                 s += (vv[0] * xx[0] + vv[1] * xx[1]) + (vv[2] * xx[2] + vv[3] * xx[3]);
             }
             s += __shfl_xor(s, 4, 8); s += __shfl_xor(s, 2, 8); s += __shfl_xor(s, 1, 8);
-            if (l == 0 && row < Nsub) { t[row] = sr[j] < 0 ? scale[j] * s : s; if (UV) pt += qrow[j] * s; }
+            if (l == 0 && row < Nsub) t[row] = sr[j] < 0 ? scale[j] * s : s;
         }
-        return pt;
+        return;
     }
-    if (!UV && ctrl->done) return 0.0;
+    if (ctrl->done) return;
     const int row = bid - nsb;                                      // 0 or 1
     const xrp_t p0 = rp[row], p1 = rp[row + 1];
     double s0 = 0.0, s1 = 0.0;
     xrp_t p = p0 + threadIdx.x;
-    if (UV) {
-        for (; p + XT_NT < p1; p += 2 * XT_NT) { const int c0 = ci[p], c1 = ci[p + XT_NT]; s0 += val[p] * (beta * q[c0] - V[c0]); s1 += val[p + XT_NT] * (beta * q[c1] - V[c1]); }
-        if (p < p1) { const int c0 = ci[p]; s0 += val[p] * (beta * q[c0] - V[c0]); }
-    } else {
-        for (; p + XT_NT < p1; p += 2 * XT_NT) { s0 += val[p] * q[ci[p]]; s1 += val[p + XT_NT] * q[ci[p + XT_NT]]; }
-        if (p < p1) s0 += val[p] * q[ci[p]];
-    }
+    for (; p + XT_NT < p1; p += 2 * XT_NT) { s0 += val[p] * q[ci[p]]; s1 += val[p + XT_NT] * q[ci[p + XT_NT]]; }
+    if (p < p1) s0 += val[p] * q[ci[p]];
     const double s = block_sum_all<XT_NT>(s0 + s1, red);
-    if (threadIdx.x == 0) { t[row] = sc[row] * s; if (UV) pt = (beta * q[row] - V[row]) * s; }
-    return pt;
+    if (threadIdx.x == 0) t[row] = sc[row] * s;
 }
 // Blocks 0, 1: the two driver rows (thousands of entries each: the longest dependent chain of the launch starts first).  Blocks
 // [2, 2 + ntb): tile work items (one per wave).  The rest: the atom rows of Xs, 8 lanes per row, one row per group (no barrier,
@@ -549,108 +480,6 @@ __global__ __launch_bounds__(XT_NT) void k_xt_neigh(int nsb, int Nsub, const xrp
     __shared__ double red[XT_NT / 64];
     const int vb = (int)blockIdx.x;
     xt_neigh_roles<1>(vb < 2 ? nsb + vb : vb - 2, nsb, Nsub, rp, ci, val, q, sc, nsrank, ctrl, t, red);
-}
-// ---- two launches per CG iteration (single GPU; dkmc_set_x_loop(1), NOT the default: measured slower, see the end of this comment) ----
-// Iteration k of solve_sparse_CG_Jacobi (iterative_solvers_gpu.cu:405-455): t = A p_k; alpha = r.r / p.t; y += alpha p; r' = r + alpha t;
-// beta = r'.r' / r.r; p' = beta p - r'.  The reference needs the two dot products as host-synchronised reductions; the three-launch
-// loop above (product, row sums + dots, vector step) needs the second one -- r'.r', wanted for beta before r' exists everywhere -- as a
-// recurrence.  Here the loop is cut where the data dependencies allow a cut without any reduction on the critical path:
-//   k_xt_apply2(k)    every wave first sums the r.r partials of the two previous fold/step launches (fixed order, every wave the same
-//                     bits): beta_k and the stop test, uniform over the launch without a flag.  The direction is not stored yet:
-//                     the product is taken of q = S p_k = beta_k U - V formed on the fly (U = S p_{k-1}, V = S r_k, written by the
-//                     previous fold/step launch).  p_k.t = q' X q is bilinear in what the product already holds: every tile wave adds
-//                     q_row * (partial row sum) over its tiles (each stored entry of the upper triangle once, doubled at the end), every
-//                     neighbour row q_row * (row sum): one partial per workgroup, no fold needed for alpha.
-//   k_xt_fold_step(k) alpha_k from those partials; per S row block the fold of the tile partial sums (as k_xt_rows), then for every row
-//                     p_k = beta_k p_{k-1} - r_k (stored now), y += alpha p_k, r_{k+1} = r_k + alpha t, U = S p_k, V = S r_{k+1} and the DIRECT
-//                     partial sums of r_{k+1}^2 for the next beta.
-// Both dot products are direct sums like the reference's (no recurrence), and one kernel boundary per iteration is gone.  Results equal
-// the three-launch loop to rounding.  MEASURED (MI355X, same box, bench.py --x-loop 0 / 1): 85 071 sites 24.0 + 6.3 + 5.4 us per iteration
-// (three launches) against 32.2 + 13.4 us (two): 39.1 against 31.1 steps/s; 234 975 sites 612 against 717 ms per step.  The boundary that
-// disappears costs less than what the two remaining kernels gain in dependent latency (the scalar reductions in front of every wave, the
-// second vector stream of the on-the-fly direction, seven stores per row in the fold kernel).  Kept as a tested alternative, off by default.
-#define XT_RRS 1024              // distance between the three r.r partial arrays of the two-launch loop
-__device__ __forceinline__ double xt_wave_total(const double *__restrict__ part, int n)
-{
-    double s = 0.0;
-    for (int i = threadIdx.x & 63; i < n; i += 64) s += part[i];
-    return wave_sum_all(s);
-}
-// beta and the stop test of iteration it (first test on ||r||, later ones on ||r||^2, both against tol^2: iterative_solvers_gpu.cu:418,448)
-// ctrl->done makes the stop sticky: the launches the host has enqueued beyond the converging iteration find the partial arrays of the
-// rotation stale.  It is written by workgroup 0 of the k_xt_apply2 launch that detects convergence; a workgroup of that same launch that
-// already sees it has reached the same verdict from the partial sums (no decision depends on the timing of the write).
-__device__ __forceinline__ void xt_iter_head(const double *__restrict__ part_rr, int it, int n_cur, int n_prev, double tol2, double &beta, double &rr, bool &stop,
-                                             const XCtrl *ctrl)
-{
-    const int was_done = ctrl->done;
-    // three partial arrays in rotation: the fold/step launch of iteration it reads those of it and it - 1 while its own workgroups
-    // already write those of it + 1
-    rr = xt_wave_total(part_rr + XT_RRS * (it % 3), n_cur);
-    if (it == 0) { beta = 0.0; stop = !(sqrt(rr) > tol2); }
-    else { const double rr_old = xt_wave_total(part_rr + XT_RRS * ((it + 2) % 3), n_prev); beta = rr / rr_old; stop = !(rr > tol2); }
-    if (was_done) stop = true;
-}
-// workgroup roles as in k_xt_apply (vb0: role offset of the first workgroup; a multi-GB sweep launches the tile roles alone, vb0 = 2, nsb = 0,
-// and the neighbour part as k_xt_neigh2).  ppart: [0, ntb) tile workgroups, [ntb, ntb + nsb) neighbour workgroups, then the two driver rows.
-template <int NTL>
-__global__ __launch_bounds__(XT_NT) void k_xt_apply2(int nitems, const XItem *__restrict__ items, const XTile *__restrict__ tiles, int sub_base,
-                                                     const double *__restrict__ tval, const double *__restrict__ US, const double *__restrict__ VS,
-                                                     int nW, int ns_pad, double *__restrict__ rowpart, double *__restrict__ colpart, XCtrl *ctrl,
-                                                     int ntb, int nsb, int Nsub, const xrp_t *__restrict__ rp, const int *__restrict__ ci,
-                                                     const double *__restrict__ val, const double *__restrict__ U, const double *__restrict__ V,
-                                                     const double *__restrict__ sc, const int *__restrict__ nsrank, double *__restrict__ t, int vb0,
-                                                     const double *__restrict__ part_rr, int it, int n_cur, int n_prev, double tol2, double *__restrict__ ppart)
-{
-    __shared__ double red[XT_NT / 64];
-    __shared__ __attribute__((aligned(16))) double lcol[XT_NT / 64][2 * XT_C];
-    const int vb = (int)blockIdx.x + vb0;
-    int tile_idx = -1, nb_idx = -1;
-    if (vb >= 2) {
-        const int i = vb - 2, nmix = NTL ? 0 : (min(ntb, nsb) >> 3) << 3;
-        if (i < 2 * nmix) { const int grp = i >> 3, idx = ((grp >> 1) << 3) + (i & 7); if (grp & 1) nb_idx = idx; else tile_idx = idx; }
-        else { const int j = i - 2 * nmix; if (j < ntb - nmix) tile_idx = nmix + j; else nb_idx = nmix + j - (ntb - nmix); }
-    }
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    XItem itm{};
-    int item = 0;
-    if (tile_idx >= 0) { item = tile_idx * (XT_NT / 64) + wv; itm = items[min(item, nitems - 1)]; }      // in flight behind the partial sums
-    double beta, rr; bool stop;
-    xt_iter_head(part_rr, it, n_cur, n_prev, tol2, beta, rr, stop, ctrl);
-    if (blockIdx.x == 0 && threadIdx.x == 0 && !ctrl->done) {       // rr / iters: for the host's poll only
-        ctrl->rr[0] = rr; ctrl->rr[1] = rr; ctrl->iters = it;
-        if (stop) ctrl->done = 1;
-    }
-    if (stop) return;
-    if (tile_idx >= 0) {
-        double pt = 0.0;
-        if (item < nitems)
-            xt_tile_role<0, NTL, 1>(itm, tiles, sub_base, tval, US, nW, ns_pad, rowpart, colpart, true, lcol[wv], lcol[wv] + XT_C, VS, beta, &pt);
-        const double tot = block_sum_all<XT_NT>(pt, red);
-        if (threadIdx.x == 0) ppart[tile_idx] = 2.0 * tot;         // upper triangle stored: every pair counted once
-        return;
-    }
-    const int role = vb < 2 ? nsb + vb : nb_idx;
-    const double pt = xt_neigh_roles<XT_RPG_FUSED, 1>(role, nsb, Nsub, rp, ci, val, U, sc, nsrank, nullptr, t, red, V, beta);
-    if (role < nsb) { const double tot = block_sum_all<XT_NT>(pt, red); if (threadIdx.x == 0) ppart[ntb + role] = tot; }
-    else if (threadIdx.x == 0) ppart[ntb + role] = pt;
-}
-// the neighbour part alone, behind a tiles-only k_xt_apply2 (multi-GB sweeps: see k_xt_neigh)
-__global__ __launch_bounds__(XT_NT) void k_xt_neigh2(int nsb, int Nsub, const xrp_t *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ val,
-                                                     const double *__restrict__ U, const double *__restrict__ V, const double *__restrict__ sc,
-                                                     const int *__restrict__ nsrank, double *__restrict__ t,
-                                                     const double *__restrict__ part_rr, int it, int n_cur, int n_prev, double tol2, double *__restrict__ ppart_nb,
-                                                     const XCtrl *ctrl)
-{
-    __shared__ double red[XT_NT / 64];
-    const int vb = (int)blockIdx.x;
-    double beta, rr; bool stop;
-    xt_iter_head(part_rr, it, n_cur, n_prev, tol2, beta, rr, stop, ctrl);
-    if (stop) return;
-    const int role = vb < 2 ? nsb + vb : vb - 2;
-    const double pt = xt_neigh_roles<1, 1>(role, nsb, Nsub, rp, ci, val, U, sc, nsrank, nullptr, t, red, V, beta);
-    if (role < nsb) { const double tot = block_sum_all<XT_NT>(pt, red); if (threadIdx.x == 0) ppart_nb[role] = tot; }
-    else if (threadIdx.x == 0) ppart_nb[role] = pt;
 }
 // tiles only (diagonal pass with q = 1, power pass with q = m)
 template <int OP>
@@ -808,80 +637,6 @@ __global__ __launch_bounds__(XT_NT) void k_xt_rows(int ns, int nK, int nW, int n
     for (int i = ifirst + XT_NT; i < i1; i += XT_NT) if (nsrank[i] < 0) { const double tv = t[i]; acc += pvec[i] * tv; arr += rvec[i] * tv; att += tv * tv; }
     xt_dots_write(acc, arr, att, red, part);
 }
-// second launch of the two-launch loop: fold + every vector update (see k_xt_apply2).  Grid and row-block ownership as k_xt_rows<0>.
-__global__ __launch_bounds__(XT_NT) void k_xt_fold_step(int ns, int nK, int nW, int ns_pad, const int2 *__restrict__ wrange, const int *__restrict__ nitem_w,
-                                                        const double *__restrict__ rowpart, const double *__restrict__ colpart,
-                                                        const int *__restrict__ srow, const double *__restrict__ sS, int m, const int *__restrict__ nsrank,
-                                                        const double *__restrict__ sc, const double *__restrict__ t, double *__restrict__ P, double *__restrict__ R,
-                                                        double *__restrict__ y, double *__restrict__ U, double *__restrict__ V, double *__restrict__ US,
-                                                        double *__restrict__ VS, const double *__restrict__ ppart, int np1, double *__restrict__ part_rr,
-                                                        int it, int n_cur, int n_prev, double tol2, const XCtrl *ctrl)
-{
-    __shared__ double red[XT_NT / 64];
-    __shared__ double sl_sum[8][XT_R];
-    __shared__ double scal[4];
-    // what does not depend on the scalars or the partial sums is fetched first (as in k_xt_rows)
-    const int chunk = (m + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int i0 = blockIdx.x * chunk, i1 = min(m, i0 + chunk);
-    const int ifirst = i0 + (int)threadIdx.x;
-    double fP = 0.0, fR = 0.0, fy = 0.0, ft = 0.0, fs = 0.0; int fsr = 0;
-    if (ifirst < i1) { fsr = nsrank[ifirst]; fP = P[ifirst]; fR = R[ifirst]; fy = y[ifirst]; ft = t[ifirst]; fs = sc[ifirst]; }
-    int row0 = -1; double s0 = 0.0, t0 = 0.0, P0 = 0.0, R0 = 0.0, y0 = 0.0, sc0 = 0.0;
-    {
-        const int s = XT_R * (int)blockIdx.x + (int)threadIdx.x;
-        if ((int)blockIdx.x < nK && threadIdx.x < XT_R && s < ns) { row0 = srow[s]; s0 = sS[s]; t0 = t[row0]; P0 = P[row0]; R0 = R[row0]; y0 = y[row0]; sc0 = sc[row0]; }
-    }
-    int2 wr0 = make_int2(0, 0); int nc0 = 0;
-    int cb0 = 0;
-    if ((int)blockIdx.x < nK) { wr0 = wrange[blockIdx.x]; nc0 = xt_row_block_runs(blockIdx.x, nitem_w, 0, nW, nW); cb0 = xt_row_block_cbase(blockIdx.x, nW, nitem_w); }
-    if (threadIdx.x < 64) {
-        double beta, rr; bool stop;
-        xt_iter_head(part_rr, it, n_cur, n_prev, tol2, beta, rr, stop, ctrl);
-        const double pAp = xt_wave_total(ppart, np1);
-        if (threadIdx.x == 0) { scal[0] = stop ? 1.0 : 0.0; scal[1] = beta; scal[2] = rr / pAp; }
-    }
-    __syncthreads();
-    if (scal[0] != 0.0) return;
-    const double beta = scal[1], alpha = scal[2];
-    double acc = 0.0;
-#define XT_UPDATE(i_, P_, R_, y_, t_, s_, sidx_)                                         \
-    {                                                                                    \
-        const double pn_ = beta * (P_) - (R_);                                           \
-        P[i_] = pn_; y[i_] = (y_) + alpha * pn_;                                         \
-        const double rn_ = (R_) + alpha * (t_);                                          \
-        R[i_] = rn_; acc += rn_ * rn_;                                                   \
-        const double u_ = (s_) * pn_, v_ = (s_) * rn_;                                   \
-        U[i_] = u_; V[i_] = v_;                                                          \
-        if ((sidx_) >= 0) { US[sidx_] = u_; VS[sidx_] = v_; }                            \
-    }
-    for (int k = blockIdx.x; k < nK; k += gridDim.x) {
-        const bool own = k == (int)blockIdx.x;
-        const double sum = xt_row_block_sum(k, nW, own ? cb0 : xt_row_block_cbase(k, nW, nitem_w), own ? wr0 : wrange[k], own ? nc0 : xt_row_block_runs(k, nitem_w, 0, nW, nW), rowpart, colpart, sl_sum, 0, nW);
-        const int s = XT_R * k + (int)threadIdx.x;
-        if (threadIdx.x < XT_R && s < ns) {
-            if (own) { const double tv = s0 * (t0 + sum); XT_UPDATE(row0, P0, R0, y0, tv, sc0, s) }
-            else { const int row = srow[s]; const double tv = sS[s] * (t[row] + sum); XT_UPDATE(row, P[row], R[row], y[row], tv, sc[row], s) }
-        }
-    }
-    // the non-S rows of this workgroup's share of the vector (finished, scaled, by the product launch)
-    if (ifirst < i1 && fsr < 0) XT_UPDATE(ifirst, fP, fR, fy, ft, fs, -1)
-    for (int i = ifirst + XT_NT; i < i1; i += XT_NT) if (nsrank[i] < 0) XT_UPDATE(i, P[i], R[i], y[i], t[i], sc[i], -1)
-#undef XT_UPDATE
-    const double tot = block_sum_all<XT_NT>(acc, red);
-    if (threadIdx.x == 0) part_rr[XT_RRS * ((it + 1) % 3) + blockIdx.x] = tot;
-}
-// state of the two-launch loop before iteration 0: p_{-1} = 0 (beta_0 = 0 makes p_0 = -r_0), U = 0, V = S r_0
-__global__ void k_xt_uv_init(int m, const double *__restrict__ r, const double *__restrict__ sc, const int *__restrict__ nsrank, double *__restrict__ P,
-                             double *__restrict__ U, double *__restrict__ V, double *__restrict__ US, double *__restrict__ VS)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
-    const double v = sc[i] * r[i];
-    P[i] = 0.0; U[i] = 0.0; V[i] = v;
-    const int sr = nsrank[i];
-    if (sr >= 0) { US[sr] = 0.0; VS[sr] = v; }
-}
-
 // sharded solve, after the all-reduce of xout: finish the S rows, then the same partials as MODE 0
 __global__ __launch_bounds__(XT_NT) void k_xt_rows_apply(int ns, int nK, const double *__restrict__ xbuf, const int *__restrict__ srow,
                                                          const double *__restrict__ sS, const double *__restrict__ pvec, double *__restrict__ t,
@@ -1033,6 +788,16 @@ __global__ void k_xt_abort_word(XCtrl *ctrl, double *xbuf, int ns) { ctrl->abort
 // test aid: make this rank fail once, in the assembly (phase 1) or on the host side of CG iteration `iteration` (phase 2)
 static int g_fault_phase = 0, g_fault_iter = 0;
 extern "C" void dkmc_debug_inject_fault(int phase, int iteration) { g_fault_phase = phase; g_fault_iter = iteration; }
+// q = s y (full length and compact over S): the product's input when a solve continues from an iterate another loop left in y
+__global__ void k_xt_requeue(int m, const double *__restrict__ y, const double *__restrict__ sc, const int *__restrict__ nsrank, double *__restrict__ q, double *__restrict__ qS)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const double qv = sc[i] * y[i];
+    q[i] = qv;
+    const int sr = nsrank[i];
+    if (sr >= 0) qS[sr] = qv;
+}
 __global__ void k_xt_vec_mul(int m, double *__restrict__ y, const double *__restrict__ s)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1083,31 +848,9 @@ __global__ __launch_bounds__(XT_NT) void k_xt_power_rows(int Nsub, const xrp_t *
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------
-struct XTState {
-    // shape of the last assembly
-    int Nsub = 0, ns = 0, ns_pad = 0, nK = 0, nW = 0, ntiles = 0, nitems = 0, kc = 1, maxchunk = 1, rec_shift = 0;
-    long long nsub_total = 0, xs_nnz = 0;
-    unsigned long long t_upper = 0;
-    // this rank's share
-    int item_lo = 0, item_n = 0, tile_lo = 0, tile_n = 0, w_lo = 0, w_hi = 0; long long sub_base = 0, sub_n = 0;
-    bool valid = false;
-};
-static XTState g_xt;
+XTState g_xt;
+XTBuffers g_xb;
 
-struct XTBuffers {
-    SNodes S; int *srow; XTile *tiles; XItem *items; int2 *wrange; int *nitem_w; double *tval, *rowpart, *colpart;
-    xrp_t *rp, *dpos; int *ci; double *val; int *nsrank;
-    unsigned *cmask; int *toff;      // census of the last assembly (kept for dkmc_xt_time_share)
-};
-static XTBuffers g_xb;
-
-static inline int xt_grid(long long work, int per_block, int cap)
-{
-    long long b = (work + per_block - 1) / per_block;
-    if (b < 1) b = 1;
-    if (b > cap) b = cap;
-    return (int)b;
-}
 
 // one pass over this rank's tiles with the vector vS (compact over S), tile sums of every S-row into out[ns] (all ranks)
 template <int OP>
@@ -1128,6 +871,8 @@ static int xt_tile_sums(const double *vS, double *out, int vpos)
     }
     return 0;
 }
+
+int xt_tile_sums_mv(const double *vS, double *out) { return xt_tile_sums<0>(vS, out, 1); }      // xtb.hip (test aid)
 
 // Builds the work items for an nranks-way split and reports rank `me`'s share.  Slots: where the item arrays go (the resident ones of
 // an assembly, or temporary ones of dkmc_xt_time_share).
@@ -1212,7 +957,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
            *q = nullptr, *vS = nullptr, *part = nullptr, *qS = nullptr, *sS = nullptr, *xS = nullptr, *part_pt = nullptr, *part_rr = nullptr;
     XTile *tiles = nullptr; int2 *wrange = nullptr; XItem *items = nullptr; unsigned long long *d_cnt = nullptr; XCtrl *ctrl = nullptr;
     SNodes SN{};
-    double *xbuf = nullptr, *uv = nullptr, *uvS = nullptr;
+    double *xbuf = nullptr;
     auto assemble = [&]() -> int {
         if (g_fault_phase == 1) { g_fault_phase = 0; return dkmc_fail(90, "injected fault (assembly of X)", __FILE__, __LINE__); }
         if (sharded) { xbuf = (double *)scratch(S_CG_XCHG, (size_t)(ns + 2) * 8); if (!xbuf) return e.err_code; if (ns > 0) { rc = xt_side_init(); if (rc) return rc; } }
@@ -1322,12 +1067,6 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         ctrl = (XCtrl *)scratch(S_CG_CTRL, sizeof(XCtrl));
         if (!sc || !r || !p || !t || !q || !vS || !part || !ctrl) return e.err_code;
         qS = vS; sS = vS + ns_pad; xS = vS + 2 * (size_t)ns_pad;
-        if (!sharded && e.x_loop) {       // two-launch loop: U = S p, V = S r (full length and compact over S), p.Ap partials of the product launch
-            uv = (double *)scratch(S_XT_UV, (size_t)m * 2 * 8);
-            uvS = (double *)scratch(S_XT_UVS, (size_t)ns_pad * 2 * 8);
-            if (!uv || !uvS) return e.err_code;
-            HIPCHK(hipMemsetAsync(uvS, 0, (size_t)ns_pad * 2 * 8, st));
-        }
         HIPCHK(hipMemsetAsync(vS, 0, (size_t)ns_pad * 3 * 8, st));
         part_pt = part; part_rr = part + 4096;          // p.t | r.t | t.t partials (XT_PSTRIDE apart); r.r partials, double-buffered (512 apart)
         return 0;
@@ -1414,34 +1153,32 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
                               part_pt, (const XCtrl *)ctrl, (double *)nullptr, m, (const int *)nsrank, 0, (const double *)r, 0, nW);
         return 0;
     };
-    // ---- one iteration of the two-launch loop (single GPU): product with the direction formed on the fly, then fold + vector step ----
-    const bool two = !sharded && e.x_loop != 0;
-    double *ppart = nullptr;
-    if (two) { ppart = (double *)scratch(S_XT_PPART, (size_t)(ntb + std::max(nsb, nsb1) + 4) * 8); if (!ppart) return e.err_code; }
-    double *U = uv, *V = uv ? uv + m : nullptr, *US = uvS, *VS = uvS ? uvS + ns_pad : nullptr;
-    auto iter2 = [&](int it, hipEvent_t e0, hipEvent_t e1, hipEvent_t e2, hipEvent_t e3) -> int {
-        const int n_cur = it == 0 ? gv : n2b, n_prev = it <= 1 ? gv : n2b;
-        int np1;
-#define XT_APPLY2_ARGS(NTB, NSB, VB0) X.item_n, (const XItem *)items + X.item_lo, (const XTile *)tiles, (int)X.sub_base, (const double *)tval, (const double *)US, \
-                      (const double *)VS, nW, ns_pad, rowpart, colpart, ctrl, NTB, NSB, m, (const xrp_t *)rp, (const int *)col, (const double *)val, (const double *)U, \
-                      (const double *)V, (const double *)sc, (const int *)nsrank, t, VB0, (const double *)part_rr, it, n_cur, n_prev, tol2, ppart
-        if (seq_neigh && ntb > 0) {
-            hipExtLaunchKernelGGL((k_xt_apply2<1>), dim3(ntb), dim3(XT_NT), 0, st, e0, e1, 0, XT_APPLY2_ARGS(ntb, 0, 2));
-            hipLaunchKernelGGL(k_xt_neigh2, dim3(nsb1 + 2), dim3(XT_NT), 0, st, nsb1, m, (const xrp_t *)rp, (const int *)col, (const double *)val, (const double *)U,
-                               (const double *)V, (const double *)sc, (const int *)nsrank, t, (const double *)part_rr, it, n_cur, n_prev, tol2, ppart + ntb, (const XCtrl *)ctrl);
-            np1 = ntb + nsb1 + 2;
-        } else {
-            if (nt_loads) hipExtLaunchKernelGGL((k_xt_apply2<1>), dim3(ntb + nsb + 2), dim3(XT_NT), 0, st, e0, e1, 0, XT_APPLY2_ARGS(ntb, nsb, 0));
-            else hipExtLaunchKernelGGL((k_xt_apply2<0>), dim3(ntb + nsb + 2), dim3(XT_NT), 0, st, e0, e1, 0, XT_APPLY2_ARGS(ntb, nsb, 0));
-            np1 = ntb + nsb + 2;
-        }
-#undef XT_APPLY2_ARGS
-        hipExtLaunchKernelGGL(k_xt_fold_step, dim3(n2b), dim3(XT_NT), 0, st, e2, e3, 0, ns, nK, nW, ns_pad, (const int2 *)wrange, (const int *)nitem_w,
-                              (const double *)rowpart, (const double *)colpart, (const int *)srow, (const double *)sS, m, (const int *)nsrank, (const double *)sc,
-                              (const double *)t, p, r, y, U, V, US, VS, (const double *)ppart, np1, part_rr, it, n_cur, n_prev, tol2, (const XCtrl *)ctrl);
-        return 0;
-    };
 
+    // ---- block-CG (dkmc_set_x_block(s > 1), one GPU): xtb.hip.  Column 0 = this system; on a loss of definiteness of its s x s systems the
+    // single-vector loop below continues from the last good iterate ----
+    XCtrl h{};
+    bool solved = false;
+    double prof_long_ms = 0.0, prof_short_ms = 0.0, prof_comm_ms = 0.0; int prof_long_n = 0, prof_short_n = 0, prof_comm_n = 0;
+    e.stats.xb_width = 1; e.stats.xb_fallback = 0;
+    if (e.x_block > 1 && !sharded && ns > 0) {
+        XtbArgs B{};
+        B.m = m; B.ns = ns; B.ns_pad = ns_pad; B.nK = nK; B.nW = nW; B.s = e.x_block;
+        B.items = (const XItem *)items + X.item_lo; B.item_n = X.item_n; B.tiles = tiles; B.sub_base = (int)X.sub_base; B.tval = tval;
+        B.wrange = wrange; B.nitem_w = nitem_w; B.nrecords = X.nitems >> X.rec_shift;
+        B.srow = srow; B.sS = sS; B.nsrank = nsrank; B.rp = rp; B.ci = col; B.val = val; B.sc = sc; B.b = rhs; B.y = y;
+        B.ctrl = ctrl; B.tol2 = tol2; B.nt_loads = nt_loads;
+        int bi = 0; double brr = 0.0;
+        rc = xtb_cg(B, &bi, &brr);
+        e.stats.xb_width = e.x_block;
+        if (rc == 0) { solved = true; h.iters = bi; h.rr[bi & 1] = brr; }
+        else if (rc != DKMC_XTB_BREAKDOWN) return rc;
+        else {
+            e.stats.xb_fallback = 1;
+            hipLaunchKernelGGL(k_xt_requeue, dim3(nbr), dim3(256), 0, st, m, (const double *)y, (const double *)sc, (const int *)nsrank, q, qS);
+        }
+    }
+    const bool prof = e.profiling != 0;
+    if (!solved) {
     // ---- r = A y - b, p = -r ----
     HIPCHK(hipMemsetAsync(ctrl, 0, sizeof(XCtrl), st));
     if (sharded && ns > 0) hipLaunchKernelGGL(k_xt_set_sharded, dim3(1), dim3(1), 0, st, ctrl);
@@ -1449,19 +1186,15 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
     rc = matvec(nullptr, nullptr, nullptr, nullptr, nullptr); if (rc) return rc;
     hipLaunchKernelGGL(k_xt_resid_init, dim3(gv), dim3(XT_NT), 0, st, m, (const double *)t, (const double *)rhs, r, p, (const double *)sc, q, (const int *)nsrank, qS, part_rr);
     hipLaunchKernelGGL(k_xt_check0, dim3(1), dim3(XT_NT), 0, st, (const double *)part_rr, gv, ctrl, tol2);
-    if (two) hipLaunchKernelGGL(k_xt_uv_init, dim3(nbr), dim3(256), 0, st, m, (const double *)r, (const double *)sc, (const int *)nsrank, p, U, V, US, VS);
     KCHK();
 
     // ---- optional kernel profile: start/stop events of sampled apply launches (bench.py roofline) ----
-    const bool prof = e.profiling != 0;
     static hipEvent_t evs[4 * 64], evc[64 / XT_PROF_STRIDE]; static bool evs_ready = false;
-    double prof_long_ms = 0.0, prof_short_ms = 0.0, prof_comm_ms = 0.0; int prof_long_n = 0, prof_short_n = 0, prof_comm_n = 0;
     if (prof && !evs_ready) { for (auto &ev : evs) HIPCHK(hipEventCreate(&ev)); for (auto &ev : evc) HIPCHK(hipEventCreate(&ev)); evs_ready = true; }
 
     // ---- iterations in batches; the host polls the control block between batches (batch plan: see cg.hip) ----
     int it = 0, launched = 0, batch = 8;
     if (e.x_iter_hint > 24) batch = e.x_iter_hint - 8;
-    XCtrl h{};
     int loop_rc = 0;
     for (;;) {
         HIPCHK(hipMemcpyAsync(&h, ctrl, sizeof(XCtrl), hipMemcpyDeviceToHost, st));
@@ -1480,11 +1213,6 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         for (int b = 0; b < batch; ++b, ++it) {
             cur_it = it;
             const bool pb = prof && b < 64 && (b % XT_PROF_STRIDE == 0);
-            if (two) {
-                loop_rc = iter2(it, pb ? evs[4 * b] : nullptr, pb ? evs[4 * b + 1] : nullptr, pb ? evs[4 * b + 2] : nullptr, pb ? evs[4 * b + 3] : nullptr);
-                if (loop_rc) break;
-                continue;
-            }
             loop_rc = matvec(pb ? evs[4 * b] : nullptr, pb ? evs[4 * b + 1] : nullptr, pb ? evs[4 * b + 2] : nullptr, pb ? evs[4 * b + 3] : nullptr,
                              pb ? evc[b / XT_PROF_STRIDE] : nullptr);
             if (loop_rc) break;
@@ -1498,6 +1226,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
     if (loop_rc) return loop_rc;
     if (local_fail) return local_fail;                                                     // this rank failed between two collectives: the peers were told (abort word)
     if (h.aborted) return dkmc_fail(46, "a peer rank aborted the sharded current solve", __FILE__, __LINE__);
+    }
     hipLaunchKernelGGL(k_xt_vec_mul, dim3(nbr), dim3(256), 0, st, m, y, (const double *)sc);
     KCHK();
     if (sharded) { rc = comm_bcast0_f64(y, (size_t)m); if (rc) return rc; }        // the solution every later phase starts from: rank 0's bits
@@ -1523,7 +1252,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
     e.stats.xt_sparse_nnz = xs_nnz; e.stats.xt_ns = ns;
     e.stats.spmv_segments = 0; e.stats.spmv_segment_entries = 0;
     e.stats.spmv_long_rows = ns; e.stats.spmv_short_rows = m - ns; e.stats.spmv_long_nnz = 2 * t_upper; e.stats.spmv_short_nnz = xs_nnz;
-    if (prof) {
+    if (prof && !solved) {
         e.stats.spmv_long_ms = prof_long_ms; e.stats.spmv_short_ms = prof_short_ms;
         e.stats.spmv_long_launches = prof_long_n; e.stats.spmv_short_launches = prof_short_n;
         e.stats.comm_ms = prof_comm_ms; e.stats.comm_launches = prof_comm_n;

@@ -1,0 +1,802 @@
+// xtb.hip -- block-CG of the current solve on the tiled X, with the tile x panel product on the matrix cores (dkmc_set_x_block(s), s = 2 ... 16).
+//
+// What it replaces: solve_sparse_CG_Jacobi (iterative_solvers_gpu.cu:309-480) as update_power_gpu_sparse calls it
+// (current_solver_gpu.cu:963-994), and -- for the tunnelling block -- the dense tile product of the reference's unfinished split path
+// (add_submatrix_product, iterative_solvers_gpu.cu:634-652; solve_sparse_CG_splitmatrix :656-821), which applies the tile as a GEMV.
+// X changes every superstep and has ONE physical right-hand side, so there is nothing to batch -- but a block-CG whose other columns are
+// AUXILIARY right-hand sides (fixed-seed pseudo-random, zero start) searches the block Krylov space of all s columns and deflates the
+// outlying part of X's spectrum (loop_G = 1e12, high_G = 1e5, low_G = 1e-8 nodes): on the oracle's X of the 85 071-site device the
+// reference's stop test on the physical column is met after 666 / 208 / 133 / 95 sweeps at s = 1 / 4 / 8 / 16 (tools/blockcg_proto.py).
+// One sweep streams every stored 32 x 32 sub-block ONCE (8 KiB, both triangles from one read, as the single-vector kernel does) and
+// multiplies it and its transpose into 32 x 16 panels: 4 s flops per 8 bytes -- at s = 16 a contraction of 8 flop/B, which is what
+// north_star reserves the matrix cores for.
+//
+// Algorithm (scaled system A = S X S, sign convention of the reference: R = A Y - B, first direction -R):
+//     T = A P                                            one sweep
+//     c = -(P'T)^-1 P'R ;  Y += P c ;  R+ = R + T c
+//     beta = (P'T)^-1 (T'R + T'T c)                      = (P'T)^-1 T'R+ : makes the new directions A-conjugate to P
+//     P+ = (-R+ + P beta) W                              W = inverse transposed Cholesky factor of the Gram matrix of (-R+ + P beta):
+//                                                        directions stay orthonormal, the s x s systems well conditioned
+// Every s x s matrix (P'T, P'R, T'R, T'T, R'R) comes from ONE pass over the panels (k_xtb_rows, MFMA with the rows as the contraction
+// index); R+'R+ and the Gram matrix of the new directions follow from them algebraically (exact for the R+ actually formed, the
+// identity the single-vector loop of xt.hip uses for r'.r'), so an iteration has no second global reduction:
+//     k_xtb_apply (+ k_xtb_neigh)   T = A P: tiles on the matrix cores; neighbour part Xs as CSR x panel
+//     k_xtb_rows                    partial sums -> S rows of T; partial Gram matrices
+//     k_xtb_gred + k_xtb_small      Gram matrices in a fixed order; ONE wave: the s x s algebra, stop test on column 0 (||r||^2 <= tol^2)
+//     k_xtb_step                    Y, R, P, Q = S P as 16-row x 16 x 16 MFMA products
+// Column 0 carries the reference's right-hand side and start vector; the result is its solution, to the same stop test.  The iterate
+// sequence is NOT the reference's (s = 1 keeps that: xt.hip).
+//
+// Tile x panel product (k_xtb_apply), per 32 x 32 sub-block, v_mfma_f64_16x16x4_f64 (A[i][k]: lane = i + 16 k; B[k][j]: lane = j + 16 k;
+// D[i][j]: lane = j + 16 (i % 4), register i / 4):
+//   column sums  Yc[col][v] += sum_row T[row][col] Qr[row][v]:  the 8 wave loads of the stream (lane (cc, rr) holds rows 4 j + rr, columns
+//                2 cc, 2 cc + 1) ARE the A operands (i = cc, k = rr): no data movement; 16 MFMAs.
+//   row sums     Yr[row][v] += sum_col T[row][col] Qc[col][v]:  needs the sub-block with the COLUMN on the k index: one round trip through
+//                wave-private LDS (8 ds_write_b128 into an XOR-swizzled image, 8 ds_read_b128, both conflict-free); 16 MFMAs.
+// Column sums stay in 128 accumulator registers over the run of tiles (one 256-column strip), the four waves of a workgroup leave one
+// combined record; row sums (32 x 16) go to a grid-indexed array per tile.
+#include "xtiles.h"
+#include <hip/hip_ext.h>
+#include <algorithm>
+#include <vector>
+
+#define XB_SP 16                      // vectors per panel row (padded block width)
+#define XB_DSPLIT 8                   // workgroups per driver row of Xs
+#define XB_NG 5                       // Gram matrices per pass: P'T, P'R, T'R, T'T, R'R
+typedef double dbl4 __attribute__((ext_vector_type(4)));
+#define XB_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+
+// auxiliary right-hand sides: a hash of (row, column) -> uniform in [-1, 1); the same on every rank and in tools/blockcg_proto.py
+__device__ __forceinline__ double xtb_aux(int row, int col)
+{
+    unsigned long long h = (unsigned long long)row * 0x9E3779B97F4A7C15ull + (unsigned long long)col * 0xC2B2AE3D27D4EB4Full + 12345ull;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    return (double)(h >> 11) * (1.0 / 4503599627370496.0) - 1.0;
+}
+// column v of the scaled right-hand side panel at a row: the physical one, an auxiliary one, or padding
+__device__ __forceinline__ double xtb_rhs(const double *__restrict__ b, int row, int v, int s)
+{
+    return v == 0 ? b[row] : (v < s ? xtb_aux(row, v) : 0.0);
+}
+// position of (S rank r, vector v) in the compact panel QS: rows pairwise interleaved, [r / 2][v][r % 2] -- two consecutive rows of one
+// vector are one 16-byte LDS read (the two k-steps e' = 0, 1 of the row product)
+__device__ __forceinline__ size_t xtb_qs_pos(int r, int v) { return (size_t)(r >> 1) * 32 + 2 * v + (r & 1); }
+
+// ---- tiles x panel -----------------------------------------------------------------------------------------------------------------
+// One run of tiles per wave, the four runs of a workgroup in one strip (the run list is padded to groups of four per strip: xt.hip).
+template <int NTL>
+__global__ __launch_bounds__(XT_NT) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__restrict__ tiles, int sub_base, const double *__restrict__ tval,
+                 const double *__restrict__ QS, int nW, double *__restrict__ rowpartB, double *__restrict__ colpartB, const XCtrl *ctrl, int so)
+{
+    __shared__ __attribute__((aligned(16))) double qc[XT_C * XB_SP];          // the strip's 256 panel rows, pairwise interleaved (32 KiB)
+    __shared__ __attribute__((aligned(16))) double ts[4 * 2 * XT_SUB];        // per wave: two sub-block images (2 x 8 KiB)
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, cc = lane & 15, rr = lane >> 4;         // also (a, b) / (jv, b) of the MFMA operand maps
+    const int item = (int)blockIdx.x * 4 + wv;
+    const XItem it = items[min(item, nitems - 1)];
+    if (ctrl->done) return;                                                    // uniform over the launch
+    {   // the window of the strip: a straight copy (QS is stored in the LDS image's order)
+        const dbl2 *src = reinterpret_cast<const dbl2 *>(QS + (size_t)it.w * XT_C * XB_SP);
+        dbl2 *dst = reinterpret_cast<dbl2 *>(qc);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) dst[threadIdx.x + 256 * u] = src[threadIdx.x + 256 * u];
+    }
+    __syncthreads();
+    double *tsw = ts + (size_t)wv * 2 * XT_SUB;
+    dbl4 Yc[8][2];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { Yc[q][0] = (dbl4)(0.0); Yc[q][1] = (dbl4)(0.0); }
+    // LDS offsets (doubles) of this lane: image g(r, c) = 32 r + (c ^ ((r & 15) << 1))
+    int woff[8], roff[2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int r = 4 * j + rr; woff[j] = 32 * r + ((2 * cc) ^ ((r & 15) << 1)); }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) roff[mb] = 32 * (16 * mb + cc);            // + ((8 kk + 2 rr) ^ (cc << 1)) per k-pair
+    const int qoff = rr * 32 + 2 * cc;                                         // + (16 q + 4 kk) * 32: B operands of the row product
+#define XB_LD(dst, slot) _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) dst[j_] = NTL ? __builtin_nontemporal_load(base + (size_t)(8 * (slot) + j_) * 64) : base[(size_t)(8 * (slot) + j_) * 64];
+    // one sub-block: column sums straight from the loaded registers, row sums after the LDS round trip
+#define XB_SUBBLOCK(vv, q, bufi)                                                                                               \
+    {                                                                                                                           \
+        double *img_ = tsw + (bufi) * XT_SUB;                                                                                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) *reinterpret_cast<dbl2 *>(img_ + woff[j_]) = vv[j_];                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                                                      \
+            Yc[q][0] = XB_MFMA(vv[j_].x, br[j_], Yc[q][0]);                                                                     \
+            Yc[q][1] = XB_MFMA(vv[j_].y, br[j_], Yc[q][1]);                                                                     \
+        }                                                                                                                       \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                                  \
+        __builtin_amdgcn_wave_barrier();                                                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                                  \
+        _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_) {                                                                   \
+            const dbl2 bc_ = *reinterpret_cast<const dbl2 *>(qc + qoff + (16 * (q) + 4 * kk_) * 32);                            \
+            const int sw_ = (8 * kk_ + 2 * rr) ^ (cc << 1);                                                                     \
+            const dbl2 a0_ = *reinterpret_cast<const dbl2 *>(img_ + roff[0] + sw_);                                             \
+            const dbl2 a1_ = *reinterpret_cast<const dbl2 *>(img_ + roff[1] + sw_);                                             \
+            Yr0 = XB_MFMA(a0_.x, bc_.x, Yr0); Yr1 = XB_MFMA(a1_.x, bc_.x, Yr1);                                                 \
+            Yr0 = XB_MFMA(a0_.y, bc_.y, Yr0); Yr1 = XB_MFMA(a1_.y, bc_.y, Yr1);                                                 \
+        }                                                                                                                       \
+    }
+    XTile td; td.k = it.k0; td.w = it.w; td.mask = it.mask0; td.soff = it.soff0;
+#pragma unroll 1
+    for (int t = it.t0; t < it.t1; ++t) {
+        XTile nxt = td;
+        if (t + 1 < it.t1) nxt = tiles[t + 1];
+        // B operands of the column sums: the tile's 32 panel rows, row 4 j + rr of vector cc
+        double br[8];
+        {
+            const double *qr = QS + (size_t)td.k * XT_R * XB_SP + (rr >> 1) * 32 + 2 * cc + (rr & 1);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) br[j] = qr[64 * j];
+        }
+        dbl4 Yr0 = (dbl4)(0.0), Yr1 = (dbl4)(0.0);
+        const dbl2 *base = reinterpret_cast<const dbl2 *>(tval + (size_t)(td.soff - sub_base) * XT_SUB) + lane;
+        if (td.mask == 0xffu) {
+            // full tile: 64 KiB contiguous, two sub-blocks in flight
+            dbl2 va[8], vb[8];
+            XB_LD(va, 0)
+            XB_LD(vb, 1)
+            XB_SUBBLOCK(va, 0, 0)
+            XB_LD(va, 2)
+            XB_SUBBLOCK(vb, 1, 1)
+            XB_LD(vb, 3)
+            XB_SUBBLOCK(va, 2, 0)
+            XB_LD(va, 4)
+            XB_SUBBLOCK(vb, 3, 1)
+            XB_LD(vb, 5)
+            XB_SUBBLOCK(va, 4, 0)
+            XB_LD(va, 6)
+            XB_SUBBLOCK(vb, 5, 1)
+            XB_LD(vb, 7)
+            XB_SUBBLOCK(va, 6, 0)
+            XB_SUBBLOCK(vb, 7, 1)
+        } else {
+            int sl = 0;                                                     // partial tile (a few per cent of the storage): one sub-block at a time
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if ((td.mask >> q) & 1u) {
+                    dbl2 va[8];
+                    XB_LD(va, sl)
+                    XB_SUBBLOCK(va, q, q & 1)
+                    ++sl;
+                }
+            }
+        }
+        // row sums of the tile: D[i][jv] of Yr{0,1}: row 16 mb + rr + 4 v, vector cc
+        if (cc < so) {
+            double *rp_ = rowpartB + (((size_t)td.k * nW + td.w) * XT_R + rr) * so + cc;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) { rp_[(size_t)(4 * v) * so] = Yr0[v]; rp_[(size_t)(16 + 4 * v) * so] = Yr1[v]; }
+        }
+        td = nxt;
+    }
+#undef XB_LD
+#undef XB_SUBBLOCK
+    // one record of column sums per workgroup: the four waves' accumulators are added in a fixed order through LDS, four sub-block
+    // positions per round.  Yc[q][e] register v of lane (cc, rr) is column 32 q + 2 (rr + 4 v) + e, vector cc.
+    double *rec = colpartB + (size_t)it.pad * XT_C * so;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();                                                     // every wave is done with its images (and with the previous round)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) tsw[(q4 * 8 + e * 4 + v) * 64 + lane] = Yc[4 * h + q4][e][v];
+        __syncthreads();
+        if (cc < so) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int idx = (wv * 8 + e * 4 + v) * 64 + lane;
+                    const double sum = (ts[idx] + ts[2 * XT_SUB + idx]) + (ts[4 * XT_SUB + idx] + ts[6 * XT_SUB + idx]);
+                    rec[(size_t)(32 * (4 * h + wv) + 2 * (rr + 4 * v) + e) * so + cc] = sum;
+                }
+        }
+    }
+}
+
+// ---- neighbour part Xs x panel ------------------------------------------------------------------------------------------------------
+// Workgroups [0, 2 XB_DSPLIT): the two driver rows (thousands of entries each), XB_DSPLIT slices per row, partial sums to drvpart (finished
+// by k_xtb_rows).  The rest: 16 atom rows per workgroup, 16 lanes per row (one per vector).  Non-S rows are finished (scaled) here; S rows
+// leave their sparse sum in T for k_xtb_rows.
+__global__ __launch_bounds__(XT_NT) void k_xtb_neigh(int m, const xrp_t *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ val,
+                                                     const double *__restrict__ Q, const double *__restrict__ sc, const int *__restrict__ nsrank,
+                                                     const XCtrl *ctrl, double *__restrict__ T, double *__restrict__ drvpart)
+{
+    __shared__ double red[16][16];
+    if (ctrl->done) return;
+    const int v = threadIdx.x & 15, g = threadIdx.x >> 4;
+    if (blockIdx.x < 2 * XB_DSPLIT) {
+        const int row = blockIdx.x / XB_DSPLIT, part = blockIdx.x % XB_DSPLIT;
+        const xrp_t p0 = rp[row], p1 = rp[row + 1];
+        const xrp_t len = p1 - p0, a = p0 + len * part / XB_DSPLIT, b = p0 + len * (part + 1) / XB_DSPLIT;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        xrp_t p = a + g;
+        for (; p + 48 < b; p += 64) {
+            const int c0 = ci[p], c1 = ci[p + 16], c2 = ci[p + 32], c3 = ci[p + 48];
+            const double a0 = val[p], a1 = val[p + 16], a2 = val[p + 32], a3 = val[p + 48];
+            s0 += a0 * Q[(size_t)c0 * XB_SP + v]; s1 += a1 * Q[(size_t)c1 * XB_SP + v]; s2 += a2 * Q[(size_t)c2 * XB_SP + v]; s3 += a3 * Q[(size_t)c3 * XB_SP + v];
+        }
+        for (; p < b; p += 16) s0 += val[p] * Q[(size_t)ci[p] * XB_SP + v];
+        red[g][v] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (g == 0) {
+            double s = 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) s += red[u][v];
+            drvpart[(row * XB_DSPLIT + part) * XB_SP + v] = s;
+        }
+        return;
+    }
+    const int row = 2 + ((int)blockIdx.x - 2 * XB_DSPLIT) * 16 + g;
+    if (row >= m) return;
+    const xrp_t p0 = rp[row], p1 = rp[row + 1];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    xrp_t p = p0;
+    for (; p + 3 < p1; p += 4) {
+        const int c0 = ci[p], c1 = ci[p + 1], c2 = ci[p + 2], c3 = ci[p + 3];
+        const double a0 = val[p], a1 = val[p + 1], a2 = val[p + 2], a3 = val[p + 3];
+        s0 += a0 * Q[(size_t)c0 * XB_SP + v]; s1 += a1 * Q[(size_t)c1 * XB_SP + v]; s2 += a2 * Q[(size_t)c2 * XB_SP + v]; s3 += a3 * Q[(size_t)c3 * XB_SP + v];
+    }
+    for (; p < p1; ++p) s0 += val[p] * Q[(size_t)ci[p] * XB_SP + v];
+    const double s = (s0 + s1) + (s2 + s3);
+    T[(size_t)row * XB_SP + v] = nsrank[row] < 0 ? sc[row] * s : s;
+}
+
+// ---- row kernel: partial sums -> S rows of T, then the partial Gram matrices of this workgroup's rows ------------------------------------
+// Thread (r4 = tid / 16, v = tid % 16) owns vector v of S rows r4 and r4 + 16 of a row block; wave wv thus holds rows 4 wv ... 4 wv + 3
+// (and + 16) in exactly the operand map of v_mfma_f64_16x16x4_f64 with the ROW on the k index: X'Z over four rows is one MFMA.
+// INIT: T = A Y0 has just been formed; R = T - B is stored and only R'R is accumulated.
+__device__ __forceinline__ double xtb_list_sum(const double *__restrict__ p, size_t stride, int first, int n, int step)
+{
+    // terms first, first + step, ... < n of a strided list; term j goes to accumulator j % 4 whatever the unrolling
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int c = first;
+    for (; c + 7 * step < n; c += 8 * step) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = p[(size_t)(c + u * step) * stride];
+        a0 += x[0]; a1 += x[1]; a2 += x[2]; a3 += x[3]; a0 += x[4]; a1 += x[5]; a2 += x[6]; a3 += x[7];
+    }
+    for (; c + 3 * step < n; c += 4 * step) { a0 += p[(size_t)c * stride]; a1 += p[(size_t)(c + step) * stride]; a2 += p[(size_t)(c + 2 * step) * stride]; a3 += p[(size_t)(c + 3 * step) * stride]; }
+    for (; c < n; c += step) a0 += p[(size_t)c * stride];
+    return (a0 + a1) + (a2 + a3);
+}
+template <int INIT>
+__global__ __launch_bounds__(XT_NT) void k_xtb_rows(int ns, int nK, int nW, int m, int s, int so, const int2 *__restrict__ wrange, const int *__restrict__ nitem_w,
+                                                    const double *__restrict__ rowpartB, const double *__restrict__ colpartB,
+                                                    const int *__restrict__ srow, const double *__restrict__ sS, const int *__restrict__ nsrank,
+                                                    const double *__restrict__ sc, const double *__restrict__ drvpart, double *__restrict__ T,
+                                                    const double *__restrict__ P, double *__restrict__ R, const double *__restrict__ b,
+                                                    double *__restrict__ gpart, const XCtrl *ctrl)
+{
+    __shared__ double lg[4][XB_NG][4][64];                                     // the four waves' Gram accumulators (40 KiB)
+    __shared__ int sdone;
+    if (threadIdx.x == 0) sdone = ctrl->done;
+    __syncthreads();
+    if (sdone) return;
+    const int v = threadIdx.x & 15, r4 = threadIdx.x >> 4;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rec_shift = nitem_w[2 * (nW + 2)];
+    dbl4 G[XB_NG];
+#pragma unroll
+    for (int g = 0; g < XB_NG; ++g) G[g] = (dbl4)(0.0);
+    // ---- S rows: fold the partial sums of this workgroup's row blocks ----
+    for (int k = blockIdx.x; k < nK; k += gridDim.x) {
+        const int2 wr = wrange[k];
+        const int wk = k / (XT_C / XT_R);
+        const int nc = nitem_w[wk] >> rec_shift, cbase = nitem_w[nW + 2 + wk] >> rec_shift;
+        double tA = 0.0, tB = 0.0;
+        if (v < so) {
+            const double *rpp = rowpartB + ((size_t)k * nW * XT_R + r4) * so + v;
+            const double *cpp = colpartB + ((size_t)cbase * XT_C + (XT_R * (k % (XT_C / XT_R)) + r4)) * so + v;
+            const size_t rs = (size_t)XT_R * so, cs = (size_t)XT_C * so;
+            tA = xtb_list_sum(cpp, cs, 0, nc, 1) + xtb_list_sum(rpp, rs, wr.x, wr.y, 1);
+            tB = xtb_list_sum(cpp + (size_t)16 * so, cs, 0, nc, 1) + xtb_list_sum(rpp + (size_t)16 * so, rs, wr.x, wr.y, 1);
+        }
+        const int sA = XT_R * k + r4, sB = sA + 16;
+        double pA = 0.0, pB = 0.0, rA = 0.0, rB = 0.0;
+        if (sA < ns) {
+            const int row = srow[sA]; const size_t o = (size_t)row * XB_SP + v;
+            tA = sS[sA] * (T[o] + tA); T[o] = tA;
+            if (INIT) { rA = tA - xtb_rhs(b, row, v, s); R[o] = rA; } else { pA = P[o]; rA = R[o]; }
+        } else tA = 0.0;
+        if (sB < ns) {
+            const int row = srow[sB]; const size_t o = (size_t)row * XB_SP + v;
+            tB = sS[sB] * (T[o] + tB); T[o] = tB;
+            if (INIT) { rB = tB - xtb_rhs(b, row, v, s); R[o] = rB; } else { pB = P[o]; rB = R[o]; }
+        } else tB = 0.0;
+        if (!INIT) {
+            G[0] = XB_MFMA(pA, tA, G[0]); G[1] = XB_MFMA(pA, rA, G[1]); G[2] = XB_MFMA(tA, rA, G[2]); G[3] = XB_MFMA(tA, tA, G[3]);
+            G[0] = XB_MFMA(pB, tB, G[0]); G[1] = XB_MFMA(pB, rB, G[1]); G[2] = XB_MFMA(tB, rB, G[2]); G[3] = XB_MFMA(tB, tB, G[3]);
+        }
+        G[4] = XB_MFMA(rA, rA, G[4]); G[4] = XB_MFMA(rB, rB, G[4]);
+    }
+    // ---- the other rows of this workgroup's share of the vector (finished by k_xtb_neigh; the driver rows from their partial sums).
+    // Four k-steps (16 rows) of a wave in flight: the loads do not wait for the S-rank test (every row below i1 is in bounds) ----
+    {
+        const int chunk = ((m + (int)gridDim.x - 1) / (int)gridDim.x + 3) & ~3;
+        const int i0 = blockIdx.x * chunk, i1 = min(m, i0 + chunk);
+        for (int r0 = i0 + 4 * wv; r0 < i1; r0 += 64) {
+            double tv[4], pv[4], rv[4]; int sr[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = r0 + 16 * u + (lane >> 4);
+                const bool in = row < i1;
+                const size_t o = (size_t)(in ? row : i0) * XB_SP + v;
+                sr[u] = in ? nsrank[row] : 0;
+                tv[u] = T[o];
+                if (!INIT) { pv[u] = P[o]; rv[u] = R[o]; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int row = r0 + 16 * u + (lane >> 4);
+                if (r0 + 16 * u >= i1) break;                                 // uniform over the wave
+                const bool use = row < i1 && sr[u] < 0;
+                const size_t o = (size_t)row * XB_SP + v;
+                double t_ = use ? tv[u] : 0.0, p_ = 0.0, r_ = 0.0;
+                if (use && row < 2) {
+                    double sd = 0.0;
+#pragma unroll
+                    for (int w = 0; w < XB_DSPLIT; ++w) sd += drvpart[(row * XB_DSPLIT + w) * XB_SP + v];
+                    t_ = sc[row] * sd; T[o] = t_;
+                }
+                if (INIT) { if (use) { r_ = t_ - xtb_rhs(b, row, v, s); R[o] = r_; } }
+                else if (use) { p_ = pv[u]; r_ = rv[u]; }
+                if (!INIT) { G[0] = XB_MFMA(p_, t_, G[0]); G[1] = XB_MFMA(p_, r_, G[1]); G[2] = XB_MFMA(t_, r_, G[2]); G[3] = XB_MFMA(t_, t_, G[3]); }
+                G[4] = XB_MFMA(r_, r_, G[4]);
+            }
+        }
+    }
+    // ---- one partial per workgroup: the four waves added in a fixed order; entry (register u, lane l) is (i = l / 16 + 4 u, j = l % 16) ----
+#pragma unroll
+    for (int g = 0; g < XB_NG; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) lg[wv][g][u][lane] = G[g][u];
+    __syncthreads();
+    for (int e = threadIdx.x; e < XB_NG * 256; e += XT_NT) {
+        const int g = e >> 8, u = (e >> 6) & 3, l = e & 63;
+        gpart[(size_t)blockIdx.x * (XB_NG * 256) + e] = (lg[0][g][u][l] + lg[1][g][u][l]) + (lg[2][g][u][l] + lg[3][g][u][l]);
+    }
+}
+
+// ---- Gram matrices: the row kernel's partials, reduced in a fixed order ----------------------------------------------------------------
+// 16 entries per workgroup, 16 slices of the partial list per entry (slice q adds partials q, q + 16, ...), the slices combined in order.
+__global__ __launch_bounds__(XT_NT) void k_xtb_gred(int npart, const double *__restrict__ gpart, double *__restrict__ gfin, const XCtrl *ctrl)
+{
+    __shared__ double red[16][17];
+    if (ctrl->done) return;
+    const int el = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int e = 16 * (int)blockIdx.x + el;
+    red[q][el] = xtb_list_sum(gpart + e, (size_t)XB_NG * 256, q, npart, 16);
+    __syncthreads();
+    if (q == 0) {
+        double a = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a += red[u][el];
+        gfin[e] = a;
+    }
+}
+
+// ---- the s x s algebra of one iteration: ONE wave (no workgroup barriers; the matrices live in LDS, entry (i, j) = e / 16, e % 16 of lane
+// e % 64) -----------------------------------------------------------------------------------------------------------------------------------
+// mats: c | M1 = -W | M2 = beta W | M3 = c M1, each 16 x 16 row-major, zero outside s x s.  it = -1: set-up (P = 0, R = A Y0 - B): only
+// R'R is read; c = M2 = M3 = 0, W from R'R, first stop test on ||r|| (iterative_solvers_gpu.cu:418), later ones on ||r||^2 (:448).
+#define XB_M(name) double (*name)[17]
+#define XB_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+__device__ __forceinline__ void xtb_mm(XB_M(C), XB_M(A), XB_M(B), bool ta, double alpha, XB_M(D), double delta)
+{
+    // C = alpha op(A) B + delta D; op = transpose if ta; D may be null; C may alias A, B or D.  All matrices are zero outside their
+    // leading s x s block, so the loops run over the full 16 (compile-time bounds: the 80 LDS reads of a lane are issued together).
+    // Lane l owns entries (l / 16 + 4 u, l % 16), u = 0 ... 3: one column index, four rows.
+    const int j = threadIdx.x & 15, i0 = threadIdx.x >> 4;
+    double bcol[16], acc[4];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) bcol[k] = B[k][j];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 4 * u;
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) { a0 += (ta ? A[k][i] : A[i][k]) * bcol[k]; a1 += (ta ? A[k + 1][i] : A[i][k + 1]) * bcol[k + 1]; }
+        acc[u] = alpha * (a0 + a1) + (D ? delta * D[i][j] : 0.0);
+    }
+    XB_WSYNC();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) C[i0 + 4 * u][j] = acc[u];
+    XB_WSYNC();
+}
+__device__ __forceinline__ void xtb_symmetrise(XB_M(A), int s)
+{
+    double acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int e = (int)threadIdx.x + 64 * u, i = e >> 4, j = e & 15; acc[u] = (i < s && j < s) ? 0.5 * (A[i][j] + A[j][i]) : 0.0; }
+    XB_WSYNC();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int e = (int)threadIdx.x + 64 * u; A[e >> 4][e & 15] = acc[u]; }
+    XB_WSYNC();
+}
+// in-place Cholesky of the leading s x s block (lower triangle); false on a non-positive pivot (uniform: every lane reads the same pivots)
+__device__ __forceinline__ bool xtb_chol(XB_M(A), int s)
+{
+    bool ok = true;
+    if ((int)threadIdx.x >= s && threadIdx.x < 16) A[threadIdx.x][threadIdx.x] = 1.0;      // padding: unit diagonal (the rest of it is zero)
+    XB_WSYNC();
+    for (int k = 0; k < s; ++k) {
+        const double d = A[k][k];
+        if (!(d > 0.0)) ok = false;
+        const double ld = sqrt(d > 0.0 ? d : 1.0);
+        XB_WSYNC();
+        if ((int)threadIdx.x == k) A[k][k] = ld;
+        else if ((int)threadIdx.x > k && (int)threadIdx.x < s) A[threadIdx.x][k] = A[threadIdx.x][k] / ld;
+        XB_WSYNC();
+        const int j = threadIdx.x & 15, i0 = threadIdx.x >> 4;
+        const double ljk = A[j][k];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 4 * u;
+            if (i > k && j > k && j <= i && i < s) A[i][j] -= A[i][k] * ljk;
+        }
+        XB_WSYNC();
+    }
+    return ok;
+}
+// (padding rows / columns of L beyond s carry a unit diagonal, see xtb_chol: the loops below run over the full 16 with compile-time bounds)
+__device__ __forceinline__ void xtb_chol_solve(XB_M(X), XB_M(L), XB_M(B), int s)
+{
+    const int j = threadIdx.x & 15;
+    double x[16];
+    if (threadIdx.x < 16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) x[i] = B[i][j];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            double a = x[i];
+#pragma unroll
+            for (int p = 0; p < i; ++p) a -= L[i][p] * x[p];
+            x[i] = a / L[i][i];
+        }
+#pragma unroll
+        for (int i = 15; i >= 0; --i) {
+            double a = x[i];
+#pragma unroll
+            for (int p = i + 1; p < 16; ++p) a -= L[p][i] * x[p];
+            x[i] = a / L[i][i];
+        }
+    }
+    XB_WSYNC();                                                               // X may alias B
+    if (threadIdx.x < 16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) X[i][j] = (i < s && j < s) ? x[i] : 0.0;
+    }
+    XB_WSYNC();
+}
+__global__ __launch_bounds__(64) void k_xtb_small(int it, int s, const double *__restrict__ gfin, double *__restrict__ mats, XCtrl *ctrl, double tol2)
+{
+    __shared__ double Gm[XB_NG][16][17], Lp[16][17], Cm[16][17], Vm[16][17], Bm[16][17], Grn[16][17], Gprn[16][17], Gg[16][17], Wm[16][17], Tm[16][17];
+    if (ctrl->done) return;
+    // Gram matrices: entry e = (register u, lane l) of the row kernel's accumulators is (l / 16 + 4 u, l % 16)
+#pragma unroll
+    for (int g = 0; g < XB_NG; ++g)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int l = threadIdx.x; Gm[g][(l >> 4) + 4 * u][l & 15] = gfin[g * 256 + u * 64 + l]; }
+    XB_WSYNC();
+    const bool init = it < 0;
+    double rr_new;
+    if (init) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = (int)threadIdx.x + 64 * u, i = e >> 4, j = e & 15;
+            Cm[i][j] = 0.0; Bm[i][j] = 0.0;
+            const double g = (i < s && j < s) ? 0.5 * (Gm[4][i][j] + Gm[4][j][i]) : 0.0;
+            Grn[i][j] = g; Gg[i][j] = g;
+        }
+        XB_WSYNC();
+        rr_new = Grn[0][0];
+    } else {
+        // P'T is symmetric by construction of A; symmetrise its rounding.  Tm keeps it, Lp becomes its Cholesky factor
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = (int)threadIdx.x + 64 * u, i = e >> 4, j = e & 15;
+            const double g = (i < s && j < s) ? 0.5 * (Gm[0][i][j] + Gm[0][j][i]) : 0.0;
+            Lp[i][j] = g; Tm[i][j] = g;
+        }
+        XB_WSYNC();
+        if (!xtb_chol(Lp, s)) {                                               // no step can be taken: stop BEFORE this iteration's update (uniform)
+            if (threadIdx.x == 0) { ctrl->pad[0] = 1; ctrl->done = it + 1; }
+            return;
+        }
+        xtb_chol_solve(Cm, Lp, Gm[1], s);                                     // (P'T)^-1 P'R
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int e = (int)threadIdx.x + 64 * u; Cm[e >> 4][e & 15] = -Cm[e >> 4][e & 15]; }     // c = -(...)
+        XB_WSYNC();
+        xtb_mm(Vm, Gm[3], Cm, false, 1.0, Gm[2], 1.0);                     // V = T'T c + T'R      (= T'R+)
+        xtb_chol_solve(Bm, Lp, Vm, s);                                        // beta
+        // R+'R+ = R'R + c'T'R + (c'T'R)' + c'(T'T c) = R'R + c'V + (T'R)'c
+        xtb_mm(Grn, Cm, Vm, true, 1.0, Gm[4], 1.0);
+        xtb_mm(Grn, Gm[2], Cm, true, 1.0, Grn, 1.0);
+        xtb_symmetrise(Grn, s);
+        rr_new = Grn[0][0];
+        // Gram matrix of D = -R+ + P beta (P'P = I): R+'R+ - beta'(P'R+) - (P'R+)'beta + beta'beta, P'R+ = P'R + P'T c
+        xtb_mm(Gprn, Tm, Cm, false, 1.0, Gm[1], 1.0);
+        xtb_mm(Gg, Bm, Bm, true, 1.0, Grn, 1.0);
+        xtb_mm(Gg, Bm, Gprn, true, -1.0, Gg, 1.0);
+        xtb_mm(Gg, Gprn, Bm, true, -1.0, Gg, 1.0);
+        xtb_symmetrise(Gg, s);
+    }
+    const bool stop = init ? !(sqrt(rr_new) > tol2) : !(rr_new > tol2);
+    // W = L^-T of the Gram matrix's Cholesky factor: W' G W = I.  A failure here still lets this iteration's update of Y stand.
+    const bool okg = xtb_chol(Gg, s);
+    // W = (L')^-1: column j of W solves L' w = e_j (upper triangular), by lane j
+    if (threadIdx.x < 16) {
+        const int jj = threadIdx.x;
+        double w[16];
+#pragma unroll
+        for (int r = 15; r >= 0; --r) {
+            double a = (r == jj) ? 1.0 : 0.0;
+#pragma unroll
+            for (int p = r + 1; p < 16; ++p) a -= Gg[p][r] * w[p];
+            w[r] = a / Gg[r][r];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Wm[r][jj] = (r < s && jj < s && okg) ? w[r] : 0.0;
+    }
+    XB_WSYNC();
+    xtb_mm(Vm, Bm, Wm, false, 1.0, nullptr, 0.0);                          // M2 = beta W
+    xtb_mm(Tm, Cm, Wm, false, -1.0, nullptr, 0.0);                         // M3 = c M1 = -c W
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int e = (int)threadIdx.x + 64 * u, i = e >> 4, j = e & 15;
+        mats[0 * 256 + e] = Cm[i][j]; mats[1 * 256 + e] = -Wm[i][j]; mats[2 * 256 + e] = Vm[i][j]; mats[3 * 256 + e] = Tm[i][j];
+    }
+    if (threadIdx.x == 0) {
+        ctrl->rr[(it + 1) & 1] = rr_new; ctrl->rr[it & 1] = rr_new;
+        ctrl->iters = it + 1;
+        if (!okg) ctrl->pad[0] = 2;
+        if (stop || !okg) ctrl->done = it + 2;                                // the step kernel of this iteration still runs (see k_xt_step)
+    }
+}
+
+// ---- panel updates: Y += P c ; R += T c ; P = R M1 + T M3 + P M2 ; Q = S P -------------------------------------------------------------
+// 16 rows per wave and step: the three panels as A operands (row on i, vector on k), the 16 x 16 matrices as B operands, Y and R as
+// accumulator input.  P is formed from the ORIGINAL R, T, P (M3 = c M1), so no result has to change its register map.
+__global__ __launch_bounds__(XT_NT) void k_xtb_step(int m, int it, const double *__restrict__ mats, double *__restrict__ Y, double *__restrict__ R,
+                                                    double *__restrict__ P, const double *__restrict__ T, const double *__restrict__ sc,
+                                                    const int *__restrict__ nsrank, double *__restrict__ Q, double *__restrict__ QS, const XCtrl *ctrl)
+{
+    __shared__ int sdone;
+    if (threadIdx.x == 0) { const int d = ctrl->done; sdone = d != 0 && it + 1 >= d; }
+    __syncthreads();
+    if (sdone) return;
+    const int lane = threadIdx.x & 63, a = lane & 15, b = lane >> 4;
+    const int wv = threadIdx.x >> 6;
+    double cB[4], m1B[4], m2B[4], m3B[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int o = (4 * kk + b) * 16 + a;
+        cB[kk] = mats[o]; m1B[kk] = mats[256 + o]; m2B[kk] = mats[512 + o]; m3B[kk] = mats[768 + o];
+    }
+    const int ngroups = (m + 15) / 16;
+    for (int g = (int)blockIdx.x * 4 + wv; g < ngroups; g += (int)gridDim.x * 4) {
+        const int row0 = 16 * g;
+        double pa[4], ta[4], ra[4];
+        const bool oka = row0 + a < m;
+        const size_t oa = (size_t)(row0 + a) * XB_SP + b;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { pa[kk] = oka ? P[oa + 4 * kk] : 0.0; ta[kk] = oka ? T[oa + 4 * kk] : 0.0; ra[kk] = oka ? R[oa + 4 * kk] : 0.0; }
+        dbl4 yN, rN, pN = (dbl4)(0.0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = row0 + b + 4 * u;
+            const bool ok = row < m;
+            yN[u] = ok ? Y[(size_t)row * XB_SP + a] : 0.0; rN[u] = ok ? R[(size_t)row * XB_SP + a] : 0.0;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            yN = XB_MFMA(pa[kk], cB[kk], yN);
+            rN = XB_MFMA(ta[kk], cB[kk], rN);
+            pN = XB_MFMA(ra[kk], m1B[kk], pN); pN = XB_MFMA(ta[kk], m3B[kk], pN); pN = XB_MFMA(pa[kk], m2B[kk], pN);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int row = row0 + b + 4 * u;
+            if (row < m) {
+                const size_t o = (size_t)row * XB_SP + a;
+                Y[o] = yN[u]; R[o] = rN[u]; P[o] = pN[u];
+                const double qv = sc[row] * pN[u];
+                Q[o] = qv;
+                const int sr = nsrank[row];
+                if (sr >= 0) QS[xtb_qs_pos(sr, a)] = qv;
+            }
+        }
+    }
+}
+// panels before the first product: Y = [y, 0, ...], Q = S Y, P = 0
+__global__ void k_xtb_init(int m, const double *__restrict__ y, const double *__restrict__ sc, const int *__restrict__ nsrank,
+                           double *__restrict__ Y, double *__restrict__ P, double *__restrict__ Q, double *__restrict__ QS)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * XB_SP) return;
+    const int row = i >> 4, v = i & 15;
+    const double yv = v == 0 ? y[row] : 0.0;
+    Y[i] = yv; P[i] = 0.0;
+    const double qv = sc[row] * yv;
+    Q[i] = qv;
+    const int sr = nsrank[row];
+    if (sr >= 0) QS[xtb_qs_pos(sr, v)] = qv;
+}
+__global__ void k_xtb_extract(int m, const double *__restrict__ Y, double *__restrict__ y)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) y[i] = Y[(size_t)i * XB_SP];
+}
+
+// ---- host loop ------------------------------------------------------------------------------------------------------------------------
+// Returns 0 with the scaled solution of column 0 in A.y; DKMC_XTB_BREAKDOWN (> 0, no error recorded) when an s x s system lost
+// definiteness: A.y then holds the last good iterate and the caller continues with the single-vector loop from it.
+int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
+{
+    Engine &e = eng(); hipStream_t st = e.stream;
+    const int m = A.m, s = A.s, so = s <= 8 ? 8 : 16;
+    const size_t pan = (size_t)m * XB_SP;
+    const long long ncell = (long long)A.nK * A.nW;
+    const int ng = std::max(128, std::min(A.nK, 1024));                                     // row-kernel workgroups = partial Gram matrices
+    double *panels = (double *)scratch(S_XTB_PANELS, pan * 5 * 8);
+    double *QS = (double *)scratch(S_XTB_QS, (size_t)A.ns_pad * XB_SP * 8);
+    double *rowpartB = (double *)scratch(S_XTB_ROWPART, (size_t)(ncell + 1) * XT_R * so * 8);
+    double *colpartB = (double *)scratch(S_XTB_COLPART, (size_t)(A.nrecords + 1) * XT_C * so * 8);
+    double *gpart = (double *)scratch(S_XTB_GRAM, (size_t)ng * XB_NG * 256 * 8);
+    double *small = (double *)scratch(S_XTB_SMALL, (size_t)(4 * 256 + 2 * XB_DSPLIT * XB_SP + XB_NG * 256) * 8);
+    if (!panels || !QS || !rowpartB || !colpartB || !gpart || !small) return e.err_code;
+    double *Y = panels, *R = panels + pan, *P = panels + 2 * pan, *T = panels + 3 * pan, *Q = panels + 4 * pan;
+    double *mats = small, *drvpart = small + 4 * 256, *gfin = drvpart + 2 * XB_DSPLIT * XB_SP;
+    HIPCHK(hipMemsetAsync(QS, 0, (size_t)A.ns_pad * XB_SP * 8, st));
+    HIPCHK(hipMemsetAsync(rowpartB, 0, (size_t)(ncell + 1) * XT_R * so * 8, st));
+    HIPCHK(hipMemsetAsync(colpartB, 0, (size_t)(A.nrecords + 1) * XT_C * so * 8, st));
+    HIPCHK(hipMemsetAsync(A.ctrl, 0, sizeof(XCtrl), st));
+    hipLaunchKernelGGL(k_xtb_init, dim3((unsigned)((pan + 255) / 256)), dim3(256), 0, st, m, (const double *)A.y, A.sc, A.nsrank, Y, P, Q, QS);
+    const int ntb = (A.item_n + 3) / 4;
+    const int nnb = 2 * XB_DSPLIT + (std::max(m - 2, 1) + 15) / 16;
+    const int gs = xt_grid((m + 15) / 16, 4, 2048);
+    const bool prof = e.profiling != 0;
+    static hipEvent_t evs[4 * 8]; static bool evs_ready = false;
+    if (prof && !evs_ready) { for (auto &ev : evs) HIPCHK(hipEventCreate(&ev)); evs_ready = true; }
+    double prof_long_ms = 0.0, prof_short_ms = 0.0; int prof_long_n = 0, prof_short_n = 0;
+    auto product = [&](hipEvent_t e0, hipEvent_t e1) {
+        if (ntb > 0) {
+            if (A.nt_loads) hipExtLaunchKernelGGL((k_xtb_apply<1>), dim3(ntb), dim3(XT_NT), 0, st, e0, e1, 0, A.item_n, A.items, A.tiles, A.sub_base, A.tval,
+                                                  (const double *)QS, A.nW, rowpartB, colpartB, (const XCtrl *)A.ctrl, so);
+            else hipExtLaunchKernelGGL((k_xtb_apply<0>), dim3(ntb), dim3(XT_NT), 0, st, e0, e1, 0, A.item_n, A.items, A.tiles, A.sub_base, A.tval,
+                                       (const double *)QS, A.nW, rowpartB, colpartB, (const XCtrl *)A.ctrl, so);
+        }
+        hipLaunchKernelGGL(k_xtb_neigh, dim3(nnb), dim3(XT_NT), 0, st, m, A.rp, A.ci, A.val, (const double *)Q, A.sc, A.nsrank, (const XCtrl *)A.ctrl, T, drvpart);
+    };
+#define XB_ROWS_ARGS A.ns, A.nK, A.nW, m, s, so, A.wrange, A.nitem_w, (const double *)rowpartB, (const double *)colpartB, A.srow, A.sS, A.nsrank, A.sc, \
+                     (const double *)drvpart, T, (const double *)P, R, A.b, gpart, (const XCtrl *)A.ctrl
+    // ---- R = A Y0 - B ; first directions ----
+    product(nullptr, nullptr);
+    hipLaunchKernelGGL((k_xtb_rows<1>), dim3(ng), dim3(XT_NT), 0, st, XB_ROWS_ARGS);
+    hipLaunchKernelGGL(k_xtb_gred, dim3(XB_NG * 16), dim3(XT_NT), 0, st, ng, (const double *)gpart, gfin, (const XCtrl *)A.ctrl);
+    hipLaunchKernelGGL(k_xtb_small, dim3(1), dim3(64), 0, st, -1, s, (const double *)gfin, mats, A.ctrl, A.tol2);
+    hipLaunchKernelGGL(k_xtb_step, dim3(gs), dim3(XT_NT), 0, st, m, -1, (const double *)mats, Y, R, P, (const double *)T, A.sc, A.nsrank, Q, QS, (const XCtrl *)A.ctrl);
+    KCHK();
+    int it = 0, launched = 0, batch = 4;
+    if (e.x_iter_hint > 12) batch = e.x_iter_hint - 4;
+    XCtrl h{};
+    for (;;) {
+        HIPCHK(hipMemcpyAsync(&h, A.ctrl, sizeof(XCtrl), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (prof && launched) {
+            for (int bq = 0; bq < 8 && bq * XT_PROF_STRIDE < launched; ++bq) {
+                if (it - launched + bq * XT_PROF_STRIDE >= h.iters) break;
+                float ms = 0.f;
+                HIPCHK(hipEventElapsedTime(&ms, evs[4 * bq], evs[4 * bq + 1])); prof_long_ms += ms; ++prof_long_n;
+                HIPCHK(hipEventElapsedTime(&ms, evs[4 * bq + 2], evs[4 * bq + 3])); prof_short_ms += ms; ++prof_short_n;
+            }
+        }
+        if (h.done) break;
+        if (it >= 200000) { dkmc_fail(4, "block-CG: no convergence after 200000 iterations", __FILE__, __LINE__); break; }
+        for (int bq = 0; bq < batch; ++bq, ++it) {
+            const bool pb = prof && bq < 8 * XT_PROF_STRIDE && (bq % XT_PROF_STRIDE == 0);
+            const int sl = bq / XT_PROF_STRIDE;
+            product(pb ? evs[4 * sl] : nullptr, pb ? evs[4 * sl + 1] : nullptr);
+            hipExtLaunchKernelGGL((k_xtb_rows<0>), dim3(ng), dim3(XT_NT), 0, st, pb ? evs[4 * sl + 2] : nullptr, pb ? evs[4 * sl + 3] : nullptr, 0, XB_ROWS_ARGS);
+            hipLaunchKernelGGL(k_xtb_gred, dim3(XB_NG * 16), dim3(XT_NT), 0, st, ng, (const double *)gpart, gfin, (const XCtrl *)A.ctrl);
+            hipLaunchKernelGGL(k_xtb_small, dim3(1), dim3(64), 0, st, it, s, (const double *)gfin, mats, A.ctrl, A.tol2);
+            hipLaunchKernelGGL(k_xtb_step, dim3(gs), dim3(XT_NT), 0, st, m, it, (const double *)mats, Y, R, P, (const double *)T, A.sc, A.nsrank, Q, QS, (const XCtrl *)A.ctrl);
+        }
+        launched = batch;
+        KCHK();
+        if (e.x_iter_hint > 12) batch = 4; else if (batch < 64) batch *= 2;
+    }
+#undef XB_ROWS_ARGS
+    if (e.err_code) return e.err_code;
+    hipLaunchKernelGGL(k_xtb_extract, dim3((m + 255) / 256), dim3(256), 0, st, m, (const double *)Y, A.y);
+    KCHK();
+    e.x_iter_hint = h.iters;
+    if (iters_out) *iters_out = h.iters;
+    if (rr_out) *rr_out = h.rr[h.iters & 1];
+    if (prof) {
+        e.stats.spmv_long_ms = prof_long_ms; e.stats.spmv_short_ms = prof_short_ms;
+        e.stats.spmv_long_launches = prof_long_n; e.stats.spmv_short_launches = prof_short_n;
+    }
+    return h.pad[0] ? DKMC_XTB_BREAKDOWN : 0;
+}
+
+// ---- test aid (tests/test_gpu_block_cg.py; no counterpart in the reference) ---------------------------------------------------------------
+// On the X left resident by the last single-GPU solve: the tile x panel product of 16 test vectors (k_xtb_apply + the fold of k_xtb_rows)
+// against 16 passes of the single-vector tile kernel (xt_tile_sums_mv).  Reports the largest deviation and the largest sum.
+__global__ void k_xtb_test_panel(int ns, double *__restrict__ QS)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns * XB_SP) return;
+    const int r = i >> 4, v = i & 15;
+    QS[xtb_qs_pos(r, v)] = 0.25 + (double)((((unsigned)r * 2654435761u) ^ ((unsigned)v * 40503u)) >> 20) / 4096.0 + 0.125 * v;
+}
+__global__ void k_xtb_test_column(int ns, int v, const double *__restrict__ QS, double *__restrict__ vS)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < ns) vS[r] = QS[xtb_qs_pos(r, v)];
+}
+__global__ void k_xtb_test_compare(int ns, int v, const int *__restrict__ srow, const double *__restrict__ T, const double *__restrict__ ref, double *__restrict__ out)
+{
+    // out[0] = max |T - ref|, out[1] = max |ref| (atomicMax on the bits of non-negative doubles)
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= ns) return;
+    const double a = T[(size_t)srow[r] * XB_SP + v], b = ref[r];
+    atomicMax(reinterpret_cast<unsigned long long *>(out), (unsigned long long)__double_as_longlong(fabs(a - b)));
+    atomicMax(reinterpret_cast<unsigned long long *>(out + 1), (unsigned long long)__double_as_longlong(fabs(b)));
+}
+int xt_tile_sums_mv(const double *vS, double *out);
+extern "C" int dkmc_xtb_check_product(int width, double *max_abs_diff, double *max_abs)
+{
+    Engine &e = eng(); hipStream_t st = e.stream; const XTState &X = g_xt;
+    if (!X.valid || comm_attached() || X.tile_n != X.ntiles || X.ns <= 0) return dkmc_fail(13, "xtb_check_product: needs the X of a single-GPU solve", __FILE__, __LINE__);
+    const int m = X.Nsub, ns = X.ns, s = std::max(2, std::min(width, 16)), so = s <= 8 ? 8 : 16;
+    const size_t pan = (size_t)m * XB_SP;
+    const long long ncell = (long long)X.nK * X.nW;
+    const int nrec = X.nitems >> X.rec_shift, ng = 64;
+    double *panels = (double *)scratch(S_XTB_PANELS, pan * 5 * 8);
+    double *QS = (double *)scratch(S_XTB_QS, (size_t)X.ns_pad * XB_SP * 8);
+    double *rowpartB = (double *)scratch(S_XTB_ROWPART, (size_t)(ncell + 1) * XT_R * so * 8);
+    double *colpartB = (double *)scratch(S_XTB_COLPART, (size_t)(nrec + 1) * XT_C * so * 8);
+    double *gpart = (double *)scratch(S_XTB_GRAM, (size_t)1024 * XB_NG * 256 * 8);
+    double *small = (double *)scratch(S_XTB_SMALL, (size_t)(4 * 256 + 2 * XB_DSPLIT * XB_SP + XB_NG * 256) * 8);
+    double *tmp = (double *)scratch(S_XT_T_MISC, (size_t)4 * X.ns_pad * 8);
+    XCtrl *ctrl = (XCtrl *)scratch(S_MISC2, 256);
+    double *sS = (double *)e.buf[S_CG_PS], *sc = (double *)e.buf[S_CG_S], *rhs = (double *)e.buf[S_X_RHS];
+    if (!panels || !QS || !rowpartB || !colpartB || !gpart || !small || !tmp || !ctrl || !sS || !sc || !rhs) return e.err_code ? e.err_code : dkmc_fail(13, "xtb_check_product: no solver state", __FILE__, __LINE__);
+    sS += X.ns_pad;
+    double *T = panels + 3 * pan, *R = panels + pan, *P = panels + 2 * pan, *drvpart = small + 4 * 256;
+    double *vS = tmp, *ref = tmp + X.ns_pad, *res = tmp + 2 * (size_t)X.ns_pad;
+    HIPCHK(hipMemsetAsync(tmp, 0, (size_t)4 * X.ns_pad * 8, st));
+    HIPCHK(hipMemsetAsync(QS, 0, (size_t)X.ns_pad * XB_SP * 8, st));
+    HIPCHK(hipMemsetAsync(panels, 0, pan * 5 * 8, st));
+    HIPCHK(hipMemsetAsync(small, 0, (size_t)(4 * 256 + 2 * XB_DSPLIT * XB_SP) * 8, st));
+    HIPCHK(hipMemsetAsync(rowpartB, 0, (size_t)(ncell + 1) * XT_R * so * 8, st));
+    HIPCHK(hipMemsetAsync(colpartB, 0, (size_t)(nrec + 1) * XT_C * so * 8, st));
+    HIPCHK(hipMemsetAsync(ctrl, 0, sizeof(XCtrl), st));
+    hipLaunchKernelGGL(k_xtb_test_panel, dim3((ns * XB_SP + 255) / 256), dim3(256), 0, st, ns, QS);
+    hipLaunchKernelGGL((k_xtb_apply<1>), dim3((X.item_n + 3) / 4), dim3(XT_NT), 0, st, X.item_n, (const XItem *)g_xb.items + X.item_lo, (const XTile *)g_xb.tiles, (int)X.sub_base,
+                       (const double *)g_xb.tval, (const double *)QS, X.nW, rowpartB, colpartB, (const XCtrl *)ctrl, so);
+    hipLaunchKernelGGL((k_xtb_rows<1>), dim3(ng), dim3(XT_NT), 0, st, ns, X.nK, X.nW, m, s, so, (const int2 *)g_xb.wrange, (const int *)g_xb.nitem_w, (const double *)rowpartB,
+                       (const double *)colpartB, (const int *)g_xb.srow, (const double *)sS, (const int *)g_xb.nsrank, (const double *)sc, (const double *)drvpart, T,
+                       (const double *)P, R, (const double *)rhs, gpart, (const XCtrl *)ctrl);
+    KCHK();
+    const int gb = (ns + 255) / 256;
+    for (int v = 0; v < so; ++v) {
+        hipLaunchKernelGGL(k_xtb_test_column, dim3(gb), dim3(256), 0, st, ns, v, (const double *)QS, vS);
+        int rc = xt_tile_sums_mv(vS, ref); if (rc) return rc;
+        // T holds sS * (tile sums): compare with sS * ref
+        hipLaunchKernelGGL(k_xt_vec_mul, dim3(gb), dim3(256), 0, st, ns, ref, (const double *)sS);
+        hipLaunchKernelGGL(k_xtb_test_compare, dim3(gb), dim3(256), 0, st, ns, v, (const int *)g_xb.srow, (const double *)T, (const double *)ref, res);
+    }
+    double h[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(h, res, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (max_abs_diff) *max_abs_diff = h[0];
+    if (max_abs) *max_abs = h[1];
+    return e.err_code;
+}

@@ -1,0 +1,72 @@
+// xtiles.h -- layout of the tiled form of X shared by xt.hip (assembly, single-vector CG, power pass) and xtb.hip (block-CG with
+// the MFMA tile x panel product).  See the head of xt.hip for the storage scheme.
+#pragma once
+#include "xshared.h"
+
+#define XT_R 32                      // S-rows per tile
+#define XT_C 256                     // S-columns per tile
+#define XT_SBW 32                    // columns per sub-block
+#define XT_SUB (XT_R * XT_SBW)       // doubles per sub-block (8 KiB)
+#define XT_NT 256
+#define XT_MAXKC 16
+#define XT_PROF_STRIDE 8
+
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+
+struct __attribute__((aligned(16))) XTile { int k, w; unsigned mask; int soff; };   // cell (k, w); present sub-blocks; first sub-block slot
+struct __attribute__((aligned(32))) XItem { int t0, t1, w, c, k0; unsigned mask0; int soff0, pad; };   // tiles [t0, t1) of strip w; c = position of the run in its strip; descriptor of tile t0; pad = record of its column sums, colpart[pad * 256]: the run's own (c = 0; pad = its index in the item list) or, on one GPU, one record per aligned group of four runs -- the four waves of a workgroup (c = 1; pad = index / 4; every strip's run count padded to a multiple of four with empty runs)
+struct XCtrl { double rr[2]; int done_local, sharded; int done; int iters; int abort_local, aborted; int pad[2]; };
+// `done` (non-zero) gates every kernel of the loop; see k_xt_step for its iteration stamp.  Single GPU: set by the step kernel.  Sharded solve: the direction kernel only sets
+// done_local; rank 0's done_local travels in the all-reduced buffer (slot ns) and k_xt_rows_apply turns it into `done` on every
+// rank in the same iteration -- all control flow derives from data every rank received from the same collective, so the ranks
+// cannot leave the loop at different iterations even if their arithmetic differed in a bit.
+
+struct SNodes {                      // S in rank order, padded to a multiple of XT_C (flag 0 = no entries)
+    const double *x, *y, *z, *cb;
+    const int *flag, *slot, *mr;     // class flags; row of the coefficient cache (vacancies) / column (metals), -1 if none
+};
+
+struct XTState {
+    // shape of the last assembly
+    int Nsub = 0, ns = 0, ns_pad = 0, nK = 0, nW = 0, ntiles = 0, nitems = 0, kc = 1, maxchunk = 1, rec_shift = 0;
+    long long nsub_total = 0, xs_nnz = 0;
+    unsigned long long t_upper = 0;
+    // this rank's share
+    int item_lo = 0, item_n = 0, tile_lo = 0, tile_n = 0, w_lo = 0, w_hi = 0; long long sub_base = 0, sub_n = 0;
+    bool valid = false;
+};
+
+struct XTBuffers {
+    SNodes S; int *srow; XTile *tiles; XItem *items; int2 *wrange; int *nitem_w; double *tval, *rowpart, *colpart;
+    xrp_t *rp, *dpos; int *ci; double *val; int *nsrank;
+    unsigned *cmask; int *toff;      // census of the last assembly (kept for dkmc_xt_time_share)
+};
+
+extern XTState g_xt;
+extern XTBuffers g_xb;
+
+static inline int xt_grid(long long work, int per_block, int cap)
+{
+    long long b = (work + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+// ---- block-CG on the tiled X (xtb.hip) ----
+#define DKMC_XTB_BREAKDOWN 1000      // xtb_cg: an s x s system lost definiteness; y holds the last good iterate (not an error)
+struct XtbArgs {
+    int m, ns, ns_pad, nK, nW;                    // system rows; |S|; padded |S|; row blocks; windows
+    int s;                                        // block width (2 ... 16)
+    const XItem *items; int item_n;               // this rank's runs (padded to groups of four per strip)
+    const XTile *tiles; int sub_base; const double *tval;
+    const int2 *wrange; const int *nitem_w; int nrecords;
+    const int *srow; const double *sS; const int *nsrank;
+    const xrp_t *rp; const int *ci; const double *val;      // neighbour part Xs (CSR, unscaled, diagonal included)
+    const double *sc;                             // Jacobi scaling 1 / sqrt(diag)
+    const double *b;                              // scaled right-hand side
+    double *y;                                    // in: scaled start vector y / s; out: scaled solution
+    XCtrl *ctrl; double tol2; bool nt_loads;
+};
+int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out);
+__global__ void k_xt_vec_mul(int m, double *__restrict__ y, const double *__restrict__ s);

@@ -40,7 +40,7 @@ class dkmc_stats(C.Structure):
                 ("spmv_tiles", C.c_int), ("spmv_pad2", C.c_int), ("spmv_tile_entries", C.c_longlong),
                 ("xt_subblocks", C.c_longlong), ("xt_local_subblocks", C.c_longlong), ("xt_items", C.c_int), ("xt_kc", C.c_int),
                 ("xt_sparse_nnz", C.c_longlong), ("xt_ns", C.c_int), ("xt_split_launch", C.c_int),
-                ("kcg_ms", C.c_double), ("kcg_iters_timed", C.c_int), ("kcg_pad", C.c_int), ("pair_ms", C.c_double), ("pair_evaluated", C.c_longlong), ("pair_tested", C.c_longlong), ("xt_records", C.c_longlong)]
+                ("kcg_ms", C.c_double), ("kcg_iters_timed", C.c_int), ("kcg_pad", C.c_int), ("pair_ms", C.c_double), ("pair_evaluated", C.c_longlong), ("pair_tested", C.c_longlong), ("xt_records", C.c_longlong), ("xb_width", C.c_int), ("xb_fallback", C.c_int)]
 
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
@@ -58,7 +58,8 @@ SYMBOLS = {
     "dkmc_synchronize": (_I, []),
     "dkmc_set_cg_tolerance": (None, [_D]),
     "dkmc_set_cb_edge_domain": (None, [_I]),
-    "dkmc_set_x_loop": (None, [_I]),
+    "dkmc_set_x_block": (None, [_I]),
+    "dkmc_get_x_block": (_I, []),
     "dkmc_set_pair_cutoff": (None, [_D]),
     "dkmc_set_tcache_budget": (None, [C.c_longlong]),
     "dkmc_set_current_warm_start": (None, [_I]),
@@ -96,6 +97,7 @@ SYMBOLS = {
                                            C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), c_dbl_p]),
     "dkmc_xt_time_share": (_I, [_I, _I, _I, c_dbl_p, c_dbl_p, c_int_p, C.POINTER(C.c_longlong)]),
     "dkmc_xt_check_shares": (_I, [_I, c_dbl_p, c_dbl_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), c_int_p]),
+    "dkmc_xtb_check_product": (_I, [_I, c_dbl_p, c_dbl_p]),
     "dkmc_debug_inject_fault": (None, [_I, _I]),
     "dkmc_comm_unique_id": (_I, [C.c_char_p]),
     "dkmc_comm_init_rccl": (_I, [_I, _I, C.c_char_p]),

@@ -98,6 +98,7 @@ typedef struct dkmc_stats {
     long long pair_evaluated;              /* (site, charged site) pairs inside the screening cut-off of the last pair sum (profiling on) */
     long long pair_tested;                 /* pairs whose distance was tested (all N x N_charged without the cell list; the 3 x 3 columns with it) */
     long long xt_records;                  /* records of column partial sums one matrix-vector product writes (= runs; runs / 4 on one GPU, where the four waves of a workgroup share one) */
+    int xb_width, xb_fallback;             /* block-CG width of the last current solve (1 = single-vector loop); 1 if the block loop lost definiteness and the single-vector loop finished the solve */
 } dkmc_stats;
 
 const char *dkmc_last_error(void);
@@ -128,13 +129,15 @@ void dkmc_set_tcache_budget(long long bytes);
  * rounding of the sum and under the last-bit noise of the reference's atomicAdd order).  0: every pair, exactly the terms the reference
  * sums (potential_solver_gpu.cu:908-958) -- for a parity run. */
 void dkmc_set_pair_cutoff(double x_cut);
-/* CG loop of the current solve on the tiled X, single GPU.  0 (default): three launches per iteration (product, row sums + dots, vector
- * step), which a sharded solve always uses.  1: two launches -- the matrix-vector product forms its vector on the fly (q = beta S p - S r)
- * and emits the partials of p.Ap as a bilinear form; one kernel folds the tile partial sums into the S rows and does every vector
- * update; both dot products are direct sums like the reference's.  Same algorithm (solve_sparse_CG_Jacobi, iterative_solvers_gpu.cu:
- * 405-455), results equal to rounding.  Kept as a tested alternative: on MI355X it is SLOWER (85 071 sites, same box: 32.2 + 13.4 us
- * per iteration against 24.0 + 6.3 + 5.4 us; the saved kernel boundary costs less than the longer dependent chains). */
-void dkmc_set_x_loop(int two_launch);
+/* Width s of the block-CG of the current solve on the tiled X (csrc/xtb.hip).  1: the reference's single-vector loop
+ * (solve_sparse_CG_Jacobi, iterative_solvers_gpu.cu:309-480: same iterate sequence, same start vector).  2 ... 16: block-CG over s
+ * columns -- column 0 carries the physical right-hand side and start vector, columns 1 ... s - 1 fixed-seed auxiliary right-hand sides
+ * that only enlarge the Krylov space; every 32 x 32 sub-block of the tunnelling block is streamed ONCE per sweep and multiplied (it and
+ * its transpose) into 32 x 16 panels by v_mfma_f64_16x16x4_f64 -- the contraction the reference's unfinished split path applies as a
+ * GEMV (add_submatrix_product, iterative_solvers_gpu.cu:634-652).  Same stop test on column 0 (||r||^2 <= tol^2); the solution agrees
+ * with the single-vector loop to the stop tolerance, NOT iterate by iterate.  85 071 sites: 666 -> 208 / 133 / 95 sweeps at s = 4 / 8 / 16. */
+void dkmc_set_x_block(int s);
+int dkmc_get_x_block(void);
 /* 0 (default): warm-start the current solve from gpubuf.atom_virtual_potentials exactly as the
  * reference does (the buffer holds G0*m of the previous step, current_solver_gpu.cu:1015-1016);
  * 1: warm-start from a private unscaled copy of the previous solution. */
@@ -287,6 +290,9 @@ int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_us, double 
  * the rank's windows) and compares the sum of the ranks' results with the one-GPU pass.  subblocks_sum / items_sum: totals over the
  * shares (must equal the stored sub-blocks / items_total: every tile in exactly one share). */
 int dkmc_xt_check_shares(int nranks, double *max_abs_diff, double *max_abs, long long *subblocks_sum, long long *items_sum, int *items_total);
+/* Test aid: on the X left resident by the last single-GPU solve, the MFMA tile x panel product of the block-CG (16 test vectors, one
+ * sweep) against 16 passes of the single-vector tile kernel; largest absolute deviation and largest sum over the S rows. */
+int dkmc_xtb_check_product(int width, double *max_abs_diff, double *max_abs);
 /* Test aid for the error path of a sharded current solve (no counterpart in the reference): the calling rank fails ONCE, in the
  * assembly of X (phase 1) or on the host side of CG iteration `iteration` (phase 2).  Every rank's dkmc_update_power_gpu_sparse then
  * returns non-zero (the failing rank its own code, the others 46) instead of blocking in a collective: the ranks agree on the

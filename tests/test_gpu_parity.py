@@ -795,45 +795,6 @@ def test_tiled_X_agrees_with_csr_X(dev_7p5, hip):
     assert np.abs(b["power"] - a["power"]).max() <= 1e-8 * np.abs(a["power"]).max()
 
 
-def test_two_launch_loop_agrees_with_three_launch_loop(dev_7p5, cell_2p5, hip):
-    """The two CG loops on the tiled X (dkmc_set_x_loop): two launches per iteration (direction formed on the fly inside the product,
-    p.Ap as a bilinear form of what the product holds, fold + vector step in one kernel; opt-in, measured slower) against three
-    (product, row sums + dots, vector step; the default).  Same algorithm: both solutions meet the stop test in the TRUE scaled residual of the
-    CSR matrix, agree to 1e-8 relative, and need the same number of iterations to within a few per cent (the three-launch loop forms
-    r'.r' by a recurrence, the two-launch loop by direct summation like the reference).  85 071 sites at 1e-10 and at the default 1e-6; the
-    2.5 nm device (few tiles, launch-bound); run-to-run bit identity of the two-launch loop."""
-    from devicekmc_amd import params as pm
-    host, L = hip
-    for structure, p0, tols in ((dev_7p5, params_7p5(), (1e-10, 1e-6)), (cell_2p5, pm.KMCParameters(), (1e-10,))):
-        L.dkmc_set_x_format(0)
-        p0.cg_tol = 1e-10; p0.solve_heating_global = False
-        dev, sim, gb, _ = _fresh_device(structure, p0, hip)
-        dev.updateCharge(gb); dev.updatePotential(gb, p0, Vd, 0); dev.updatePower(gb, p0, Vd)
-        rp, ci, data = host.get_last_X()
-        L.dkmc_set_x_format(1)
-        for tol in tols:
-            rec = {}
-            for loop in (0, 1, 1):
-                L.dkmc_set_x_loop(loop)
-                p0.cg_tol = tol
-                L.dkmc_set_cg_tolerance(tol)
-                put(gb, "atom_virtual_potentials", np.zeros(dev.N_atom + 2))
-                dev.updatePower(gb, p0, Vd)
-                st = host.get_stats()
-                cur = dict(m=get(gb, "atom_virtual_potentials").copy(), im=dev.imacro, iters=st["cg_iters_X"])
-                assert _scaled_residual(rp, ci, data, cur["m"], p0.G0, p0.X_loop_G) <= 10 * tol, (loop, tol, cur["iters"])
-                if loop == 1 and 1 in rec:
-                    assert np.array_equal(cur["m"], rec[1]["m"]) and cur["iters"] == rec[1]["iters"] and cur["im"] == rec[1]["im"]
-                rec[loop] = cur
-            L.dkmc_set_x_loop(0)
-            a, b = rec[0], rec[1]
-            assert abs(a["iters"] - b["iters"]) <= max(3, 0.06 * a["iters"]), (a["iters"], b["iters"])      # 790 vs 761 at 85 k sites, 1e-10 (the oracle: 760 ... 799)
-            if tol <= 1e-9:
-                assert abs(b["im"] / a["im"] - 1) <= 1e-8
-                n = min(len(a["m"]), len(b["m"]))
-                assert np.abs(b["m"][:n] - a["m"][:n]).max() <= 1e-8 * np.abs(a["m"][:n]).max()
-
-
 def test_uncached_coefficients_same_bits(dev_7p5, hip):
     """The tunnelling-coefficient cache against its fallback (a device whose cache does not fit evaluates the contact->trap integrals
     directly while the tiles are filled): with the budget forced to zero the same two supersteps give the same bits -- solution, current,

@@ -7,28 +7,35 @@ dissipated power) and the global temperature update, on a synthetic device whose
 the timed region.
 
 Workloads (config.workload):
-  7.5nm   the reference's own 85 071-site single device (structures/single_devices/timing_7.5nm; the configuration its only
-          full-step timing log is quoted on = configs[1]), V = 5, rnd_seed = 5                      [default at N = 1]
-  2.5nm   9 399 sites (configs[0], plumbing)
   tile:K  the 2.5 nm cell tiled K x K laterally: tile:3 = 84 591, tile:5 = 234 975, tile:10 = 939 900 sites
-          (configs[2], the "~1e6" stack)                                                          [default at N > 1]
-          (tile:14 = 1 842 204 sites, 1.4e10 matrix entries, is the largest run so far on one GPU: 66 s per cold superstep)
+          (configs[2], the "~1e6" stack: the configuration north_star's target is stated on)      [default at every N]
+          (tile:17 = 2 716 311 sites, 3.1e10 matrix entries, is the largest run so far on one GPU)
+  7.5nm   the reference's own 85 071-site single device (structures/single_devices/timing_7.5nm; the configuration its only
+          full-step timing log is quoted on = configs[1]), V = 5, rnd_seed = 5
+  2.5nm   9 399 sites (configs[0], plumbing)
+  crossbar_10nm_5pitch   the reference's 110 813-site crossbar (structures/crossbars/timing_10nm_5pitch), V = 1, current solve off
 
-Contract: python bench.py --gpus N --steps K --warmup W ; prints ONE JSON line on rank 0.
+Contract: python bench.py --gpus N --steps K --warmup W ; prints ONE JSON line on rank 0.  `--gpus N` with N > 1 and no rank environment
+starts the N ranks itself (devicekmc_amd/launch.py); a world that is not --gpus is refused.
 
-N = 1: `value` = steps/s of the default workload at the library's default CG tolerance (1e-6, the snapshot's); the same line carries
-`at_log_tolerance` -- the same workload under KMCParameters.log_revision() (1e-12, CB edge on atoms), the configuration in which the
-reference's own log is reproduced, with the timed steps checked against that log -- and `scale_points`: tile:5 and tile:10 measured in
-the same run (tile:10: the cold step + 3 steady steps, reported separately) with their own ms/step split, CG iteration counts, HIP-event
-roofline of the dominant kernel incl. PMC `traffic` at that size, K-CG roofline on the bytes moved, pair-sum entry and a CPU baseline (the
-oracle's CG iteration timed at that size x the GPU run's iteration count); the tile:10 point also carries `strong_scaling_model`: the
-kernels one rank of a 2/4/8-way sharded solve runs, timed on this GPU on that rank's share (all-reduce latency ASSUMED).
+N = 1: `value` = steady-state steps/s of tile:10 at the library's defaults: CG tolerance 1e-6 (the snapshot's) and the block-CG of width 16
+on the tiled X (csrc/xtb.hip).  W >= 1 puts the cold step (coefficient cache, buffer sizing, zero start vector) into the warm-up; it is
+reported as `cold_step`.  The same line carries
+  * `roofline`: the dominant kernel (k_xtb_apply: tile x panel product on the matrix cores) -- HIP-event time of sampled launches,
+    algorithmic bytes AND fp64 flops per launch, HBM `traffic` from two rocprofv3 --pmc child runs;
+  * `reference_order_cg`: the same workload with dkmc_set_x_block(1), the reference's single-vector CG (its iterate sequence): cold + one
+    steady step, sweeps per step, its own kernel roofline, and the strong-scaling model of the sharded solve built on it;
+  * `alt_warm_start`: the optional unscaled warm start of the current solve (never `value`);
+  * `cpu_baseline`: the oracle's CG iteration timed at this size x the REFERENCE algorithm's iteration count (a lower bound on a CPU step);
+  * `device_7p5nm`: the reference's own 85 071-site device: steps/s, split, kernel roofline, oracle superstep on the host cores, the run
+    under KMCParameters.log_revision() checked against the reference's CUDA log (`at_log_tolerance`), the C++ host cross-check;
+  * `scale_points`: tile:5; the reference's crossbar under log_revision() against ITS log (KMC time of the timed steps, per-phase split next to
+    the log's medians); a crossbar-SIZED stack (tile:20, 3.8e6 sites) with the current solve off, as every shipped crossbar runs.
 
-N > 1 (launched with torch.distributed.run; the reference has no multi-GPU path): STRONG scaling of ONE simulation of the ~1e6-site
-stack (tile:10): every rank advances the same simulation in lockstep, the tunnelling block of X -- > 95 % of a step -- is generated,
-stored and streamed in per-rank shares with one RCCL all-reduce of |S| doubles per CG iteration (csrc/xt.hip, csrc/comm.hip);
-`value` = steps/s of that simulation, "scaling": "strong".  A `replicas` block (independent replicas of the 85 k-site device,
-aggregate steps/s, weak scaling) rides along.  A watchdog ends the run with a non-zero exit code if a rank hangs.
+N > 1 (the reference has no multi-GPU path): STRONG scaling of ONE simulation of tile:10: every rank advances the same simulation in
+lockstep, the tunnelling block of X is generated, stored and streamed in per-rank shares (csrc/xt.hip, csrc/xtb.hip, csrc/comm.hip);
+`value` = steps/s of that simulation, "scaling": "strong".  A `replicas` block (independent replicas of the 85 k-site device, aggregate
+steps/s, weak scaling) rides along.  A watchdog ends the run with a non-zero exit code if a rank hangs.
 If the requested K steps of a seconds-per-step workload would not fit the time budget (--budget, default 420 s), fewer steps are
 timed and `steps` says how many (`steps_requested` keeps K).
 """
@@ -44,8 +51,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X fp64 vector peak (half the 157.3 TF f32 vector rate of MI355X_MICROARCH.md)
+FP64_MATRIX_PEAK_TFLOPS = 78.6  # fp64 matrix peak = the vector rate on MI355X; v_mfma_f64_4x4x4_4b_f64 measured at 68-69 TFLOP/s sustained (tools/bench_mfma_f64.hip)
 VD = 5.0
-X_BLOCK = 1                    # dkmc_set_x_block (set from --x-block)
+X_BLOCK = 16                   # dkmc_set_x_block (set from --x-block; 16 = the library default)
 
 
 def make_workload(name):
@@ -63,6 +71,11 @@ def make_workload(name):
         cell = structure.load_structure(os.path.join(g, "device_2.5nm.npz"))
         s = structure.tile_structure(cell, k, 25.575, 25.575, 1440)
         p = params.KMCParameters().for_tiling(k)
+    elif name == "crossbar_10nm_5pitch":
+        s = structure.load_structure(os.path.join(g, "crossbar_10nm_5pitch.npz"))
+        p = params.KMCParameters(rnd_seed=5, lattice=tuple(s.meta["lattice"]), num_atoms_first_layer=144, num_atoms_contact=11520)
+        p.solve_current = False
+        return s, p                          # (its parameters.txt: V = 1, heating off, current off)
     else:
         raise SystemExit("unknown workload " + name)
     p.solve_heating_global = True
@@ -72,12 +85,18 @@ def make_workload(name):
 class Sim:
     """One simulation resident on the GPU: the reference's host objects (Device / KMCProcess / GPUBuffers mirror) + one superstep."""
 
-    def __init__(self, name, devname, kmc_seed=None, x_format=1, warm_start=0, log_revision=False, cg_tol=None):
+    def __init__(self, name, devname, kmc_seed=None, x_format=1, warm_start=0, log_revision=False, cg_tol=None, x_block=None, Vd=None, solve_current=None):
         from devicekmc_amd import host, lib
         self.host, self.L = host, lib.load()
         self.name = name
         t0 = time.perf_counter()
         self.s, self.p = make_workload(name)
+        self.Vd = VD if Vd is None else Vd
+        if solve_current is not None:
+            self.p.solve_current = solve_current
+            if not solve_current:
+                self.p.solve_heating_global = False
+        self.x_block = X_BLOCK if x_block is None else x_block
         if log_revision:
             self.p = self.p.log_revision()           # cg_tol 1e-12 + CB edge on atoms: the settings that reproduce the reference's own log
         if cg_tol is not None:
@@ -89,10 +108,12 @@ class Sim:
         self.gb = self.dev.make_gpubuf(devname)
         self.L.dkmc_set_current_warm_start(warm_start)
         self.L.dkmc_set_x_format(x_format)
-        self.dev.setLaplacePotential(self.gb, self.p, VD)
+        self.L.dkmc_set_x_block(self.x_block)
+        self.dev.setLaplacePotential(self.gb, self.p, self.Vd)
         self.gb.sync_HostToGPU(self.dev)
         self.setup_s = time.perf_counter() - t0
         self.k = 0
+        self.cold = None            # (seconds, CG iterations on X) of the very first step, when run() makes it as a warm-up step
         self.reset_counters()
 
     def reset_counters(self):
@@ -111,14 +132,17 @@ class Sim:
         dev.updateCharge(gb)
         if timed: sync()
         t1 = time.perf_counter()
-        dev.updatePotential(gb, p, VD, self.k)
+        self.L.dkmc_set_x_block(self.x_block)
+        dev.updatePotential(gb, p, self.Vd, self.k)
         if timed: sync()
         t2 = time.perf_counter()
         _, dt = self.kmc.executeKMCStep(gb, dev)
         t3 = time.perf_counter()
-        dev.updatePower(gb, p, VD)
+        if p.solve_current:
+            dev.updatePower(gb, p, self.Vd)
         t4 = time.perf_counter()
-        dev.updateTemperature(gb, p, dt)
+        if p.solve_current:
+            dev.updateTemperature(gb, p, dt)
         sync()
         t5 = time.perf_counter()
         self.k += 1
@@ -144,8 +168,10 @@ class Sim:
         import torch
         agree = agree or (lambda v: v)
         tw = 0.0
-        for _ in range(warmup):
+        for w in range(warmup):
             tw = self.step(False)
+            if w == 0 and self.k == 1:
+                self.cold = (tw, int(self.host.get_stats()["cg_iters_X"]))
         tw = agree(tw)
         if budget_s is not None and warmup > 0 and tw * steps > budget_s:
             steps = max(1, int(budget_s / tw))
@@ -183,8 +209,20 @@ def rooflines(sim, local_share=1.0):
         avg_ms = pr["long_ms"] / pr["long_n"]
         nnz_all = st["spmv_long_nnz"] + st["spmv_short_nnz"]
         rows_all = st["spmv_long_rows"] + st["spmv_short_rows"]
-        if st["xt_subblocks"] > 0:
-            # tiled X (default): k_xt_apply -- one wave per run of tiles of the tunnelling block (8 KiB per stored 32 x 32 sub-block,
+        flops_per_launch = None
+        if st["xt_subblocks"] > 0 and st["xb_width"] > 1 and not st["xb_fallback"]:
+            # tiled X, block-CG (default): k_xtb_apply -- 8 KiB per stored 32 x 32 sub-block, read ONCE for both triangles and all `so` vectors
+            # (so = the block width rounded up to the matrix instruction's four); per tile a 16 B descriptor, its 32 panel rows read
+            # (32 x so x 8 B) and its 32 x so row sums written; per workgroup (four runs of one strip) the strip's 256 panel rows read and one
+            # record of 256 x so column sums written.  Flops: 32 x 32 entries x 2 products (row and column sums) x 2 x so.
+            so = 4 * ((int(st["xb_width"]) + 3) // 4)
+            kname = "k_xtb_apply"
+            nrec = st["xt_records"] or max(st["xt_items"] // 4, 1)
+            bytes_per_launch = (8192.0 * st["xt_local_subblocks"] + (16.0 + 2 * 32.0 * so * 8.0) * st["spmv_tiles"] * local_share
+                                + 32.0 * st["xt_items"] + (256.0 * 16 * 8.0 + 256.0 * so * 8.0) * nrec)
+            flops_per_launch = 4096.0 * so * st["xt_local_subblocks"]
+        elif st["xt_subblocks"] > 0:
+            # tiled X, single-vector loop: k_xt_apply -- one wave per run of tiles of the tunnelling block (8 KiB per stored 32 x 32 sub-block,
             # read once for both triangles; 16 B descriptor and 32 row sums written per tile; 32 B descriptor and 256 column sums
             # per run) plus, in the same launch, the neighbour part Xs in CSR form (12 B per non-zero; per row 8 B row pointer,
             # 8 B result, 8 B scale, 4 B class).  In a sharded solve these are THIS rank's tiles.
@@ -211,6 +249,14 @@ def rooflines(sim, local_share=1.0):
             "tiles": int(st["spmv_tiles"]), "tile_entries": int(st["spmv_tile_entries"]), "subblocks": int(st["xt_subblocks"]),
             "local_subblocks": int(st["xt_local_subblocks"]), "tile_runs": int(st["xt_items"]),
             "row_kernel_us": round(pr["short_ms"] / max(pr["short_n"], 1) * 1e3, 2)}
+        if flops_per_launch is not None:
+            tf = flops_per_launch / (avg_ms * 1e-3) / 1e12
+            out["roofline"]["block_width"] = int(st["xb_width"])
+            out["roofline"]["mfma_f64"] = {"instruction": "v_mfma_f64_4x4x4_4b_f64", "flops_per_launch": flops_per_launch, "achieved": round(tf, 2), "peak": FP64_MATRIX_PEAK_TFLOPS,
+                                           "unit": "TFLOP/s", "frac": round(tf / FP64_MATRIX_PEAK_TFLOPS, 4),
+                                           "measured_instruction_rate_TFLOPs": 68.5,
+                                           "note": "flops = 4096 x so per stored sub-block (so = block width rounded up to 4); the instruction's issue rate alone (tools/bench_mfma_f64.hip, "
+                                                   "profiles/r04_mfma_f64_rates.txt) is 68-69 TFLOP/s sustained: at width 16 the kernel is bound by the matrix pipe, at width <= 8 by HBM"}
         if bytes_per_launch >= 256.0 * 2 ** 20:
             out["roofline"]["note"] = ("frac is against the 8 TB/s spec peak (the contract's ceiling); MI355X_MICROARCH.md measures 6.3 TB/s for a float4 copy and "
                                        "6.5-6.8 TB/s for a non-temporal read stream: against 6.8 TB/s this launch is at %.2f" % (achieved / 6800.0))
@@ -223,6 +269,8 @@ def rooflines(sim, local_share=1.0):
         # (warm-started K solves of 1-4 iterations are a host poll, not a kernel measurement: no entry below 32 iterations per solve)
         # one Jacobi-CG iteration on K (SpMV + update + direction): 12 nnz + 4 (m + 1) + 96 m bytes
         m, nnz = sim.s.N - 2 * sim.p.num_atoms_first_layer, int(sim.gb.c.Device_nnz)
+        if sim.p.cb_edge_domain == "atoms":
+            pass        # (the potential system is over every site in both domains; only the CB-edge solve changes)
         # bytes the three kernels move: 4 B per stored entry (column | class bit, no value array) + row pointers + 15 vector touches of 8 B
         b = 4.0 * nnz + 4.0 * (m + 1) + 120.0 * m
         b_csr = 12.0 * nnz + 4.0 * (m + 1) + 96.0 * m
@@ -310,7 +358,7 @@ def strong_scaling_model(sim, ms_per_step, reps=10):
             "not_in_the_cg_iterations_ms": round(ms_per_step - iters * t1 * 1e-3, 1), "by_n_gpus": rows}
 
 
-def cpu_cg_baseline(sim, ncores):
+def cpu_cg_baseline(sim, ncores, iters=None, iters_source=None):
     """CPU leg of a scale point: the oracle's CG iteration (okmc_cg_iter_bench: the loop body of okmc_cg_jacobi, OpenMP) timed on a
     CSR of X's shape at this size, x the GPU run's iteration count.  Everything else of a CPU step (assembly, K solve, events) is
     left out, so the CPU time is a lower bound."""
@@ -319,14 +367,16 @@ def cpu_cg_baseline(sim, ncores):
     st = sim.host.get_stats()
     m = int(st["N_atom"]) + 1
     t_it = oc.cg_iter_bench(m, int(st["xt_ns"]), 2 * int(st["spmv_tile_entries"]), int(st["xt_sparse_nnz"]), 3)
-    iters = sim.cnt["cg_iters_X"] / max(sim.cnt["steps"], 1)
+    if iters is None:
+        iters, iters_source = sim.cnt["cg_iters_X"] / max(sim.cnt["steps"], 1), "the GPU run's iteration count"
     if t_it <= 0:
         return None
     sec = t_it * iters
     return {"value": round(1.0 / sec, 6), "unit": "KMC steps/s", "cores": ncores, "kind": "port",
             "sample": "oracle CG iteration (loop body of okmc_cg_jacobi: CSR SpMV + 3 dots + 3 vector updates, OpenMP; oracle/kmc_oracle.c "
-                      "okmc_cg_iter_bench) timed over 3 iterations on a CSR of X's row and non-zero counts at this size, x the GPU run's %.0f "
-                      "CG iterations per step; assembly, K solve, pair sum and events of a CPU step are NOT included (lower bound on the CPU time)" % iters,
+                      "okmc_cg_iter_bench) timed over 3 iterations on a CSR of X's row and non-zero counts at this size, x %.0f CG iterations per step "
+                      "(%s: the CPU port runs the reference's single-vector CG); assembly, K solve, pair sum and events of a CPU step are NOT "
+                      "included (lower bound on the CPU time)" % (iters, iters_source),
             "s_per_cg_iteration": round(t_it, 4), "ms_per_step": round(sec * 1e3, 1)}
 
 
@@ -374,7 +424,7 @@ def cpp_host_crosscheck(sim, steps, warmup):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def pmc_traffic(workload, kernel_prefix, x_format, cg_tol=None):
+def pmc_traffic(workload, kernel_prefix, x_format, cg_tol=None, x_block=None):
     """HBM bytes per launch of the dominant kernel from the PMC counters, measured in this run: two rocprofv3 child runs of this
     script on the same workload (one step), `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in separate passes with the kernel trace only
     (MI355X_MICROARCH.md, HBM / rocprofv3 sections); median over the kernel's working launches (the no-op launches behind the
@@ -394,7 +444,8 @@ def pmc_traffic(workload, kernel_prefix, x_format, cg_tol=None):
         d = tempfile.mkdtemp(prefix="dkmc_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
                sys.executable, os.path.abspath(__file__), "--workload", workload, "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
-               "--scale-points", "none", "--no-alt", "--no-pmc", "--no-cpp-host", "--no-log-tolerance", "--x-format", str(x_format), "--x-block", str(X_BLOCK)]
+               "--scale-points", "none", "--no-alt", "--no-pmc", "--no-cpp-host", "--no-log-tolerance", "--no-device", "--no-reference-order",
+               "--x-format", str(x_format), "--x-block", str(x_block if x_block is not None else X_BLOCK)]
         if cg_tol is not None:      # bytes per launch do not depend on how many iterations the solve takes: a loose tolerance shortens the (serialised) counter run
             cmd += ["--cg-tol", repr(cg_tol)]
         try:
@@ -451,6 +502,40 @@ def log_tolerance_block(devname, x_format, steps, warmup):
     return blk
 
 
+def crossbar_block(devname):
+    """The crossbar the reference timed (structures/crossbars/timing_10nm_5pitch/output_initial.txt: 110 813 sites, V = 1, solve_current = 0,
+    13 supersteps, 2.04 s median per superstep on its unnamed GPU) under KMCParameters.log_revision(): the KMC time of every timed step is
+    checked against that log (fixture tests/golden/reference_logs.json; no oracle involved).  With the current solve off, a step is the charge
+    update, the potential (K-CG + pair sum) and the event loop."""
+    sim = Sim("crossbar_10nm_5pitch", devname, log_revision=True, Vd=1.0)
+    nsteps, warm = 12, 1
+    elapsed, n = sim.run(nsteps, warm)
+    res = summary(sim, elapsed, n)
+    blk = {"workload": "crossbar_10nm_5pitch", "sites": res["sites"], "Vd": 1.0, "solve_current": False, "cg_tol": sim.p.cg_tol, "cb_edge_domain": sim.p.cb_edge_domain,
+           "steps": n, "warmup": warm, "value": round(n / elapsed, 4), "unit": "KMC steps/s", "ms_per_step": res["ms_per_step"], "split_ms": res["split_ms"],
+           "cold_step_ms": round(sim.cold[0] * 1e3, 1) if sim.cold else None,
+           "per_step": {k: res["per_step"][k] for k in ("events", "cg_iters_K", "n_charged", "K_rows", "K_nnz")},
+           "us_per_executed_event": round(res["split_ms"]["rates"] * 1e3 / max(res["per_step"]["events"], 1), 1),
+           "reference_cuda_log": {"s_per_superstep_median": 2.04, "rates_s_median": 1.97, "potential_boundaries_s_median": 0.012,
+                                  "source": "structures/crossbars/timing_10nm_5pitch/output_initial.txt:11-14 (BASELINE.md; unnamed GPU)"}}
+    blk["speedup_over_reference_log"] = round(2.04 / (elapsed / n), 1)
+    blk.update(rooflines(sim))
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "reference_logs.json")) as f:
+            gold = json.load(f)["crossbars/timing_10nm_5pitch/output_initial.txt"]["steps"]
+        # sim.trace holds the timed steps = logged steps warm .. warm + n - 1; the KMC time is cumulative from the log's value before them
+        t, worst, k = (gold[warm - 1]["KMC time"] if warm > 0 else 0.0), 0.0, 0
+        for (dt, _, _), g in zip(sim.trace, gold[warm:]):
+            t += dt; k += 1
+            worst = max(worst, abs(t / g["KMC time"] - 1))
+        blk["vs_reference_log"] = {"steps_compared": k, "max_rel_kmc_time_diff": worst, "agrees_to_printed_digits": bool(worst < 1e-5),
+                                   "log": "structures/crossbars/timing_10nm_5pitch/output_initial.txt (6 printed digits)"}
+    except Exception as exc:
+        blk["vs_reference_log"] = {"error": repr(exc)[:200]}
+    sim.close()
+    return blk
+
+
 def arm_watchdog(seconds, rank, what):
     """A rank stuck in a collective cannot be unwound: report and leave with a non-zero exit code."""
     def fire():
@@ -468,20 +553,22 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=None, help="default: 7.5nm at N = 1, tile:10 at N > 1")
+    ap.add_argument("--workload", default=None, help="default: tile:10 (configs[2])")
+    ap.add_argument("--no-device", action="store_true", help="N = 1: skip the block on the reference's own 85 071-site device")
+    ap.add_argument("--no-reference-order", action="store_true", help="N = 1: skip the runs with dkmc_set_x_block(1), the reference's single-vector CG")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--warm-start", type=int, default=0, help="dkmc_set_current_warm_start mode (0 = reference)")
     ap.add_argument("--x-format", type=int, default=1, help="1: tiled X (default); 0: CSR X as the reference stores it")
     ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded",
                     help="N > 1: ONE simulation, X sharded over the ranks (strong scaling, default) or independent replicas (weak scaling)")
-    ap.add_argument("--scale-points", default=None, help="N = 1: comma list of extra workloads measured in the same run (default tile:5,tile:10; 'none')")
+    ap.add_argument("--scale-points", default=None, help="N = 1: comma list of extra workloads measured in the same run (default tile:5,crossbar_10nm_5pitch,tile:20:nocurrent; 'none')")
     ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the replicas block")
     ap.add_argument("--no-single-ref", action="store_true", help="N > 1: skip the single-GPU run of the same simulation (reference point of the speed-up)")
     ap.add_argument("--no-alt", action="store_true", help="skip the alt_warm_start block")
     ap.add_argument("--no-cpp-host", action="store_true", help="N = 1: skip the cross-check line through the C++ host driver")
     ap.add_argument("--no-pmc", action="store_true", help="N = 1: do not measure roofline.traffic (two rocprofv3 --pmc child runs)")
     ap.add_argument("--no-log-tolerance", action="store_true", help="N = 1: skip the at_log_tolerance block")
-    ap.add_argument("--x-block", type=int, default=1, help="dkmc_set_x_block: 1 = the reference's single-vector CG on X, 2..16 = block-CG width")
+    ap.add_argument("--x-block", type=int, default=16, help="dkmc_set_x_block: 16 = library default (block-CG), 1 = the reference's single-vector CG on X")
     ap.add_argument("--cg-tol", type=float, default=None, help="override the CG tolerance (default: the reference's 1e-6)")
     ap.add_argument("--budget", type=float, default=420.0, help="time budget [s] for the timed steps of seconds-per-step workloads")
     ap.add_argument("--timeout", type=float, default=570.0, help="watchdog [s]: exit 3 if the run has not finished (a rank stuck in a collective cannot be unwound)")
@@ -519,87 +606,147 @@ def main():
     out = None
 
     if world == 1:
-        name = args.workload or "7.5nm"
+        name = args.workload or "tile:10"
+        big = name.startswith("tile:") and int(name.split(":")[1]) >= 8
+        ncpu = ncores
+        # ================= the headline: steady-state steps of the default workload at the library's defaults =================
         sim = Sim(name, devname, x_format=args.x_format, warm_start=args.warm_start, cg_tol=args.cg_tol)
         elapsed, n = sim.run(args.steps, args.warmup, budget_s=args.budget if sim.s.N > 150000 else None)
         res = summary(sim, elapsed, n)
         roofs = rooflines(sim)
-        # ---- same workload with the optional unscaled warm start of the current solve (never `value`) ----
-        alt = None
-        if args.warm_start == 0 and not args.no_alt and sim.s.N <= 150000:
-            sim.L.dkmc_set_current_warm_start(1)
-            for _ in range(2):
-                sim.step(False)
-            t0 = time.perf_counter(); it0 = 0; na = min(n, 5)
-            for _ in range(na):
-                sim.step(False); it0 += sim.host.get_stats()["cg_iters_X"]
-            ta = time.perf_counter() - t0
-            alt = {"current_warm_start": 1, "value": round(na / ta, 4), "ms_per_step": round(ta / na * 1e3, 3), "cg_iters_X": it0 / na}
-            sim.L.dkmc_set_current_warm_start(0)
-        cpp = None
-        if not args.no_cpp_host and sim.s.N <= 150000:
-            cpp = cpp_host_crosscheck(sim, min(n, 10), 2)
-        cpu = None
-        if not args.no_cpu_baseline:
-            cpu = cpu_superstep_baseline(sim.s, sim.p, ncores) if sim.s.N <= 150000 else cpu_cg_baseline(sim, ncores)
         out = {
-            "metric": "KMC steps/sec", "value": round(n / elapsed, 4), "unit": "KMC steps/s", "n_gpus": 1, "steps": n, "warmup": args.warmup,
-            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": name, "sites": res["sites"], "nn": res["nn"], "atoms": res["atoms"], "Vd": VD,
+            "metric": "KMC steps/sec", "value": round(n / elapsed, 5), "unit": "KMC steps/s", "n_gpus": 1, "steps": n, "warmup": args.warmup,
+            "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "none", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": name, "sites": res["sites"], "nn": res["nn"], "atoms": res["atoms"], "Vd": sim.Vd,
                        "phases": "charge+potential+rates+current+heat", "parallelism": "single GPU", "x_format": "tiled" if args.x_format else "csr",
-                       "current_warm_start": args.warm_start, "cg_tol": sim.p.cg_tol, "x_block": args.x_block},
-            "split_ms": res["split_ms"], "per_step": res["per_step"], "cpu_baseline": cpu, "alt_warm_start": alt, "cpp_host_crosscheck": cpp,
+                       "current_warm_start": args.warm_start, "cg_tol": sim.p.cg_tol, "x_block": sim.x_block,
+                       "cg_on_X": ("block-CG of width %d, tile x panel product on the matrix cores (csrc/xtb.hip)" % sim.x_block) if sim.x_block > 1
+                                  else "single-vector CG in the reference's iterate order (csrc/xt.hip)"},
+            "split_ms": res["split_ms"], "per_step": res["per_step"],
+            "steady": {"steps": n, "ms_each": [round(t * 1e3, 1) for t, _ in sim.step_log], "cg_sweeps_X_each": [i for _, i in sim.step_log]},
+            "cold_step": ({"ms": round(sim.cold[0] * 1e3, 1), "cg_sweeps_X": sim.cold[1],
+                           "note": "first step of a fresh simulation (in the warm-up): fills the tunnelling-coefficient cache, sizes every buffer, zero start vector"}
+                          if sim.cold else None),
+            "cpu_baseline": None,
         }
         if n != args.steps:
             out["steps_requested"] = args.steps
         out.update(roofs)
+        # ---- same simulation, optional unscaled warm start of the current solve (never `value`) ----
+        if args.warm_start == 0 and not args.no_alt:
+            sim.L.dkmc_set_current_warm_start(1)
+            sim.step(False)                                  # this step stores the private copy the next ones start from
+            t0 = time.perf_counter(); it0 = 0; na = 2 if big else min(n, 5)
+            for _ in range(na):
+                sim.step(False); it0 += sim.host.get_stats()["cg_iters_X"]
+            ta = time.perf_counter() - t0
+            out["alt_warm_start"] = {"current_warm_start": 1, "steps": na, "value": round(na / ta, 5), "ms_per_step": round(ta / na * 1e3, 3), "cg_sweeps_X": it0 / na,
+                                     "note": "warm start from an unscaled private copy of the previous solution instead of the reference's G0-scaled buffer"}
+            sim.L.dkmc_set_current_warm_start(0)
+        sites_main = sim.s.N
         sim.close()
-        # ---- roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC counters, measured now ----
+        # ---- roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC counters, measured now (the counter runs stop their
+        # solves early on seconds-per-step workloads: the bytes one launch moves do not depend on the iteration count) ----
         if not args.no_pmc and "roofline" in out:
-            tb, detail = pmc_traffic(name, out["roofline"]["kernel"], args.x_format)
+            tb, detail = pmc_traffic(name, out["roofline"]["kernel"], args.x_format, cg_tol=1e-3 if sites_main > 150000 else None, x_block=X_BLOCK)
             out["roofline"]["traffic"] = tb
             out["roofline"]["traffic_detail"] = detail
             if tb:
                 out["roofline"]["traffic_over_algorithmic"] = round(tb / out["roofline"]["algorithmic_bytes_per_launch"], 3)
-        # ---- scale points: the larger stacks of BASELINE.json's configs, measured in the same run ----
-        # ---- the same workload under the settings that reproduce the reference's own log (parity-verified configuration) ----
-        if name == "7.5nm" and not args.no_log_tolerance and args.cg_tol is None:
-            out["at_log_tolerance"] = log_tolerance_block(devname, args.x_format, min(n, 10), 2)
-        sp_names = (args.scale_points if args.scale_points is not None else ("tile:5,tile:10" if args.workload is None else "none"))
+        # ================= the same workload in the reference's iterate order (single-vector CG) =================
+        ref_iters = None
+        if not args.no_reference_order and X_BLOCK > 1 and args.x_format:
+            try:
+                sr = Sim(name, devname, x_format=args.x_format, x_block=1)
+                elr, nr_ = sr.run(1 if big else min(n, 5), 1, budget_s=60.0)
+                rr = summary(sr, elr, nr_)
+                ref_iters = rr["per_step"]["cg_iters_X"]
+                blk = {"x_block": 1, "what": "dkmc_set_x_block(1): solve_sparse_CG_Jacobi's iterate sequence and start vector (iterative_solvers_gpu.cu:309-480)",
+                       "steps": nr_, "warmup": 1, "value": round(nr_ / elr, 5), "ms_per_step": rr["ms_per_step"], "split_ms": rr["split_ms"],
+                       "cg_sweeps_X": ref_iters, "cold_step": {"ms": round(sr.cold[0] * 1e3, 1), "cg_sweeps_X": sr.cold[1]} if sr.cold else None}
+                blk.update({k: v for k, v in rooflines(sr).items() if k == "roofline"})
+                if big:
+                    blk["strong_scaling_model"] = strong_scaling_model(sr, rr["ms_per_step"])
+                out["reference_order_cg"] = blk
+                out["block_cg_gain"] = {"sweeps": round(ref_iters / max(res["per_step"]["cg_iters_X"], 1), 2),
+                                        "steps_per_s": round(out["value"] / blk["value"], 2)}
+                sr.close()
+            except Exception as exc:
+                out["reference_order_cg"] = {"error": repr(exc)[:300]}
+        # ---- CPU leg: the oracle's CG iteration at this size x the reference algorithm's iteration count ----
+        if not args.no_cpu_baseline:
+            if sites_main > 150000:
+                # (needs the shape of X: a short-lived simulation, one step at a loose tolerance)
+                sc_ = Sim(name, devname, x_format=args.x_format, cg_tol=1e-2)
+                sc_.run(1, 0)
+                out["cpu_baseline"] = cpu_cg_baseline(sc_, ncpu, iters=ref_iters if ref_iters else res["per_step"]["cg_iters_X"],
+                                                      iters_source=("the sweeps of the single-vector CG on the GPU (reference_order_cg)" if ref_iters
+                                                                    else "the block-CG's sweep count (the single-vector count was not measured: an underestimate)"))
+                sc_.close()
+            else:
+                s_, p_ = make_workload(name)
+                out["cpu_baseline"] = cpu_superstep_baseline(s_, p_, ncpu)
+            if out["cpu_baseline"]:
+                out["gpu_over_cpu"] = round(out["value"] / out["cpu_baseline"]["value"], 1)
+        # ================= the reference's own 85 071-site device =================
+        if not args.no_device and name != "7.5nm":
+            try:
+                d = Sim("7.5nm", devname, x_format=args.x_format)
+                eld, nd = d.run(20, 3)
+                rd = summary(d, eld, nd)
+                blk = {"workload": "7.5nm", "sites": rd["sites"], "steps": nd, "warmup": 3, "value": round(nd / eld, 4), "unit": "KMC steps/s", "ms_per_step": rd["ms_per_step"],
+                       "split_ms": rd["split_ms"], "per_step": rd["per_step"], "x_block": d.x_block,
+                       "reference_cuda_log": {"s_per_superstep_median": 4.78, "source": "structures/single_devices/timing_7.5nm/output_noguess.txt (BASELINE.md; unnamed GPU)"}}
+                blk.update(rooflines(d))
+                if not args.no_alt:
+                    d.L.dkmc_set_current_warm_start(1)
+                    d.step(False)
+                    t0 = time.perf_counter(); it0 = 0
+                    for _ in range(5):
+                        d.step(False); it0 += d.host.get_stats()["cg_iters_X"]
+                    ta = time.perf_counter() - t0
+                    blk["alt_warm_start"] = {"current_warm_start": 1, "value": round(5 / ta, 4), "ms_per_step": round(ta / 5 * 1e3, 3), "cg_sweeps_X": it0 / 5}
+                    d.L.dkmc_set_current_warm_start(0)
+                if not args.no_cpp_host:
+                    blk["cpp_host_crosscheck"] = cpp_host_crosscheck(d, 10, 2)
+                if not args.no_cpu_baseline:
+                    blk["cpu_baseline"] = cpu_superstep_baseline(d.s, d.p, ncpu)
+                d.close()
+                if not args.no_reference_order:
+                    d1 = Sim("7.5nm", devname, x_format=args.x_format, x_block=1)
+                    el1, n1 = d1.run(10, 2)
+                    r1 = summary(d1, el1, n1)
+                    blk["reference_order_cg"] = {"x_block": 1, "value": round(n1 / el1, 4), "ms_per_step": r1["ms_per_step"], "cg_sweeps_X": r1["per_step"]["cg_iters_X"]}
+                    blk["reference_order_cg"].update({k: v for k, v in rooflines(d1).items() if k == "roofline"})
+                    d1.close()
+                if not args.no_log_tolerance and args.cg_tol is None:
+                    blk["at_log_tolerance"] = log_tolerance_block(devname, args.x_format, 10, 2)
+                out["device_7p5nm"] = blk
+            except Exception as exc:
+                out["device_7p5nm"] = {"error": repr(exc)[:300]}
+        # ================= scale points =================
+        sp_names = (args.scale_points if args.scale_points is not None else ("tile:5,crossbar_10nm_5pitch,tile:20:nocurrent" if args.workload is None else "none"))
         points = {}
         for spn in [x for x in sp_names.split(",") if x and x != "none"]:
             try:
-                big = spn.startswith("tile:") and int(spn.split(":")[1]) >= 8
-                sp = Sim(spn, devname, x_format=args.x_format)
-                # tile:10 (the ~1e6 stack): the cold step (fills the coefficient cache, sizes every buffer, zero start vector) + 3 steady ones,
-                # reported separately; tile:5: 3 steps after one
-                el, ns_ = sp.run(4 if big else 3, 0 if big else 1, budget_s=150.0)
+                if spn == "crossbar_10nm_5pitch":
+                    points[spn] = crossbar_block(devname)
+                    continue
+                nocur = spn.endswith(":nocurrent")
+                wname = spn[:-len(":nocurrent")] if nocur else spn
+                sp = Sim(wname, devname, x_format=args.x_format, solve_current=False if nocur else None)
+                el, ns_ = sp.run(3, 1, budget_s=60.0)
                 r = summary(sp, el, ns_)
-                r["steps"] = ns_; r["warmup"] = 0 if big else 1
-                if big and ns_ >= 2:
-                    cold, steady = sp.step_log[0], sp.step_log[1:]
-                    ts = sum(t for t, _ in steady) / len(steady)
-                    r["cold_step"] = {"ms": round(cold[0] * 1e3, 1), "cg_iters_X": cold[1]}
-                    r["steady"] = {"steps": len(steady), "ms_per_step": round(ts * 1e3, 1), "steps_per_s": round(1.0 / ts, 5),
-                                   "cg_iters_X": sum(i for _, i in steady) / len(steady), "ms_each": [round(t * 1e3, 1) for t, _ in steady]}
-                    r["note"] = "ms_per_step / steps_per_s average ALL timed steps (cold one included); `steady` = the steps after it"
+                r["steps"] = ns_; r["warmup"] = 1
+                if sp.cold:
+                    r["cold_step"] = {"ms": round(sp.cold[0] * 1e3, 1), "cg_sweeps_X": sp.cold[1]}
+                if nocur:
+                    r["what"] = ("a crossbar-SIZED stack with the current solve off, as every shipped crossbar parameter set runs "
+                                 "(structures/crossbars/*/parameters.txt: solve_current = 0): charge + potential (K-CG + pair sum) + event loop")
+                    r["us_per_executed_event"] = round(r["split_ms"]["rates"] * 1e3 / max(r["per_step"]["events"], 1), 1)
                 r.update(rooflines(sp))
-                if big:
-                    r["strong_scaling_model"] = strong_scaling_model(sp, r["ms_per_step"])
-                if not args.no_cpu_baseline:
-                    r["cpu_baseline"] = cpu_cg_baseline(sp, ncores)
-                    if r["cpu_baseline"]:
-                        r["gpu_over_cpu_lower_bound"] = round(r["steps_per_s"] / r["cpu_baseline"]["value"], 1)
                 points[spn] = r
                 sp.close()
-                if not args.no_pmc and "roofline" in r:
-                    # traffic per launch of the dominant kernel at this size; the counter run stops its solves early (cg_tol 1e-3):
-                    # the bytes one launch moves do not depend on the iteration count
-                    tb, detail = pmc_traffic(spn, r["roofline"]["kernel"], args.x_format, cg_tol=1e-3)
-                    r["roofline"]["traffic"] = tb
-                    r["roofline"]["traffic_detail"] = detail
-                    if tb:
-                        r["roofline"]["traffic_over_algorithmic"] = round(tb / r["roofline"]["algorithmic_bytes_per_launch"], 3)
             except Exception as exc:                 # a failed scale point must not void the main measurement
                 points[spn] = {"error": repr(exc)[:300]}
         if points:

@@ -106,7 +106,7 @@ struct Engine {
     int cb_edge_domain = 0;        // 0: CB-edge system over every site (snapshot source); 1: over atoms only (dkmc_set_cb_edge_domain)
     long long tcache_budget = -1;  // bytes the tunnelling-coefficient cache may take; -1 = a third of the free device memory, 8-128 GiB (dkmc_set_tcache_budget)
     double pair_cut = 6.5;         // screening cut-off of the pair sum in units of sigma sqrt 2 (dkmc_set_pair_cutoff; 0 = all pairs like the reference)
-    int x_block = 1;               // block-CG width of the current solve on the tiled X (dkmc_set_x_block): 1 = the reference's single-vector loop, 2 ... 16 = block-CG (xtb.hip)
+    int x_block = 16;              // block-CG width of the current solve on the tiled X (dkmc_set_x_block; xtb.hip): 16 by default, 1 = the reference's single-vector loop (its iterate sequence)
     int x_format = 1;              // 1: tiled X (xt.hip, default); 0: CSR X as the reference stores it (current.hip + cg.hip)
     int x_iter_hint = 0;           // iteration count of the previous CG solve of X (sizes the first launch batch)
     dkmc_stats stats{};

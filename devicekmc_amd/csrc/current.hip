@@ -106,8 +106,10 @@ void tcache_invalidate(const void *key) { if (XBufState *st = xstate_find(key)) 
 
 static void tc_release();
 // new structure behind the same buffer (initialize_sparsity) or buffer freed: drop everything kept for it
+void pairsum_invalidate();      // potential.hip: the cached site grouping of the pair sum is keyed on the same arrays
 void xstate_reset(const void *key)
 {
+    pairsum_invalidate();
     XBufState *st = xstate_find(key);
     if (!st) return;
     XBufState *save = g_cur; g_cur = st;

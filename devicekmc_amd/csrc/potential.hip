@@ -500,6 +500,11 @@ __global__ __launch_bounds__(PW_NT) void k_pairwise_cells(int N, const double *_
     if (w == 0 && i >= 0) out[i] = (partial[0][lane] + partial[1][lane]) + (partial[2][lane] + partial[3][lane]);
 }
 
+// what the host knows of the cached grouping of the sites by column (see dkmc_poisson_gridless_gpu)
+static struct PwKey { const void *x, *y, *z, *lattice, *perm, *cells; int N, pbc; double cut; int possible, ncell; } g_pw_key = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, -1.0, 0, 0};
+void pairsum_invalidate() { g_pw_key.x = nullptr; g_pw_key.N = 0; }
+extern "C" void dkmc_reset_pair_sum_cache(void) { pairsum_invalidate(); }
+
 extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, const double *lattice, const double *sigma,
                                          const double *k, const double *x, const double *y, const double *z,
                                          const int *charge, double *out)
@@ -534,9 +539,12 @@ extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, 
     // the grouping of the sites by column is kept between calls (positions, box and cut-off do not change); what the host can see of its key:
     // `possible`: the box has >= 3 columns along y or z, read back ONCE per key (one 64-byte copy); a box without (85 k sites: 2 x 2) skips
     // every launch of the cell path from then on
-    static struct { const void *x, *y, *z, *perm, *cells; int N, pbc; double cut; int possible, ncell; } key = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, -1.0, 0, 0};
-    const int host_rebuild = key.x != x || key.y != y || key.z != z || key.perm != pperm || key.cells != cells || key.N != N || key.pbc != pbc || key.cut != e.pair_cut;
-    if (host_rebuild) { HIPCHK(hipMemsetAsync(grid, 0, sizeof(PwGrid), st)); key = {x, y, z, pperm, cells, N, pbc, e.pair_cut, 1, PW_MAXCELL}; }
+    // The key is dropped whenever a GPUBuffers is freed or (re-)initialised (pairsum_invalidate, called from xstate_reset): hipMalloc hands a
+    // new structure of the same size the old addresses.  Positions rewritten IN PLACE behind the same pointers (only possible through this
+    // raw-pointer entry; the reference never moves a site) need dkmc_reset_pair_sum_cache().
+    auto &key = g_pw_key;
+    const int host_rebuild = key.x != x || key.y != y || key.z != z || key.lattice != lattice || key.perm != pperm || key.cells != cells || key.N != N || key.pbc != pbc || key.cut != e.pair_cut;
+    if (host_rebuild) { HIPCHK(hipMemsetAsync(grid, 0, sizeof(PwGrid), st)); key = {x, y, z, lattice, pperm, cells, N, pbc, e.pair_cut, 1, PW_MAXCELL}; }
     if (key.possible) hipLaunchKernelGGL(k_pw_grid, dim3(1), dim3(256), 0, st, lattice, sigma, e.pair_cut, pbc, (const int *)cnt, grid, tcount, ccount, cursor, host_rebuild);
     if (host_rebuild) {
         PwGrid hg{};
@@ -545,12 +553,14 @@ extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, 
         key.possible = e.pair_cut > 0.0 && (hg.ny >= 3 || hg.nz >= 3); key.ncell = std::max(1, hg.ny * hg.nz);
         if (!key.possible) HIPCHK(hipMemsetAsync(grid, 0, sizeof(PwGrid), st));          // use = 0 for good: k_pairwise does every call
     }
-    const int cell_blocks = (N + PW_SITES - 1) / PW_SITES + key.ncell;        // upper bound of the chunks of 64 sites of one column
+    // launch sizes do not rely on the host's copy of the column count (the device rebuilds its grid when the box changes): the kernels stop
+    // at the device's own counts
+    const int cell_blocks = (N + PW_SITES - 1) / PW_SITES + PW_MAXCELL;      // upper bound of the chunks of 64 sites of one column
     if (key.possible) {
         hipLaunchKernelGGL(k_pw_bin, dim3(blocks), dim3(256), 0, st, N, y, z, (const PwGrid *)grid, (const ChargedSite *)list, (const int *)cnt, site_cell, ccell, tcount, ccount);
         hipLaunchKernelGGL(k_pw_offsets, dim3(1), dim3(PW_MAXCELL), 0, st, grid, (const int *)tcount, (const int *)ccount, tstart, cstart, chunk0);
         hipLaunchKernelGGL(k_pw_perm, dim3(blocks), dim3(256), 0, st, N, (const PwGrid *)grid, (const int *)site_cell, (const int *)tstart, cursor, pperm);
-        hipLaunchKernelGGL(k_pw_partition, dim3(key.ncell), dim3(256), 0, st, (const PwGrid *)grid, (const ChargedSite *)list, (const int *)cnt, (const int *)ccell,
+        hipLaunchKernelGGL(k_pw_partition, dim3(PW_MAXCELL), dim3(256), 0, st, (const PwGrid *)grid, (const ChargedSite *)list, (const int *)cnt, (const int *)ccell,
                            (const int *)cstart, clist2);
     }
     const int *cells_in_use = &grid->use;

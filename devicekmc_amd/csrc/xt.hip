@@ -1044,7 +1044,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         e.stats.comm_local_segments = X.item_n;
 
         // ---- storage + fill ----
-        tval = (double *)scratch(S_XT_TVAL, (size_t)(X.sub_n + 1) * XT_SUB * 8);
+        tval = (double *)scratch(S_XT_TVAL, (size_t)(X.sub_n + 4) * XT_SUB * 8);       // (slack: the block-CG product requests two sub-blocks beyond a full tile)
         rowpart = (double *)scratch(S_XT_ROWPART, (size_t)(ncell + 1) * XT_R * 8);
         colpart = (double *)scratch(S_XT_COLPART, (size_t)(X.nitems + 1) * XT_C * 8);       // one 256-entry record per run (32 MB at 9.4e5 sites; [run position][S rank] took 1.8 GB)
         d_cnt = (unsigned long long *)scratch(S_XT_CNT, 16);

@@ -27,14 +27,15 @@
 // Column 0 carries the reference's right-hand side and start vector; the result is its solution, to the same stop test.  The iterate
 // sequence is NOT the reference's (s = 1 keeps that: xt.hip).
 //
-// Tile x panel product (k_xtb_apply), per 32 x 32 sub-block, v_mfma_f64_16x16x4_f64 (A[i][k]: lane = i + 16 k; B[k][j]: lane = j + 16 k;
-// D[i][j]: lane = j + 16 (i % 4), register i / 4):
+// Tile x panel product (k_xtb_apply), per 32 x 32 sub-block (instruction and lane maps: see the kernel):
 //   column sums  Yc[col][v] += sum_row T[row][col] Qr[row][v]:  the 8 wave loads of the stream (lane (cc, rr) holds rows 4 j + rr, columns
-//                2 cc, 2 cc + 1) ARE the A operands (i = cc, k = rr): no data movement; 16 MFMAs.
+//                2 cc, 2 cc + 1) ARE the A operands (tile row on the k index): no data movement.
 //   row sums     Yr[row][v] += sum_col T[row][col] Qc[col][v]:  needs the sub-block with the COLUMN on the k index: one round trip through
-//                wave-private LDS (8 ds_write_b128 into an XOR-swizzled image, 8 ds_read_b128, both conflict-free); 16 MFMAs.
-// Column sums stay in 128 accumulator registers over the run of tiles (one 256-column strip), the four waves of a workgroup leave one
-// combined record; row sums (32 x 16) go to a grid-indexed array per tile.
+//                wave-private LDS (8 ds_write_b128 into an XOR-swizzled image, 8 ds_read_b128, both conflict-free).
+// Column sums stay in accumulator registers over the run of tiles (one 256-column strip), the four waves of a workgroup leave one
+// combined record; row sums (32 x s) go to a grid-indexed array per tile.
+// Only column 0 of Y is kept (a vector): the auxiliary solutions are never needed.  The neighbour part gathers P and the scaling, so no
+// scaled full-length copy of P exists; the compact scaled copy over S (QS) feeds the tiles.
 #include "xtiles.h"
 #include <hip/hip_ext.h>
 #include <algorithm>
@@ -45,6 +46,7 @@
 #define XB_NG 5                       // Gram matrices per pass: P'T, P'R, T'R, T'T, R'R
 typedef double dbl4 __attribute__((ext_vector_type(4)));
 #define XB_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
+#define XB_MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
 
 // auxiliary right-hand sides: a hash of (row, column) -> uniform in [-1, 1); the same on every rank and in tools/blockcg_proto.py
 __device__ __forceinline__ double xtb_aux(int row, int col)
@@ -59,82 +61,182 @@ __device__ __forceinline__ double xtb_rhs(const double *__restrict__ b, int row,
     return v == 0 ? b[row] : (v < s ? xtb_aux(row, v) : 0.0);
 }
 // position of (S rank r, vector v) in the compact panel QS: rows pairwise interleaved, [r / 2][v][r % 2] -- two consecutive rows of one
-// vector are one 16-byte LDS read (the two k-steps e' = 0, 1 of the row product)
+// vector are one 16-byte read (two k-steps of the row product).  (The LDS copy of a strip's window adds a swizzle: k_xtb_apply.)
 __device__ __forceinline__ size_t xtb_qs_pos(int r, int v) { return (size_t)(r >> 1) * 32 + 2 * v + (r & 1); }
 
 // ---- tiles x panel -----------------------------------------------------------------------------------------------------------------
 // One run of tiles per wave, the four runs of a workgroup in one strip (the run list is padded to groups of four per strip: xt.hip).
-template <int NTL>
+// v_mfma_f64_4x4x4_4b_f64 (four independent 4 x 4 x 4 products per instruction; lane maps probed on gfx950, tools/probe_mfma_f64_4x4x4.hip:
+// A[i][k] of block n: lane i + 4 n + 16 k; B[k][j]: lane j + 4 n + 16 k; D[i][j]: lane j + 4 n + 16 i) issues every 18 cycles -- 68 TFLOP/s
+// measured chip-wide, twice the 16x16x4 form (tools/bench_mfma_f64.hip: 140 cycles, 34 TFLOP/s).  The four blocks of an instruction are
+// four groups of tile rows (row sums) or columns (column sums) against the SAME four vectors, so the panel operand is replicated over the
+// blocks and the cost scales with NG = ceil(s / 4) vector groups: 32 NG instructions per 32 x 32 sub-block.
+template <int NTL, int NG, int variant = 0>
 __global__ __launch_bounds__(XT_NT) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__restrict__ tiles, int sub_base, const double *__restrict__ tval,
-                 const double *__restrict__ QS, int nW, double *__restrict__ rowpartB, double *__restrict__ colpartB, const XCtrl *ctrl, int so)
+                 const double *__restrict__ QS, int nW, double *__restrict__ rowpartB, double *__restrict__ colpartB, const XCtrl *ctrl)
 {
-    __shared__ __attribute__((aligned(16))) double qc[XT_C * XB_SP];          // the strip's 256 panel rows, pairwise interleaved (32 KiB)
+    // variant (measurement aid, dkmc_xtb_time_apply; 0 in every solve): 1 = no matrix instructions (stream + LDS traffic only), 2 = the
+    // tile stream is not re-read (matrix instructions + LDS traffic only); the results of 1 and 2 are meaningless
+    constexpr int so = 4 * NG;                                                 // vectors per row of the partial-sum arrays
+    __shared__ __attribute__((aligned(16))) double qc[XT_C * XB_SP];          // the strip's 256 panel rows in QS order (32 KiB)
     __shared__ __attribute__((aligned(16))) double ts[4 * 2 * XT_SUB];        // per wave: two sub-block images (2 x 8 KiB)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63, cc = lane & 15, rr = lane >> 4;         // also (a, b) / (jv, b) of the MFMA operand maps
+    const int lane = threadIdx.x & 63, cc = lane & 15, rr = lane >> 4, jv = lane & 3, blk = cc >> 2;
     const int item = (int)blockIdx.x * 4 + wv;
     const XItem it = items[min(item, nitems - 1)];
     if (ctrl->done) return;                                                    // uniform over the launch
-    {   // the window of the strip: a straight copy (QS is stored in the LDS image's order)
+    {   // the window of the strip, 16-byte chunks (vector v of a row pair) in QS order except for a swizzle of the vector index by
+        // 4 (row pair % 4): the four row pairs a wave reads at once then sit on different LDS banks
         const dbl2 *src = reinterpret_cast<const dbl2 *>(QS + (size_t)it.w * XT_C * XB_SP);
         dbl2 *dst = reinterpret_cast<dbl2 *>(qc);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) dst[threadIdx.x + 256 * u] = src[threadIdx.x + 256 * u];
+        for (int u = 0; u < 8; ++u) { const int ch = threadIdx.x + 256 * u; dst[ch ^ (((ch >> 4) & 3) << 2)] = src[ch]; }
     }
     __syncthreads();
     double *tsw = ts + (size_t)wv * 2 * XT_SUB;
-    dbl4 Yc[8][2];
+    double Yc[8][2][NG];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { Yc[q][0] = (dbl4)(0.0); Yc[q][1] = (dbl4)(0.0); }
-    // LDS offsets (doubles) of this lane: image g(r, c) = 32 r + (c ^ ((r & 15) << 1))
-    int woff[8], roff[2];
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) Yc[q][e][g] = 0.0;
+    // LDS offsets (doubles) of this lane.  Sub-block image: g(r, c) = 32 r + (c ^ ((r & 15) << 1)), written as the loads arrive (lane
+    // (cc, rr) holds rows 4 j + rr, columns 2 cc, 2 cc + 1), read with the row on the lane (row 16 mb + cc, columns 8 kk + 2 rr, + 1)
+    int woff[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { const int r = 4 * j + rr; woff[j] = 32 * r + ((2 * cc) ^ ((r & 15) << 1)); }
+    const int roff = 32 * cc;                                                  // + 512 mb + ((8 kk + 2 rr) ^ (cc << 1))
+    // panel operands: vector 4 g + jv of panel row rho sits at xtb_qs_pos(rho, 4 g + jv); for rho = 32 q + 8 kk + 2 rr (+ 1): one 16-byte read
+    int qoff[NG];
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) roff[mb] = 32 * (16 * mb + cc);            // + ((8 kk + 2 rr) ^ (cc << 1)) per k-pair
-    const int qoff = rr * 32 + 2 * cc;                                         // + (16 q + 4 kk) * 32: B operands of the row product
-#define XB_LD(dst, slot) _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) dst[j_] = NTL ? __builtin_nontemporal_load(base + (size_t)(8 * (slot) + j_) * 64) : base[(size_t)(8 * (slot) + j_) * 64];
-    // one sub-block: column sums straight from the loaded registers, row sums after the LDS round trip
-#define XB_SUBBLOCK(vv, q, bufi)                                                                                               \
+    for (int g = 0; g < NG; ++g) qoff[g] = rr * 32 + ((2 * (4 * g + jv)) ^ (rr << 3));      // + (16 q + 4 kk) * 32
+#define XB_LD(dst, slot) if (variant != 2 || (slot) < 2) { _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) dst[j_] = NTL ? __builtin_nontemporal_load(base + (size_t)(8 * (slot) + j_) * 64) : base[(size_t)(8 * (slot) + j_) * 64]; }
+    // panel operands of the column sums: rows 4 j + rr of a tile's 32 panel rows, vectors 4 g + jv (the same in all four blocks)
+#define XB_LDBR(k_)                                                                                                            \
+    {                                                                                                                           \
+        const double *qr_ = QS + (size_t)(k_) * XT_R * XB_SP;                                                                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                                                      \
+            const int rho_ = 4 * j_ + rr, r32_ = rho_ >> 1;                                                                     \
+            _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_) br[j_][g_] = qr_[r32_ * 32 + 2 * (4 * g_ + jv) + (rho_ & 1)];      \
+        }                                                                                                                       \
+    }
+    // One sub-block = four stages of 8 NG matrix instructions each, software-pipelined by hand: hipcc issues an LDS read right in front of
+    // the instructions that use it (measured: one exposed LDS latency per 4 matrix instructions, 3.5 ms per sweep at 9.4e5 sites where the
+    // instructions alone take 1.9), so the operands of the row sums are requested one stage ahead and sched_barriers keep the order:
+    //   image -> LDS | read operands of k-pairs 0, 1 | COLUMN sums, loads 0-3 | read operands of k-pairs 2, 3 | ROW sums, k-pairs 0, 1 |
+    //   COLUMN sums, loads 4-7 | ROW sums, k-pairs 2, 3
+    // Column sums come straight from the loaded registers (they are the A operands with the tile ROW on the k index); row sums from the
+    // image read back with the tile COLUMN on the k index.
+    struct RowOps { dbl2 a0[2], a1[2], bc[2][NG]; };
+#define XB_RDROW(R, q, bufi, kk0)                                                                                              \
+    {                                                                                                                           \
+        const double *img_ = tsw + (bufi) * XT_SUB;                                                                             \
+        _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_) {                                                                      \
+            const int sw_ = (8 * ((kk0) + h_) + 2 * rr) ^ (cc << 1);                                                            \
+            R.a0[h_] = *reinterpret_cast<const dbl2 *>(img_ + roff + sw_);                                                      \
+            R.a1[h_] = *reinterpret_cast<const dbl2 *>(img_ + roff + 512 + sw_);                                                \
+            _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_)                                                                   \
+                R.bc[h_][g_] = *reinterpret_cast<const dbl2 *>(qc + qoff[g_] + (16 * (q) + 4 * ((kk0) + h_)) * 32);             \
+        }                                                                                                                       \
+    }
+#define XB_COLH(vv, q, j0)                                                                                                     \
+    if (variant != 1) {                                                                                                         \
+        _Pragma("unroll") for (int j_ = (j0); j_ < (j0) + 4; ++j_)                                                              \
+            _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_) {                                                                 \
+                Yc[q][0][g_] = XB_MFMA4(vv[j_].x, br[j_][g_], Yc[q][0][g_]);                                                    \
+                Yc[q][1][g_] = XB_MFMA4(vv[j_].y, br[j_][g_], Yc[q][1][g_]);                                                    \
+            }                                                                                                                   \
+    }
+#define XB_ROWH(R)                                                                                                             \
+    _Pragma("unroll") for (int h_ = 0; h_ < 2; ++h_)                                                                            \
+        _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_) {                                                                     \
+            if (variant != 1) {                                                                                                 \
+                Yr[0][g_] = XB_MFMA4(R.a0[h_].x, R.bc[h_][g_].x, Yr[0][g_]); Yr[1][g_] = XB_MFMA4(R.a1[h_].x, R.bc[h_][g_].x, Yr[1][g_]); \
+                Yr[0][g_] = XB_MFMA4(R.a0[h_].y, R.bc[h_][g_].y, Yr[0][g_]); Yr[1][g_] = XB_MFMA4(R.a1[h_].y, R.bc[h_][g_].y, Yr[1][g_]); \
+            } else { Yr[0][g_] += R.a0[h_].x + R.bc[h_][g_].x; Yr[1][g_] += R.a1[h_].y + R.bc[h_][g_].y; }                       \
+        }
+#define XB_COL(vv, q, bufi)                                                                                                    \
     {                                                                                                                           \
         double *img_ = tsw + (bufi) * XT_SUB;                                                                                   \
         _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) *reinterpret_cast<dbl2 *>(img_ + woff[j_]) = vv[j_];                   \
-        _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) {                                                                      \
-            Yc[q][0] = XB_MFMA(vv[j_].x, br[j_], Yc[q][0]);                                                                     \
-            Yc[q][1] = XB_MFMA(vv[j_].y, br[j_], Yc[q][1]);                                                                     \
-        }                                                                                                                       \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                                  \
         __builtin_amdgcn_wave_barrier();                                                                                        \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                                  \
-        _Pragma("unroll") for (int kk_ = 0; kk_ < 4; ++kk_) {                                                                   \
-            const dbl2 bc_ = *reinterpret_cast<const dbl2 *>(qc + qoff + (16 * (q) + 4 * kk_) * 32);                            \
-            const int sw_ = (8 * kk_ + 2 * rr) ^ (cc << 1);                                                                     \
-            const dbl2 a0_ = *reinterpret_cast<const dbl2 *>(img_ + roff[0] + sw_);                                             \
-            const dbl2 a1_ = *reinterpret_cast<const dbl2 *>(img_ + roff[1] + sw_);                                             \
-            Yr0 = XB_MFMA(a0_.x, bc_.x, Yr0); Yr1 = XB_MFMA(a1_.x, bc_.x, Yr1);                                                 \
-            Yr0 = XB_MFMA(a0_.y, bc_.y, Yr0); Yr1 = XB_MFMA(a1_.y, bc_.y, Yr1);                                                 \
-        }                                                                                                                       \
+        XB_RDROW(R0, q, bufi, 0)                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        XB_COLH(vv, q, 0)                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        XB_RDROW(R1, q, bufi, 2)                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        XB_ROWH(R0)                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        XB_COLH(vv, q, 4)                                                                                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                                      \
     }
+#define XB_ROW(q, bufi)                                                                                                        \
+    {                                                                                                                           \
+        XB_ROWH(R1)                                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    }
+#define XB_SUBBLOCK(vv, q, bufi) XB_COL(vv, q, bufi) XB_ROW(q, bufi)
+    // The stream is pipelined ACROSS tiles: the first two sub-blocks of the next tile of the run (contiguous in the store) and its panel
+    // rows are requested inside the last sub-block of this one -- one wave per SIMD holds two sub-blocks in flight, and a tile that
+    // starts with a cold load exposes a full HBM latency per 8 phases of ~1.2 us (measured: 3.6 against 2.9 ms per sweep at 9.4e5 sites).
     XTile td; td.k = it.k0; td.w = it.w; td.mask = it.mask0; td.soff = it.soff0;
+    double br[8][NG];
+    RowOps R0, R1;
+    if (it.t0 < it.t1) XB_LDBR(td.k)
+    // row sums of a tile: D[i][j] of block n of Yr[mb][g]: row 16 mb + 4 n + i (i = rr, n = blk), vector 4 g + jv
+#define XB_ROWSUMS()                                                                                                           \
+    {                                                                                                                           \
+        double *rp_ = rowpartB + (((size_t)td.k * nW + td.w) * XT_R + 4 * blk + rr) * so + jv;                                  \
+        _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_) { rp_[4 * g_] = Yr[0][g_]; rp_[(size_t)16 * so + 4 * g_] = Yr[1][g_]; } \
+    }
+    int t = it.t0;
 #pragma unroll 1
-    for (int t = it.t0; t < it.t1; ++t) {
-        XTile nxt = td;
-        if (t + 1 < it.t1) nxt = tiles[t + 1];
-        // B operands of the column sums: the tile's 32 panel rows, row 4 j + rr of vector cc
-        double br[8];
-        {
-            const double *qr = QS + (size_t)td.k * XT_R * XB_SP + (rr >> 1) * 32 + 2 * cc + (rr & 1);
+    while (t < it.t1) {
+        if (td.mask != 0xffu) {
+            // partial tile (a few per cent of the storage): one sub-block at a time
+            double Yr[2][NG];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) br[j] = qr[64 * j];
+            for (int g = 0; g < NG; ++g) { Yr[0][g] = 0.0; Yr[1][g] = 0.0; }
+            const dbl2 *base = reinterpret_cast<const dbl2 *>(tval + (size_t)(td.soff - sub_base) * XT_SUB) + lane;
+            int sl = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if ((td.mask >> q) & 1u) {
+                    dbl2 vp[8];
+                    XB_LD(vp, sl)
+                    XB_SUBBLOCK(vp, q, q & 1)
+                    ++sl;
+                }
+            }
+            XB_ROWSUMS()
+            ++t;
+            if (t < it.t1) { td = tiles[t]; XB_LDBR(td.k) }
+            continue;
         }
-        dbl4 Yr0 = (dbl4)(0.0), Yr1 = (dbl4)(0.0);
-        const dbl2 *base = reinterpret_cast<const dbl2 *>(tval + (size_t)(td.soff - sub_base) * XT_SUB) + lane;
-        if (td.mask == 0xffu) {
-            // full tile: 64 KiB contiguous, two sub-blocks in flight
-            dbl2 va[8], vb[8];
+        // a chain of full tiles (64 KiB each, contiguous in the store): two sub-blocks in flight, primed once per chain and carried across
+        // its tiles (a ring of four was measured: no faster, the registers are better spent on the operand pipeline above)
+        dbl2 va[8], vb[8];
+        {
+            const dbl2 *base = reinterpret_cast<const dbl2 *>(tval + (size_t)(td.soff - sub_base) * XT_SUB) + lane;
             XB_LD(va, 0)
             XB_LD(vb, 1)
+        }
+        bool chain;
+#pragma unroll 1
+        do {
+            XTile nxt = td;
+            const bool more = t + 1 < it.t1;
+            if (more) nxt = tiles[t + 1];
+            chain = more && nxt.mask == 0xffu;
+            double Yr[2][NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) { Yr[0][g] = 0.0; Yr[1][g] = 0.0; }
+            const dbl2 *base = reinterpret_cast<const dbl2 *>(tval + (size_t)(td.soff - sub_base) * XT_SUB) + lane;
             XB_SUBBLOCK(va, 0, 0)
             XB_LD(va, 2)
             XB_SUBBLOCK(vb, 1, 1)
@@ -148,31 +250,27 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
             XB_SUBBLOCK(vb, 5, 1)
             XB_LD(vb, 7)
             XB_SUBBLOCK(va, 6, 0)
-            XB_SUBBLOCK(vb, 7, 1)
-        } else {
-            int sl = 0;                                                     // partial tile (a few per cent of the storage): one sub-block at a time
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                if ((td.mask >> q) & 1u) {
-                    dbl2 va[8];
-                    XB_LD(va, sl)
-                    XB_SUBBLOCK(va, q, q & 1)
-                    ++sl;
-                }
-            }
-        }
-        // row sums of the tile: D[i][jv] of Yr{0,1}: row 16 mb + rr + 4 v, vector cc
-        if (cc < so) {
-            double *rp_ = rowpartB + (((size_t)td.k * nW + td.w) * XT_R + rr) * so + cc;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) { rp_[(size_t)(4 * v) * so] = Yr0[v]; rp_[(size_t)(16 + 4 * v) * so] = Yr1[v]; }
-        }
-        td = nxt;
+            if (chain) { XB_LD(va, 8) }                                     // the next tile's first sub-block
+            XB_COL(vb, 7, 1)
+            if (more) XB_LDBR(nxt.k)                                        // this tile's column sums are issued: the panel registers are free
+            XB_ROW(7, 1)
+            if (chain) { XB_LD(vb, 9) }
+            XB_ROWSUMS()
+            td = nxt;
+            ++t;
+        } while (chain);
     }
+#undef XB_ROWSUMS
 #undef XB_LD
+#undef XB_LDBR
+#undef XB_COL
+#undef XB_ROW
+#undef XB_RDROW
+#undef XB_COLH
+#undef XB_ROWH
 #undef XB_SUBBLOCK
     // one record of column sums per workgroup: the four waves' accumulators are added in a fixed order through LDS, four sub-block
-    // positions per round.  Yc[q][e] register v of lane (cc, rr) is column 32 q + 2 (rr + 4 v) + e, vector cc.
+    // positions per round.  Yc[q][e][g] of lane (block n = blk, i = rr, j = jv) is column 32 q + 8 n + 2 i + e, vector 4 g + jv.
     double *rec = colpartB + (size_t)it.pad * XT_C * so;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -182,18 +280,16 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
 #pragma unroll
             for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) tsw[(q4 * 8 + e * 4 + v) * 64 + lane] = Yc[4 * h + q4][e][v];
+                for (int g = 0; g < NG; ++g) tsw[((q4 * 2 + e) * NG + g) * 64 + lane] = Yc[4 * h + q4][e][g];
         __syncthreads();
-        if (cc < so) {
 #pragma unroll
-            for (int e = 0; e < 2; ++e)
+        for (int e = 0; e < 2; ++e)
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int idx = (wv * 8 + e * 4 + v) * 64 + lane;
-                    const double sum = (ts[idx] + ts[2 * XT_SUB + idx]) + (ts[4 * XT_SUB + idx] + ts[6 * XT_SUB + idx]);
-                    rec[(size_t)(32 * (4 * h + wv) + 2 * (rr + 4 * v) + e) * so + cc] = sum;
-                }
-        }
+            for (int g = 0; g < NG; ++g) {
+                const int idx = ((wv * 2 + e) * NG + g) * 64 + lane;
+                const double sum = (ts[idx] + ts[2 * XT_SUB + idx]) + (ts[4 * XT_SUB + idx] + ts[6 * XT_SUB + idx]);
+                rec[(size_t)(32 * (4 * h + wv) + 8 * blk + 2 * rr + e) * so + 4 * g + jv] = sum;
+            }
     }
 }
 
@@ -202,7 +298,7 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
 // by k_xtb_rows).  The rest: 16 atom rows per workgroup, 16 lanes per row (one per vector).  Non-S rows are finished (scaled) here; S rows
 // leave their sparse sum in T for k_xtb_rows.
 __global__ __launch_bounds__(XT_NT) void k_xtb_neigh(int m, const xrp_t *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ val,
-                                                     const double *__restrict__ Q, const double *__restrict__ sc, const int *__restrict__ nsrank,
+                                                     const double *__restrict__ P, const double *__restrict__ sc, const int *__restrict__ nsrank,
                                                      const XCtrl *ctrl, double *__restrict__ T, double *__restrict__ drvpart)
 {
     __shared__ double red[16][16];
@@ -217,9 +313,10 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_neigh(int m, const xrp_t *__restr
         for (; p + 48 < b; p += 64) {
             const int c0 = ci[p], c1 = ci[p + 16], c2 = ci[p + 32], c3 = ci[p + 48];
             const double a0 = val[p], a1 = val[p + 16], a2 = val[p + 32], a3 = val[p + 48];
-            s0 += a0 * Q[(size_t)c0 * XB_SP + v]; s1 += a1 * Q[(size_t)c1 * XB_SP + v]; s2 += a2 * Q[(size_t)c2 * XB_SP + v]; s3 += a3 * Q[(size_t)c3 * XB_SP + v];
+            s0 += a0 * (sc[c0] * P[(size_t)c0 * XB_SP + v]); s1 += a1 * (sc[c1] * P[(size_t)c1 * XB_SP + v]);
+            s2 += a2 * (sc[c2] * P[(size_t)c2 * XB_SP + v]); s3 += a3 * (sc[c3] * P[(size_t)c3 * XB_SP + v]);
         }
-        for (; p < b; p += 16) s0 += val[p] * Q[(size_t)ci[p] * XB_SP + v];
+        for (; p < b; p += 16) { const int c0 = ci[p]; s0 += val[p] * (sc[c0] * P[(size_t)c0 * XB_SP + v]); }
         red[g][v] = (s0 + s1) + (s2 + s3);
         __syncthreads();
         if (g == 0) {
@@ -238,9 +335,10 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_neigh(int m, const xrp_t *__restr
     for (; p + 3 < p1; p += 4) {
         const int c0 = ci[p], c1 = ci[p + 1], c2 = ci[p + 2], c3 = ci[p + 3];
         const double a0 = val[p], a1 = val[p + 1], a2 = val[p + 2], a3 = val[p + 3];
-        s0 += a0 * Q[(size_t)c0 * XB_SP + v]; s1 += a1 * Q[(size_t)c1 * XB_SP + v]; s2 += a2 * Q[(size_t)c2 * XB_SP + v]; s3 += a3 * Q[(size_t)c3 * XB_SP + v];
+        s0 += a0 * (sc[c0] * P[(size_t)c0 * XB_SP + v]); s1 += a1 * (sc[c1] * P[(size_t)c1 * XB_SP + v]);
+        s2 += a2 * (sc[c2] * P[(size_t)c2 * XB_SP + v]); s3 += a3 * (sc[c3] * P[(size_t)c3 * XB_SP + v]);
     }
-    for (; p < p1; ++p) s0 += val[p] * Q[(size_t)ci[p] * XB_SP + v];
+    for (; p < p1; ++p) { const int c0 = ci[p]; s0 += val[p] * (sc[c0] * P[(size_t)c0 * XB_SP + v]); }
     const double s = (s0 + s1) + (s2 + s3);
     T[(size_t)row * XB_SP + v] = nsrank[row] < 0 ? sc[row] * s : s;
 }
@@ -251,17 +349,16 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_neigh(int m, const xrp_t *__restr
 // INIT: T = A Y0 has just been formed; R = T - B is stored and only R'R is accumulated.
 __device__ __forceinline__ double xtb_list_sum(const double *__restrict__ p, size_t stride, int first, int n, int step)
 {
-    // terms first, first + step, ... < n of a strided list; term j goes to accumulator j % 4 whatever the unrolling
+    // terms first, first + step, ... < n of a strided list; 16 loads in flight (the tail predicated, not looped); term j goes to
+    // accumulator j % 4 whatever the batching
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    int c = first;
-    for (; c + 7 * step < n; c += 8 * step) {
-        double x[8];
+    for (int c = first; c < n; c += 16 * step) {
+        double x[16];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = p[(size_t)(c + u * step) * stride];
-        a0 += x[0]; a1 += x[1]; a2 += x[2]; a3 += x[3]; a0 += x[4]; a1 += x[5]; a2 += x[6]; a3 += x[7];
+        for (int u = 0; u < 16; ++u) { const int cu = c + u * step; x[u] = cu < n ? p[(size_t)cu * stride] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) { a0 += x[u]; a1 += x[u + 1]; a2 += x[u + 2]; a3 += x[u + 3]; }
     }
-    for (; c + 3 * step < n; c += 4 * step) { a0 += p[(size_t)c * stride]; a1 += p[(size_t)(c + step) * stride]; a2 += p[(size_t)(c + 2 * step) * stride]; a3 += p[(size_t)(c + 3 * step) * stride]; }
-    for (; c < n; c += step) a0 += p[(size_t)c * stride];
     return (a0 + a1) + (a2 + a3);
 }
 template <int INIT>
@@ -562,9 +659,9 @@ __global__ __launch_bounds__(64) void k_xtb_small(int it, int s, const double *_
 // ---- panel updates: Y += P c ; R += T c ; P = R M1 + T M3 + P M2 ; Q = S P -------------------------------------------------------------
 // 16 rows per wave and step: the three panels as A operands (row on i, vector on k), the 16 x 16 matrices as B operands, Y and R as
 // accumulator input.  P is formed from the ORIGINAL R, T, P (M3 = c M1), so no result has to change its register map.
-__global__ __launch_bounds__(XT_NT) void k_xtb_step(int m, int it, const double *__restrict__ mats, double *__restrict__ Y, double *__restrict__ R,
+__global__ __launch_bounds__(XT_NT) void k_xtb_step(int m, int it, const double *__restrict__ mats, double *__restrict__ y0, double *__restrict__ R,
                                                     double *__restrict__ P, const double *__restrict__ T, const double *__restrict__ sc,
-                                                    const int *__restrict__ nsrank, double *__restrict__ Q, double *__restrict__ QS, const XCtrl *ctrl)
+                                                    const int *__restrict__ nsrank, double *__restrict__ QS, const XCtrl *ctrl)
 {
     __shared__ int sdone;
     if (threadIdx.x == 0) { const int d = ctrl->done; sdone = d != 0 && it + 1 >= d; }
@@ -572,11 +669,12 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_step(int m, int it, const double 
     if (sdone) return;
     const int lane = threadIdx.x & 63, a = lane & 15, b = lane >> 4;
     const int wv = threadIdx.x >> 6;
-    double cB[4], m1B[4], m2B[4], m3B[4];
+    double cB[4], m1B[4], m2B[4], m3B[4], c0[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         const int o = (4 * kk + b) * 16 + a;
         cB[kk] = mats[o]; m1B[kk] = mats[256 + o]; m2B[kk] = mats[512 + o]; m3B[kk] = mats[768 + o];
+        c0[kk] = mats[(4 * kk + b) * 16];                                     // column 0 of c: the physical column of Y += P c
     }
     const int ngroups = (m + 15) / 16;
     for (int g = (int)blockIdx.x * 4 + wv; g < ngroups; g += (int)gridDim.x * 4) {
@@ -586,16 +684,19 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_step(int m, int it, const double 
         const size_t oa = (size_t)(row0 + a) * XB_SP + b;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { pa[kk] = oka ? P[oa + 4 * kk] : 0.0; ta[kk] = oka ? T[oa + 4 * kk] : 0.0; ra[kk] = oka ? R[oa + 4 * kk] : 0.0; }
-        dbl4 yN, rN, pN = (dbl4)(0.0);
+        dbl4 rN, pN = (dbl4)(0.0);
+        const double yold = (b == 0 && oka) ? y0[row0 + a] : 0.0;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int row = row0 + b + 4 * u;
-            const bool ok = row < m;
-            yN[u] = ok ? Y[(size_t)row * XB_SP + a] : 0.0; rN[u] = ok ? R[(size_t)row * XB_SP + a] : 0.0;
+            rN[u] = row < m ? R[(size_t)row * XB_SP + a] : 0.0;
         }
+        // y0[row0 + a] += sum_i P[row0 + a][i] c[i][0]: lane (a, b) holds i = 4 kk + b; the four b-groups are added in a fixed order
+        double yacc = (pa[0] * c0[0] + pa[1] * c0[1]) + (pa[2] * c0[2] + pa[3] * c0[3]);
+        yacc += __shfl_xor(yacc, 16, WAVE); yacc += __shfl_xor(yacc, 32, WAVE);
+        if (b == 0 && oka) y0[row0 + a] = yold + yacc;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            yN = XB_MFMA(pa[kk], cB[kk], yN);
             rN = XB_MFMA(ta[kk], cB[kk], rN);
             pN = XB_MFMA(ra[kk], m1B[kk], pN); pN = XB_MFMA(ta[kk], m3B[kk], pN); pN = XB_MFMA(pa[kk], m2B[kk], pN);
         }
@@ -604,33 +705,30 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_step(int m, int it, const double 
             const int row = row0 + b + 4 * u;
             if (row < m) {
                 const size_t o = (size_t)row * XB_SP + a;
-                Y[o] = yN[u]; R[o] = rN[u]; P[o] = pN[u];
-                const double qv = sc[row] * pN[u];
-                Q[o] = qv;
+                R[o] = rN[u]; P[o] = pN[u];
                 const int sr = nsrank[row];
-                if (sr >= 0) QS[xtb_qs_pos(sr, a)] = qv;
+                if (sr >= 0) QS[xtb_qs_pos(sr, a)] = sc[row] * pN[u];
             }
         }
     }
 }
-// panels before the first product: Y = [y, 0, ...], Q = S Y, P = 0
+// before the first product: P = [y, 0, ...] stands in for Y0 (the product below is A Y0), QS = S Y0 over S; y0 = y
 __global__ void k_xtb_init(int m, const double *__restrict__ y, const double *__restrict__ sc, const int *__restrict__ nsrank,
-                           double *__restrict__ Y, double *__restrict__ P, double *__restrict__ Q, double *__restrict__ QS)
+                           double *__restrict__ y0, double *__restrict__ P, double *__restrict__ QS)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m * XB_SP) return;
     const int row = i >> 4, v = i & 15;
     const double yv = v == 0 ? y[row] : 0.0;
-    Y[i] = yv; P[i] = 0.0;
-    const double qv = sc[row] * yv;
-    Q[i] = qv;
+    P[i] = yv;
+    if (v == 0) y0[row] = yv;
     const int sr = nsrank[row];
-    if (sr >= 0) QS[xtb_qs_pos(sr, v)] = qv;
+    if (sr >= 0) QS[xtb_qs_pos(sr, v)] = sc[row] * yv;
 }
-__global__ void k_xtb_extract(int m, const double *__restrict__ Y, double *__restrict__ y)
+__global__ void k_xtb_zero(long long n, double *__restrict__ p)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < m) y[i] = Y[(size_t)i * XB_SP];
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0;
 }
 
 // ---- host loop ------------------------------------------------------------------------------------------------------------------------
@@ -639,24 +737,24 @@ __global__ void k_xtb_extract(int m, const double *__restrict__ Y, double *__res
 int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
 {
     Engine &e = eng(); hipStream_t st = e.stream;
-    const int m = A.m, s = A.s, so = s <= 8 ? 8 : 16;
+    const int m = A.m, s = A.s, so = 4 * ((s + 3) / 4);                       // vector groups of four: the matrix instruction's width
     const size_t pan = (size_t)m * XB_SP;
     const long long ncell = (long long)A.nK * A.nW;
     const int ng = std::max(128, std::min(A.nK, 1024));                                     // row-kernel workgroups = partial Gram matrices
-    double *panels = (double *)scratch(S_XTB_PANELS, pan * 5 * 8);
+    double *panels = (double *)scratch(S_XTB_PANELS, (pan * 3 + m + 16) * 8);
     double *QS = (double *)scratch(S_XTB_QS, (size_t)A.ns_pad * XB_SP * 8);
     double *rowpartB = (double *)scratch(S_XTB_ROWPART, (size_t)(ncell + 1) * XT_R * so * 8);
     double *colpartB = (double *)scratch(S_XTB_COLPART, (size_t)(A.nrecords + 1) * XT_C * so * 8);
     double *gpart = (double *)scratch(S_XTB_GRAM, (size_t)ng * XB_NG * 256 * 8);
     double *small = (double *)scratch(S_XTB_SMALL, (size_t)(4 * 256 + 2 * XB_DSPLIT * XB_SP + XB_NG * 256) * 8);
     if (!panels || !QS || !rowpartB || !colpartB || !gpart || !small) return e.err_code;
-    double *Y = panels, *R = panels + pan, *P = panels + 2 * pan, *T = panels + 3 * pan, *Q = panels + 4 * pan;
+    double *R = panels, *P = panels + pan, *T = panels + 2 * pan, *y0 = panels + 3 * pan;
     double *mats = small, *drvpart = small + 4 * 256, *gfin = drvpart + 2 * XB_DSPLIT * XB_SP;
     HIPCHK(hipMemsetAsync(QS, 0, (size_t)A.ns_pad * XB_SP * 8, st));
     HIPCHK(hipMemsetAsync(rowpartB, 0, (size_t)(ncell + 1) * XT_R * so * 8, st));
     HIPCHK(hipMemsetAsync(colpartB, 0, (size_t)(A.nrecords + 1) * XT_C * so * 8, st));
     HIPCHK(hipMemsetAsync(A.ctrl, 0, sizeof(XCtrl), st));
-    hipLaunchKernelGGL(k_xtb_init, dim3((unsigned)((pan + 255) / 256)), dim3(256), 0, st, m, (const double *)A.y, A.sc, A.nsrank, Y, P, Q, QS);
+    hipLaunchKernelGGL(k_xtb_init, dim3((unsigned)((pan + 255) / 256)), dim3(256), 0, st, m, (const double *)A.y, A.sc, A.nsrank, y0, P, QS);
     const int ntb = (A.item_n + 3) / 4;
     const int nnb = 2 * XB_DSPLIT + (std::max(m - 2, 1) + 15) / 16;
     const int gs = xt_grid((m + 15) / 16, 4, 2048);
@@ -666,12 +764,13 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
     double prof_long_ms = 0.0, prof_short_ms = 0.0; int prof_long_n = 0, prof_short_n = 0;
     auto product = [&](hipEvent_t e0, hipEvent_t e1) {
         if (ntb > 0) {
-            if (A.nt_loads) hipExtLaunchKernelGGL((k_xtb_apply<1>), dim3(ntb), dim3(XT_NT), 0, st, e0, e1, 0, A.item_n, A.items, A.tiles, A.sub_base, A.tval,
-                                                  (const double *)QS, A.nW, rowpartB, colpartB, (const XCtrl *)A.ctrl, so);
-            else hipExtLaunchKernelGGL((k_xtb_apply<0>), dim3(ntb), dim3(XT_NT), 0, st, e0, e1, 0, A.item_n, A.items, A.tiles, A.sub_base, A.tval,
-                                       (const double *)QS, A.nW, rowpartB, colpartB, (const XCtrl *)A.ctrl, so);
+#define XB_APPLY(NTL_, NG_) hipExtLaunchKernelGGL((k_xtb_apply<NTL_, NG_>), dim3(ntb), dim3(XT_NT), 0, st, e0, e1, 0, A.item_n, A.items, A.tiles, A.sub_base, A.tval, \
+                                                  (const double *)QS, A.nW, rowpartB, colpartB, (const XCtrl *)A.ctrl)
+            if (A.nt_loads) { if (so == 4) XB_APPLY(1, 1); else if (so == 8) XB_APPLY(1, 2); else if (so == 12) XB_APPLY(1, 3); else XB_APPLY(1, 4); }
+            else { if (so == 4) XB_APPLY(0, 1); else if (so == 8) XB_APPLY(0, 2); else if (so == 12) XB_APPLY(0, 3); else XB_APPLY(0, 4); }
+#undef XB_APPLY
         }
-        hipLaunchKernelGGL(k_xtb_neigh, dim3(nnb), dim3(XT_NT), 0, st, m, A.rp, A.ci, A.val, (const double *)Q, A.sc, A.nsrank, (const XCtrl *)A.ctrl, T, drvpart);
+        hipLaunchKernelGGL(k_xtb_neigh, dim3(nnb), dim3(XT_NT), 0, st, m, A.rp, A.ci, A.val, (const double *)P, A.sc, A.nsrank, (const XCtrl *)A.ctrl, T, drvpart);
     };
 #define XB_ROWS_ARGS A.ns, A.nK, A.nW, m, s, so, A.wrange, A.nitem_w, (const double *)rowpartB, (const double *)colpartB, A.srow, A.sS, A.nsrank, A.sc, \
                      (const double *)drvpart, T, (const double *)P, R, A.b, gpart, (const XCtrl *)A.ctrl
@@ -680,7 +779,8 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
     hipLaunchKernelGGL((k_xtb_rows<1>), dim3(ng), dim3(XT_NT), 0, st, XB_ROWS_ARGS);
     hipLaunchKernelGGL(k_xtb_gred, dim3(XB_NG * 16), dim3(XT_NT), 0, st, ng, (const double *)gpart, gfin, (const XCtrl *)A.ctrl);
     hipLaunchKernelGGL(k_xtb_small, dim3(1), dim3(64), 0, st, -1, s, (const double *)gfin, mats, A.ctrl, A.tol2);
-    hipLaunchKernelGGL(k_xtb_step, dim3(gs), dim3(XT_NT), 0, st, m, -1, (const double *)mats, Y, R, P, (const double *)T, A.sc, A.nsrank, Q, QS, (const XCtrl *)A.ctrl);
+    hipLaunchKernelGGL(k_xtb_zero, dim3((unsigned)((pan + 255) / 256)), dim3(256), 0, st, (long long)pan, P);          // Y0 has served: P_{-1} = 0
+    hipLaunchKernelGGL(k_xtb_step, dim3(gs), dim3(XT_NT), 0, st, m, -1, (const double *)mats, y0, R, P, (const double *)T, A.sc, A.nsrank, QS, (const XCtrl *)A.ctrl);
     KCHK();
     int it = 0, launched = 0, batch = 4;
     if (e.x_iter_hint > 12) batch = e.x_iter_hint - 4;
@@ -705,7 +805,7 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
             hipExtLaunchKernelGGL((k_xtb_rows<0>), dim3(ng), dim3(XT_NT), 0, st, pb ? evs[4 * sl + 2] : nullptr, pb ? evs[4 * sl + 3] : nullptr, 0, XB_ROWS_ARGS);
             hipLaunchKernelGGL(k_xtb_gred, dim3(XB_NG * 16), dim3(XT_NT), 0, st, ng, (const double *)gpart, gfin, (const XCtrl *)A.ctrl);
             hipLaunchKernelGGL(k_xtb_small, dim3(1), dim3(64), 0, st, it, s, (const double *)gfin, mats, A.ctrl, A.tol2);
-            hipLaunchKernelGGL(k_xtb_step, dim3(gs), dim3(XT_NT), 0, st, m, it, (const double *)mats, Y, R, P, (const double *)T, A.sc, A.nsrank, Q, QS, (const XCtrl *)A.ctrl);
+            hipLaunchKernelGGL(k_xtb_step, dim3(gs), dim3(XT_NT), 0, st, m, it, (const double *)mats, y0, R, P, (const double *)T, A.sc, A.nsrank, QS, (const XCtrl *)A.ctrl);
         }
         launched = batch;
         KCHK();
@@ -713,8 +813,7 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
     }
 #undef XB_ROWS_ARGS
     if (e.err_code) return e.err_code;
-    hipLaunchKernelGGL(k_xtb_extract, dim3((m + 255) / 256), dim3(256), 0, st, m, (const double *)Y, A.y);
-    KCHK();
+    HIPCHK(hipMemcpyAsync(A.y, y0, (size_t)m * 8, hipMemcpyDeviceToDevice, st));
     e.x_iter_hint = h.iters;
     if (iters_out) *iters_out = h.iters;
     if (rr_out) *rr_out = h.rr[h.iters & 1];
@@ -754,11 +853,11 @@ extern "C" int dkmc_xtb_check_product(int width, double *max_abs_diff, double *m
 {
     Engine &e = eng(); hipStream_t st = e.stream; const XTState &X = g_xt;
     if (!X.valid || comm_attached() || X.tile_n != X.ntiles || X.ns <= 0) return dkmc_fail(13, "xtb_check_product: needs the X of a single-GPU solve", __FILE__, __LINE__);
-    const int m = X.Nsub, ns = X.ns, s = std::max(2, std::min(width, 16)), so = s <= 8 ? 8 : 16;
+    const int m = X.Nsub, ns = X.ns, s = std::max(2, std::min(width, 16)), so = 4 * ((s + 3) / 4);
     const size_t pan = (size_t)m * XB_SP;
     const long long ncell = (long long)X.nK * X.nW;
     const int nrec = X.nitems >> X.rec_shift, ng = 64;
-    double *panels = (double *)scratch(S_XTB_PANELS, pan * 5 * 8);
+    double *panels = (double *)scratch(S_XTB_PANELS, (pan * 3 + m + 16) * 8);
     double *QS = (double *)scratch(S_XTB_QS, (size_t)X.ns_pad * XB_SP * 8);
     double *rowpartB = (double *)scratch(S_XTB_ROWPART, (size_t)(ncell + 1) * XT_R * so * 8);
     double *colpartB = (double *)scratch(S_XTB_COLPART, (size_t)(nrec + 1) * XT_C * so * 8);
@@ -769,18 +868,20 @@ extern "C" int dkmc_xtb_check_product(int width, double *max_abs_diff, double *m
     double *sS = (double *)e.buf[S_CG_PS], *sc = (double *)e.buf[S_CG_S], *rhs = (double *)e.buf[S_X_RHS];
     if (!panels || !QS || !rowpartB || !colpartB || !gpart || !small || !tmp || !ctrl || !sS || !sc || !rhs) return e.err_code ? e.err_code : dkmc_fail(13, "xtb_check_product: no solver state", __FILE__, __LINE__);
     sS += X.ns_pad;
-    double *T = panels + 3 * pan, *R = panels + pan, *P = panels + 2 * pan, *drvpart = small + 4 * 256;
+    double *T = panels + 2 * pan, *R = panels, *P = panels + pan, *drvpart = small + 4 * 256;
     double *vS = tmp, *ref = tmp + X.ns_pad, *res = tmp + 2 * (size_t)X.ns_pad;
     HIPCHK(hipMemsetAsync(tmp, 0, (size_t)4 * X.ns_pad * 8, st));
     HIPCHK(hipMemsetAsync(QS, 0, (size_t)X.ns_pad * XB_SP * 8, st));
-    HIPCHK(hipMemsetAsync(panels, 0, pan * 5 * 8, st));
+    HIPCHK(hipMemsetAsync(panels, 0, (pan * 3 + m + 16) * 8, st));
     HIPCHK(hipMemsetAsync(small, 0, (size_t)(4 * 256 + 2 * XB_DSPLIT * XB_SP) * 8, st));
     HIPCHK(hipMemsetAsync(rowpartB, 0, (size_t)(ncell + 1) * XT_R * so * 8, st));
     HIPCHK(hipMemsetAsync(colpartB, 0, (size_t)(nrec + 1) * XT_C * so * 8, st));
     HIPCHK(hipMemsetAsync(ctrl, 0, sizeof(XCtrl), st));
     hipLaunchKernelGGL(k_xtb_test_panel, dim3((ns * XB_SP + 255) / 256), dim3(256), 0, st, ns, QS);
-    hipLaunchKernelGGL((k_xtb_apply<1>), dim3((X.item_n + 3) / 4), dim3(XT_NT), 0, st, X.item_n, (const XItem *)g_xb.items + X.item_lo, (const XTile *)g_xb.tiles, (int)X.sub_base,
-                       (const double *)g_xb.tval, (const double *)QS, X.nW, rowpartB, colpartB, (const XCtrl *)ctrl, so);
+#define XB_APPLY(NG_) hipLaunchKernelGGL((k_xtb_apply<1, NG_>), dim3((X.item_n + 3) / 4), dim3(XT_NT), 0, st, X.item_n, (const XItem *)g_xb.items + X.item_lo, (const XTile *)g_xb.tiles, \
+                       (int)X.sub_base, (const double *)g_xb.tval, (const double *)QS, X.nW, rowpartB, colpartB, (const XCtrl *)ctrl)
+    if (so == 4) XB_APPLY(1); else if (so == 8) XB_APPLY(2); else if (so == 12) XB_APPLY(3); else XB_APPLY(4);
+#undef XB_APPLY
     hipLaunchKernelGGL((k_xtb_rows<1>), dim3(ng), dim3(XT_NT), 0, st, ns, X.nK, X.nW, m, s, so, (const int2 *)g_xb.wrange, (const int *)g_xb.nitem_w, (const double *)rowpartB,
                        (const double *)colpartB, (const int *)g_xb.srow, (const double *)sS, (const int *)g_xb.nsrank, (const double *)sc, (const double *)drvpart, T,
                        (const double *)P, R, (const double *)rhs, gpart, (const XCtrl *)ctrl);
@@ -798,5 +899,42 @@ extern "C" int dkmc_xtb_check_product(int width, double *max_abs_diff, double *m
     HIPCHK(hipStreamSynchronize(st));
     if (max_abs_diff) *max_abs_diff = h[0];
     if (max_abs) *max_abs = h[1];
+    return e.err_code;
+}
+
+// ---- measurement aid (bench.py / tools; no counterpart in the reference) ------------------------------------------------------------------
+// Average duration of the tile x panel kernel over the X left resident by the last single-GPU solve, `reps` launches back to back.
+// variant 0: the kernel as a solve runs it; 1: without its matrix instructions; 2: without re-reading the tile stream (see k_xtb_apply).
+extern "C" int dkmc_xtb_time_apply(int width, int variant, int reps, double *us)
+{
+    Engine &e = eng(); hipStream_t st = e.stream; const XTState &X = g_xt;
+    if (!X.valid || comm_attached() || X.tile_n != X.ntiles || X.ns <= 0 || reps < 1) return dkmc_fail(13, "xtb_time_apply: needs the X of a single-GPU solve", __FILE__, __LINE__);
+    const int s = std::max(2, std::min(width, 16)), so = 4 * ((s + 3) / 4);
+    const long long ncell = (long long)X.nK * X.nW;
+    const int nrec = X.nitems >> X.rec_shift;
+    double *QS = (double *)scratch(S_XTB_QS, (size_t)X.ns_pad * XB_SP * 8);
+    double *rowpartB = (double *)scratch(S_XTB_ROWPART, (size_t)(ncell + 1) * XT_R * so * 8);
+    double *colpartB = (double *)scratch(S_XTB_COLPART, (size_t)(nrec + 1) * XT_C * so * 8);
+    XCtrl *ctrl = (XCtrl *)scratch(S_MISC2, 256);
+    if (!QS || !rowpartB || !colpartB || !ctrl) return e.err_code;
+    HIPCHK(hipMemsetAsync(ctrl, 0, sizeof(XCtrl), st));
+    hipLaunchKernelGGL(k_xtb_test_panel, dim3((X.ns * XB_SP + 255) / 256), dim3(256), 0, st, X.ns, QS);
+    hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    for (int r = -1; r < reps; ++r) {
+        if (r == 0) HIPCHK(hipEventRecord(e0, st));
+#define XB_APPLY(NG_, V_) hipLaunchKernelGGL((k_xtb_apply<1, NG_, V_>), dim3((X.item_n + 3) / 4), dim3(XT_NT), 0, st, X.item_n, (const XItem *)g_xb.items + X.item_lo, (const XTile *)g_xb.tiles, \
+                       (int)X.sub_base, (const double *)g_xb.tval, (const double *)QS, X.nW, rowpartB, colpartB, (const XCtrl *)ctrl)
+        if (so == 4) XB_APPLY(1, 0);
+        else if (so == 8) { if (variant == 1) XB_APPLY(2, 1); else if (variant == 2) XB_APPLY(2, 2); else XB_APPLY(2, 0); }
+        else if (so == 12) XB_APPLY(3, 0);
+        else { if (variant == 1) XB_APPLY(4, 1); else if (variant == 2) XB_APPLY(4, 2); else XB_APPLY(4, 0); }
+#undef XB_APPLY
+    }
+    HIPCHK(hipEventRecord(e1, st));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    KCHK();
+    if (us) *us = (double)ms * 1e3 / reps;
     return e.err_code;
 }

@@ -61,6 +61,7 @@ SYMBOLS = {
     "dkmc_set_x_block": (None, [_I]),
     "dkmc_get_x_block": (_I, []),
     "dkmc_set_pair_cutoff": (None, [_D]),
+    "dkmc_reset_pair_sum_cache": (None, []),
     "dkmc_set_tcache_budget": (None, [C.c_longlong]),
     "dkmc_set_current_warm_start": (None, [_I]),
     "dkmc_set_profiling": (None, [_I]),
@@ -98,6 +99,7 @@ SYMBOLS = {
     "dkmc_xt_time_share": (_I, [_I, _I, _I, c_dbl_p, c_dbl_p, c_int_p, C.POINTER(C.c_longlong)]),
     "dkmc_xt_check_shares": (_I, [_I, c_dbl_p, c_dbl_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), c_int_p]),
     "dkmc_xtb_check_product": (_I, [_I, c_dbl_p, c_dbl_p]),
+    "dkmc_xtb_time_apply": (_I, [_I, _I, _I, c_dbl_p]),
     "dkmc_debug_inject_fault": (None, [_I, _I]),
     "dkmc_comm_unique_id": (_I, [C.c_char_p]),
     "dkmc_comm_init_rccl": (_I, [_I, _I, C.c_char_p]),

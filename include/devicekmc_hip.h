@@ -129,6 +129,10 @@ void dkmc_set_tcache_budget(long long bytes);
  * rounding of the sum and under the last-bit noise of the reference's atomicAdd order).  0: every pair, exactly the terms the reference
  * sums (potential_solver_gpu.cu:908-958) -- for a parity run. */
 void dkmc_set_pair_cutoff(double x_cut);
+/* The pair sum keeps the grouping of the sites by (y, z) column between calls, keyed on the position / lattice arrays, N, pbc and the
+ * cut-off; freeing or re-initialising a GPUBuffers drops it.  A host that rewrites site positions IN PLACE behind the same device pointers
+ * (only possible through the raw-pointer entry dkmc_poisson_gridless_gpu; the reference never moves a site) calls this afterwards. */
+void dkmc_reset_pair_sum_cache(void);
 /* Width s of the block-CG of the current solve on the tiled X (csrc/xtb.hip).  1: the reference's single-vector loop
  * (solve_sparse_CG_Jacobi, iterative_solvers_gpu.cu:309-480: same iterate sequence, same start vector).  2 ... 16: block-CG over s
  * columns -- column 0 carries the physical right-hand side and start vector, columns 1 ... s - 1 fixed-seed auxiliary right-hand sides
@@ -293,6 +297,10 @@ int dkmc_xt_check_shares(int nranks, double *max_abs_diff, double *max_abs, long
 /* Test aid: on the X left resident by the last single-GPU solve, the MFMA tile x panel product of the block-CG (16 test vectors, one
  * sweep) against 16 passes of the single-vector tile kernel; largest absolute deviation and largest sum over the S rows. */
 int dkmc_xtb_check_product(int width, double *max_abs_diff, double *max_abs);
+/* Measurement aid: average duration [us] of the tile x panel kernel of the block-CG over the X left resident by the last single-GPU solve
+ * (`reps` launches).  variant 0: as a solve runs it; 1: without its matrix instructions (tile stream + LDS traffic); 2: without re-reading
+ * the tile stream (matrix instructions + LDS traffic). */
+int dkmc_xtb_time_apply(int width, int variant, int reps, double *us);
 /* Test aid for the error path of a sharded current solve (no counterpart in the reference): the calling rank fails ONCE, in the
  * assembly of X (phase 1) or on the host side of CG iteration `iteration` (phase 2).  Every rank's dkmc_update_power_gpu_sparse then
  * returns non-zero (the failing rank its own code, the others 46) instead of blocking in a collective: the ranks agree on the

@@ -236,7 +236,12 @@ def test_rccl_transport_one_rank():
         got_t = _supersteps(1, fmt=1, big=True)               # all-reduce variant (ncclAllReduce in place), 85 k sites
     finally:
         parallel.detach_solver_comm()
-    ref_t = _supersteps(1, fmt=1, big=True)
+    # (a sharded solve runs the single-vector loop; the one-GPU run it is compared with bit for bit must run it too, not the block-CG default)
+    lib.load().dkmc_set_x_block(1)
+    try:
+        ref_t = _supersteps(1, fmt=1, big=True)
+    finally:
+        lib.load().dkmc_set_x_block(16)
     assert got_t[0] == ref_t[0] and got_t[3]["spmv_tiles"] > 0     # one rank: the all-reduce is the identity, same bits as without it
     assert got_t[3]["xt_local_subblocks"] == got_t[3]["xt_subblocks"]
     assert got[0] == ref[0] and got[1] == ref[1]

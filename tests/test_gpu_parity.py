@@ -1128,3 +1128,80 @@ def test_split_matrix_cg(hip, offset):
     assert np.abs(got - want).max() <= 1e-8 * np.abs(want).max()
     # inputs are read only
     assert np.array_equal(dM.cpu().numpy(), M) and np.array_equal(dA.cpu().numpy(), A.data) and np.array_equal(dx.cpu().numpy(), x)
+
+
+def test_pair_sum_site_grouping_follows_the_structure(cell_2p5, hip):
+    """The cached grouping of the sites by (y, z) column (cell-list pair sum) must not outlive the structure it was built for:
+    a GPUBuffers is freed and one of the SAME size with the sites in another order is created -- hipMalloc returns the old addresses -- and
+    the pair sum of the second structure equals the oracle's; then positions are rewritten in place behind the same pointers and
+    dkmc_reset_pair_sum_cache() is called: again the oracle's sums.  (Before the fix the first case summed sites over the columns of the
+    old structure.)"""
+    from devicekmc_amd import params as pm, structure
+    from devicekmc_amd.host import _ptr
+    from devicekmc_amd.lib import check
+    from oracle import oracle as oc
+    host, L = hip
+    k = 6
+    s = structure.tile_structure(cell_2p5, k, 25.575, 25.575, 1440)
+    p = pm.KMCParameters().for_tiling(k)
+    lat = np.asarray(p.lattice, dtype=np.float64)
+    rng = np.random.default_rng(23)
+
+    def oracle_sum(x, y, z, q):
+        want = np.zeros(len(x))
+        oc.lib().okmc_poisson_gridless(len(x), oc._p(x), oc._p(y), oc._p(z), oc._p(lat), 0, C.c_double(p.sigma), C.c_double(p.k), oc._p(q), oc._p(want))
+        return want
+
+    def gpu_sum(gb):
+        check(L.dkmc_poisson_gridless_gpu(0, 0, gb.N_, _ptr(gb.lattice), _ptr(gb.sigma), _ptr(gb.k), _ptr(gb.site_x), _ptr(gb.site_y),
+                                          _ptr(gb.site_z), _ptr(gb.site_charge), _ptr(gb.site_potential_charge)))
+        return get(gb, "site_potential_charge").copy()
+
+    dev = host.Device(s, p, gpu_neighbors="cuda:0")
+    ok = (dev.site_element == pm.O_EL) | (dev.site_element == pm.VACANCY)
+    q = np.where(ok & (rng.random(dev.N) < 0.02), rng.choice([-2, 2], dev.N), 0).astype(np.int32)
+    gb = dev.make_gpubuf("cuda:0")
+    put(gb, "site_charge", q)
+    want = oracle_sum(dev.site_x, dev.site_y, dev.site_z, q)
+    assert np.abs(gpu_sum(gb) - want).max() <= 1e-12 * np.abs(want).max()
+    ptrs = (_ptr(gb.site_x), _ptr(gb.site_y), _ptr(gb.site_z))
+    # ---- same size, the lateral coordinates mirrored: every site changes its column ----
+    y2 = np.ascontiguousarray(lat[1] - dev.site_y - 1e-3); z2 = np.ascontiguousarray(lat[2] - dev.site_z - 1e-3)
+    want2 = oracle_sum(dev.site_x, y2, z2, q)
+    del gb                      # (GPUBuffers.__del__ -> dkmc_free_sparsity; torch's caching allocator hands the next buffers the same addresses)
+    import gc
+    gc.collect()
+    dev2 = host.Device(s, p, gpu_neighbors="cuda:0")
+    dev2.site_y[:] = y2; dev2.site_z[:] = z2
+    gb2 = dev2.make_gpubuf("cuda:0")
+    put(gb2, "site_charge", q)
+    got2 = gpu_sum(gb2)
+    assert np.abs(got2 - want2).max() <= 1e-12 * np.abs(want2).max(), "stale grouping after free + create (same addresses: %s)" % (ptrs == (_ptr(gb2.site_x), _ptr(gb2.site_y), _ptr(gb2.site_z)))
+    # ---- in place, behind the same pointers ----
+    put(gb2, "site_y", dev.site_y); put(gb2, "site_z", dev.site_z)
+    L.dkmc_reset_pair_sum_cache()
+    assert np.abs(gpu_sum(gb2) - want).max() <= 1e-12 * np.abs(want).max()
+
+
+def test_soak_60_supersteps_against_the_oracle(cell_2p5, hip):
+    """60 coupled supersteps of the 2.5 nm device with global heating on, HIP path against the CPU oracle step by step (the long-trajectory
+    check that used to live in tools/soak_vs_oracle.py): the same executed events (slot, i, j, type), charges and elements bit for bit,
+    current / KMC time / temperature within the CG tolerance (1e-10), at the library's defaults otherwise (block-CG on X)."""
+    from devicekmc_amd import params as pm
+    host, L = hip
+    p = pm.KMCParameters(); p.cg_tol = 1e-10; p.solve_heating_global = True
+    dev, sim, gb, o = make_pair(cell_2p5, p, hip)
+    worst = dict(I=0.0, T=0.0, dt=0.0, margin=1.0)
+    nev = 0
+    for k in range(60):
+        dev.updateCharge(gb); dev.updatePotential(gb, p, Vd, k)
+        _, dt = sim.executeKMCStep(gb, dev, want_log=True)
+        dev.updatePower(gb, p, Vd); dev.updateTemperature(gb, p, dt)
+        out = o.superstep(Vd)
+        assert np.array_equal(sim.last_event_log, o.last_events["log"]), k
+        assert np.array_equal(get(gb, "site_element"), o.element) and np.array_equal(get(gb, "site_charge"), o.charge), k
+        worst["I"] = max(worst["I"], abs(dev.imacro / out["imacro"] - 1)); worst["T"] = max(worst["T"], abs(dev.T_bg - out["T_bg"]))
+        worst["dt"] = max(worst["dt"], abs(dt / out["step_time"] - 1)); worst["margin"] = min(worst["margin"], float(o.last_events["margin"].min()))
+        nev += len(sim.last_event_log)
+        assert worst["I"] <= 1e-6 and worst["dt"] <= 1e-6 and worst["T"] <= 1e-7, (k, worst)
+    assert nev > 60 and worst["margin"] > 1e-9, (nev, worst)

@@ -787,7 +787,8 @@ __global__ void k_xt_set_sharded(XCtrl *ctrl) { ctrl->sharded = 1; }
 __global__ void k_xt_abort_word(XCtrl *ctrl, double *xbuf, int ns) { ctrl->abort_local = 1; xbuf[ns + 1] = 1.0; }
 // test aid: make this rank fail once, in the assembly (phase 1) or on the host side of CG iteration `iteration` (phase 2)
 static int g_fault_phase = 0, g_fault_iter = 0;
-extern "C" void dkmc_debug_inject_fault(int phase, int iteration) { g_fault_phase = phase; g_fault_iter = iteration; }
+extern int g_xtb_fault_iter;                 // xtb.hip: phase 3 = host side of a block-CG iteration of a sharded solve
+extern "C" void dkmc_debug_inject_fault(int phase, int iteration) { if (phase == 3) { g_xtb_fault_iter = iteration; return; } g_fault_phase = phase; g_fault_iter = iteration; }
 // q = s y (full length and compact over S): the product's input when a solve continues from an iterate another loop left in y
 __global__ void k_xt_requeue(int m, const double *__restrict__ y, const double *__restrict__ sc, const int *__restrict__ nsrank, double *__restrict__ q, double *__restrict__ qS)
 {
@@ -960,7 +961,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
     double *xbuf = nullptr;
     auto assemble = [&]() -> int {
         if (g_fault_phase == 1) { g_fault_phase = 0; return dkmc_fail(90, "injected fault (assembly of X)", __FILE__, __LINE__); }
-        if (sharded) { xbuf = (double *)scratch(S_CG_XCHG, (size_t)(ns + 2) * 8); if (!xbuf) return e.err_code; if (ns > 0) { rc = xt_side_init(); if (rc) return rc; } }
+        if (sharded) { xbuf = (double *)scratch(S_CG_XCHG, ((size_t)ns * (e.x_block > 1 ? 16 : 1) + 2) * 8); if (!xbuf) return e.err_code; if (ns > 0) { rc = xt_side_init(); if (rc) return rc; } }
         // ---- sparse part Xs: neighbour pattern of every row + values (same kernels as the CSR path, all rows) ----
         cnt = (int *)scratch(S_X_CNT, (size_t)(Nsub + 4) * 4);
         rp = (xrp_t *)scratch(S_X_ROWPTR, (size_t)(Nsub + 4) * sizeof(xrp_t));
@@ -1160,17 +1161,17 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
     bool solved = false;
     double prof_long_ms = 0.0, prof_short_ms = 0.0, prof_comm_ms = 0.0; int prof_long_n = 0, prof_short_n = 0, prof_comm_n = 0;
     e.stats.xb_width = 1; e.stats.xb_fallback = 0;
-    if (e.x_block > 1 && !sharded && ns > 0) {
+    if (e.x_block > 1 && ns > 0) {
         XtbArgs B{};
         B.m = m; B.ns = ns; B.ns_pad = ns_pad; B.nK = nK; B.nW = nW; B.s = e.x_block;
         B.items = (const XItem *)items + X.item_lo; B.item_n = X.item_n; B.tiles = tiles; B.sub_base = (int)X.sub_base; B.tval = tval;
         B.wrange = wrange; B.nitem_w = nitem_w; B.nrecords = X.nitems >> X.rec_shift;
         B.srow = srow; B.sS = sS; B.nsrank = nsrank; B.rp = rp; B.ci = col; B.val = val; B.sc = sc; B.b = rhs; B.y = y;
-        B.ctrl = ctrl; B.tol2 = tol2; B.nt_loads = nt_loads;
+        B.ctrl = ctrl; B.tol2 = tol2; B.nt_loads = nt_loads; B.sharded = sharded; B.w_lo = X.w_lo; B.w_hi = X.w_hi;
         int bi = 0; double brr = 0.0;
         rc = xtb_cg(B, &bi, &brr);
         e.stats.xb_width = e.x_block;
-        if (rc == 0) { solved = true; h.iters = bi; h.rr[bi & 1] = brr; }
+        if (rc == 0) { solved = true; h.iters = bi; h.rr[bi & 1] = brr; if (sharded) e.stats.comm_count_per_rank = (long long)ns * (4 * ((e.x_block + 3) / 4)) + 2; }
         else if (rc != DKMC_XTB_BREAKDOWN) return rc;
         else {
             e.stats.xb_fallback = 1;

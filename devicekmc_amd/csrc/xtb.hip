@@ -43,7 +43,7 @@
 
 #define XB_SP 16                      // vectors per panel row (padded block width)
 #define XB_DSPLIT 8                   // workgroups per driver row of Xs
-#define XB_NG 5                       // Gram matrices per pass: P'T, P'R, T'R, T'T, R'R
+#define XB_NG 6                       // Gram matrices per pass: P'T, P'R, T'R, T'T, R'R, P'P
 typedef double dbl4 __attribute__((ext_vector_type(4)));
 #define XB_MFMA(a, b, c) __builtin_amdgcn_mfma_f64_16x16x4f64((a), (b), (c), 0, 0, 0)
 #define XB_MFMA4(a, b, c) __builtin_amdgcn_mfma_f64_4x4x4f64((a), (b), (c), 0, 0, 0)
@@ -361,17 +361,60 @@ __device__ __forceinline__ double xtb_list_sum(const double *__restrict__ p, siz
     }
     return (a0 + a1) + (a2 + a3);
 }
-template <int INIT>
+// ---- sharded solve: this rank's tile sums of every S row -> the exchange buffer xbuf[ns][so]; behind them the control words: rank 0's stop
+// decision and any rank's abort word.  [w_lo, w_hi): windows that can hold this rank's partial sums (every other cell of its arrays is zero)
+__global__ __launch_bounds__(XT_NT) void k_xtb_fold_local(int ns, int nK, int nW, int so, const int2 *__restrict__ wrange, const int *__restrict__ nitem_w,
+                                                          const double *__restrict__ rowpartB, const double *__restrict__ colpartB, double *__restrict__ xbuf,
+                                                          const XCtrl *ctrl, int flag_rank0, int w_lo, int w_hi)
+{
+    if (ctrl->done) return;
+    const int v = threadIdx.x & 15, r4 = threadIdx.x >> 4;
+    const int rec_shift = nitem_w[2 * (nW + 2)];
+    for (int k = blockIdx.x; k < nK; k += gridDim.x) {
+        int2 wr = wrange[k];
+        wr.x = max(wr.x, w_lo); wr.y = min(wr.y, w_hi);
+        const int wk = k / (XT_C / XT_R);
+        const bool mine = wk >= w_lo && wk < w_hi;
+        const int nc = mine ? nitem_w[wk] >> rec_shift : 0, cbase = nitem_w[nW + 2 + wk] >> rec_shift;
+        double tA = 0.0, tB = 0.0;
+        if (v < so) {
+            const double *rpp = rowpartB + ((size_t)k * nW * XT_R + r4) * so + v;
+            const double *cpp = colpartB + ((size_t)cbase * XT_C + (XT_R * (k % (XT_C / XT_R)) + r4)) * so + v;
+            const size_t rs = (size_t)XT_R * so, cs = (size_t)XT_C * so;
+            tA = xtb_list_sum(cpp, cs, 0, nc, 1) + xtb_list_sum(rpp, rs, wr.x, wr.y, 1);
+            tB = xtb_list_sum(cpp + (size_t)16 * so, cs, 0, nc, 1) + xtb_list_sum(rpp + (size_t)16 * so, rs, wr.x, wr.y, 1);
+            const int sA = XT_R * k + r4, sB = sA + 16;
+            if (sA < ns) xbuf[(size_t)sA * so + v] = tA;
+            if (sB < ns) xbuf[(size_t)sB * so + v] = tB;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        xbuf[(size_t)ns * so] = (flag_rank0 && ctrl->done_local) ? 1.0 : 0.0;
+        xbuf[(size_t)ns * so + 1] = ctrl->abort_local ? 1.0 : 0.0;
+    }
+}
+__global__ void k_xtb_abort_word(XCtrl *ctrl, double *xbuf, size_t slot) { ctrl->abort_local = 1; xbuf[slot] = 1.0; }
+__global__ void k_xtb_set_sharded(XCtrl *ctrl) { ctrl->sharded = 1; }
+
+// SH: sharded solve -- the tile sums of the S rows come all-reduced in xbuf[ns][so]; xbuf[ns so] carries rank 0's stop decision and
+// xbuf[ns so + 1] the abort word, which every rank turns into `done` here, in the same iteration (see k_xt_rows_apply)
+template <int INIT, int SH = 0>
 __global__ __launch_bounds__(XT_NT) void k_xtb_rows(int ns, int nK, int nW, int m, int s, int so, const int2 *__restrict__ wrange, const int *__restrict__ nitem_w,
                                                     const double *__restrict__ rowpartB, const double *__restrict__ colpartB,
                                                     const int *__restrict__ srow, const double *__restrict__ sS, const int *__restrict__ nsrank,
                                                     const double *__restrict__ sc, const double *__restrict__ drvpart, double *__restrict__ T,
                                                     const double *__restrict__ P, double *__restrict__ R, const double *__restrict__ b,
-                                                    double *__restrict__ gpart, const XCtrl *ctrl)
+                                                    double *__restrict__ gpart, XCtrl *ctrl, const double *__restrict__ xbuf, int it)
 {
-    __shared__ double lg[4][XB_NG][4][64];                                     // the four waves' Gram accumulators (40 KiB)
+    __shared__ double lg[4][XB_NG][4][64];                                     // the four waves' Gram accumulators (48 KiB)
     __shared__ int sdone;
-    if (threadIdx.x == 0) sdone = ctrl->done;
+    if (threadIdx.x == 0) {
+        sdone = ctrl->done;
+        if (SH && !sdone && (xbuf[(size_t)ns * so] != 0.0 || xbuf[(size_t)ns * so + 1] != 0.0)) {
+            sdone = 1;
+            if (blockIdx.x == 0) { ctrl->done = it + 1; if (xbuf[(size_t)ns * so + 1] != 0.0) ctrl->aborted = 1; }     // stops this iteration's step kernel too
+        }
+    }
     __syncthreads();
     if (sdone) return;
     const int v = threadIdx.x & 15, r4 = threadIdx.x >> 4;
@@ -386,14 +429,16 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_rows(int ns, int nK, int nW, int 
         const int wk = k / (XT_C / XT_R);
         const int nc = nitem_w[wk] >> rec_shift, cbase = nitem_w[nW + 2 + wk] >> rec_shift;
         double tA = 0.0, tB = 0.0;
-        if (v < so) {
+        const int sA = XT_R * k + r4, sB = sA + 16;
+        if (SH) {
+            if (v < so) { tA = sA < ns ? xbuf[(size_t)sA * so + v] : 0.0; tB = sB < ns ? xbuf[(size_t)sB * so + v] : 0.0; }
+        } else if (v < so) {
             const double *rpp = rowpartB + ((size_t)k * nW * XT_R + r4) * so + v;
             const double *cpp = colpartB + ((size_t)cbase * XT_C + (XT_R * (k % (XT_C / XT_R)) + r4)) * so + v;
             const size_t rs = (size_t)XT_R * so, cs = (size_t)XT_C * so;
             tA = xtb_list_sum(cpp, cs, 0, nc, 1) + xtb_list_sum(rpp, rs, wr.x, wr.y, 1);
             tB = xtb_list_sum(cpp + (size_t)16 * so, cs, 0, nc, 1) + xtb_list_sum(rpp + (size_t)16 * so, rs, wr.x, wr.y, 1);
         }
-        const int sA = XT_R * k + r4, sB = sA + 16;
         double pA = 0.0, pB = 0.0, rA = 0.0, rB = 0.0;
         if (sA < ns) {
             const int row = srow[sA]; const size_t o = (size_t)row * XB_SP + v;
@@ -406,8 +451,8 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_rows(int ns, int nK, int nW, int 
             if (INIT) { rB = tB - xtb_rhs(b, row, v, s); R[o] = rB; } else { pB = P[o]; rB = R[o]; }
         } else tB = 0.0;
         if (!INIT) {
-            G[0] = XB_MFMA(pA, tA, G[0]); G[1] = XB_MFMA(pA, rA, G[1]); G[2] = XB_MFMA(tA, rA, G[2]); G[3] = XB_MFMA(tA, tA, G[3]);
-            G[0] = XB_MFMA(pB, tB, G[0]); G[1] = XB_MFMA(pB, rB, G[1]); G[2] = XB_MFMA(tB, rB, G[2]); G[3] = XB_MFMA(tB, tB, G[3]);
+            G[0] = XB_MFMA(pA, tA, G[0]); G[1] = XB_MFMA(pA, rA, G[1]); G[2] = XB_MFMA(tA, rA, G[2]); G[3] = XB_MFMA(tA, tA, G[3]); G[5] = XB_MFMA(pA, pA, G[5]);
+            G[0] = XB_MFMA(pB, tB, G[0]); G[1] = XB_MFMA(pB, rB, G[1]); G[2] = XB_MFMA(tB, rB, G[2]); G[3] = XB_MFMA(tB, tB, G[3]); G[5] = XB_MFMA(pB, pB, G[5]);
         }
         G[4] = XB_MFMA(rA, rA, G[4]); G[4] = XB_MFMA(rB, rB, G[4]);
     }
@@ -442,7 +487,7 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_rows(int ns, int nK, int nW, int 
                 }
                 if (INIT) { if (use) { r_ = t_ - xtb_rhs(b, row, v, s); R[o] = r_; } }
                 else if (use) { p_ = pv[u]; r_ = rv[u]; }
-                if (!INIT) { G[0] = XB_MFMA(p_, t_, G[0]); G[1] = XB_MFMA(p_, r_, G[1]); G[2] = XB_MFMA(t_, r_, G[2]); G[3] = XB_MFMA(t_, t_, G[3]); }
+                if (!INIT) { G[0] = XB_MFMA(p_, t_, G[0]); G[1] = XB_MFMA(p_, r_, G[1]); G[2] = XB_MFMA(t_, r_, G[2]); G[3] = XB_MFMA(t_, t_, G[3]); G[5] = XB_MFMA(p_, p_, G[5]); }
                 G[4] = XB_MFMA(r_, r_, G[4]);
             }
         }
@@ -602,6 +647,7 @@ __global__ __launch_bounds__(64) void k_xtb_small(int it, int s, const double *_
         }
         XB_WSYNC();
         if (!xtb_chol(Lp, s)) {                                               // no step can be taken: stop BEFORE this iteration's update (uniform)
+            // (sharded: every rank holds the same Gram matrices -- the all-reduce hands all of them the same bits -- and takes this branch together)
             if (threadIdx.x == 0) { ctrl->pad[0] = 1; ctrl->done = it + 1; }
             return;
         }
@@ -616,16 +662,33 @@ __global__ __launch_bounds__(64) void k_xtb_small(int it, int s, const double *_
         xtb_mm(Grn, Gm[2], Cm, true, 1.0, Grn, 1.0);
         xtb_symmetrise(Grn, s);
         rr_new = Grn[0][0];
-        // Gram matrix of D = -R+ + P beta (P'P = I): R+'R+ - beta'(P'R+) - (P'R+)'beta + beta'beta, P'R+ = P'R + P'T c
+        // Gram matrix of D = -R+ + P beta: R+'R+ - beta'(P'R+) - (P'R+)'beta + beta'(P'P)beta, P'R+ = P'R + P'T c.  P'P is MEASURED (it is
+        // the identity only as far as the previous orthonormalisation was exact), so the recurrence holds for whatever P the loop carries
         xtb_mm(Gprn, Tm, Cm, false, 1.0, Gm[1], 1.0);
-        xtb_mm(Gg, Bm, Bm, true, 1.0, Grn, 1.0);
+        xtb_symmetrise(Gm[5], s);
+        xtb_mm(Gg, Gm[5], Bm, false, 1.0, nullptr, 0.0);                      // (P'P) beta
+        xtb_mm(Gg, Bm, Gg, true, 1.0, Grn, 1.0);
         xtb_mm(Gg, Bm, Gprn, true, -1.0, Gg, 1.0);
         xtb_mm(Gg, Gprn, Bm, true, -1.0, Gg, 1.0);
         xtb_symmetrise(Gg, s);
     }
     const bool stop = init ? !(sqrt(rr_new) > tol2) : !(rr_new > tol2);
-    // W = L^-T of the Gram matrix's Cholesky factor: W' G W = I.  A failure here still lets this iteration's update of Y stand.
-    const bool okg = xtb_chol(Gg, s);
+    // W = L^-T of the Gram matrix's Cholesky factor: W' G W = I.  Close to convergence G can lose definiteness in its rounding (its
+    // columns become dependent): the directions are then only scaled to unit length this iteration (W diagonal) -- P'P is measured, so
+    // nothing downstream assumes more.  Only a non-positive DIAGONAL ends the block loop (the update of Y of this iteration stands).
+    bool diag_ok = true;
+    for (int k = 0; k < s; ++k) if (!(Gg[k][k] > 0.0)) diag_ok = false;
+    double gdiag = (threadIdx.x < 16 && (int)threadIdx.x < s && diag_ok) ? Gg[threadIdx.x][threadIdx.x] : 1.0;
+    XB_WSYNC();
+    const bool cholg = xtb_chol(Gg, s);
+    const bool okg = diag_ok;
+    if (!cholg) {                                                             // uniform: Gg <- diag(sqrt(g_ii)) stands in for the factor
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int e = (int)threadIdx.x + 64 * u, i = e >> 4, j = e & 15; Gg[i][j] = (i == j) ? 1.0 : 0.0; }
+        XB_WSYNC();
+        if (threadIdx.x < 16) Gg[threadIdx.x][threadIdx.x] = sqrt(gdiag);
+        XB_WSYNC();
+    }
     // W = (L')^-1: column j of W solves L' w = e_j (upper triangular), by lane j
     if (threadIdx.x < 16) {
         const int jj = threadIdx.x;
@@ -652,7 +715,10 @@ __global__ __launch_bounds__(64) void k_xtb_small(int it, int s, const double *_
         ctrl->rr[(it + 1) & 1] = rr_new; ctrl->rr[it & 1] = rr_new;
         ctrl->iters = it + 1;
         if (!okg) ctrl->pad[0] = 2;
-        if (stop || !okg) ctrl->done = it + 2;                                // the step kernel of this iteration still runs (see k_xt_step)
+        else if (!cholg) ctrl->pad[1] += 1;                                   // iterations that only rescaled their directions (statistics)
+        // the step kernel of this iteration still runs (see k_xt_step).  Sharded solve: only the local flag is set; rank 0's travels in the next
+        // exchange and k_xtb_rows turns it into `done` on every rank in the same iteration (one wasted product per solve)
+        if (stop || !okg) { if (ctrl->sharded) ctrl->done_local = 1; else ctrl->done = it + 2; }
     }
 }
 
@@ -731,6 +797,9 @@ __global__ void k_xtb_zero(long long n, double *__restrict__ p)
     if (i < n) p[i] = 0.0;
 }
 
+// test aid: make this rank fail once on the host side of block-CG iteration `iteration` of a sharded solve (dkmc_debug_inject_fault(3, it))
+int g_xtb_fault_iter = -1;
+
 // ---- host loop ------------------------------------------------------------------------------------------------------------------------
 // Returns 0 with the scaled solution of column 0 in A.y; DKMC_XTB_BREAKDOWN (> 0, no error recorded) when an s x s system lost
 // definiteness: A.y then holds the last good iterate and the caller continues with the single-vector loop from it.
@@ -754,6 +823,17 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
     HIPCHK(hipMemsetAsync(rowpartB, 0, (size_t)(ncell + 1) * XT_R * so * 8, st));
     HIPCHK(hipMemsetAsync(colpartB, 0, (size_t)(A.nrecords + 1) * XT_C * so * 8, st));
     HIPCHK(hipMemsetAsync(A.ctrl, 0, sizeof(XCtrl), st));
+    // sharded solve (comm.hip): this rank streams its share of the tiles; the tile sums of the S rows are completed by ONE all-reduce of
+    // ns x so doubles (+ two control words) per sweep -- a sixteenth of the exchanges of the single-vector loop at 16 times the payload
+    const bool sharded = A.sharded;
+    double *xbuf = nullptr;
+    const size_t xcount = (size_t)A.ns * so + 2;
+    if (sharded) {
+        xbuf = (double *)scratch(S_CG_XCHG, xcount * 8);
+        if (!xbuf) return e.err_code;
+        hipLaunchKernelGGL(k_xtb_set_sharded, dim3(1), dim3(1), 0, st, A.ctrl);
+    }
+    int local_fail = 0;
     hipLaunchKernelGGL(k_xtb_init, dim3((unsigned)((pan + 255) / 256)), dim3(256), 0, st, m, (const double *)A.y, A.sc, A.nsrank, y0, P, QS);
     const int ntb = (A.item_n + 3) / 4;
     const int nnb = 2 * XB_DSPLIT + (std::max(m - 2, 1) + 15) / 16;
@@ -772,11 +852,30 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
         }
         hipLaunchKernelGGL(k_xtb_neigh, dim3(nnb), dim3(XT_NT), 0, st, m, A.rp, A.ci, A.val, (const double *)P, A.sc, A.nsrank, (const XCtrl *)A.ctrl, T, drvpart);
     };
-#define XB_ROWS_ARGS A.ns, A.nK, A.nW, m, s, so, A.wrange, A.nitem_w, (const double *)rowpartB, (const double *)colpartB, A.srow, A.sS, A.nsrank, A.sc, \
-                     (const double *)drvpart, T, (const double *)P, R, A.b, gpart, (const XCtrl *)A.ctrl
+#define XB_ROWS_ARGS(IT_) A.ns, A.nK, A.nW, m, s, so, A.wrange, A.nitem_w, (const double *)rowpartB, (const double *)colpartB, A.srow, A.sS, A.nsrank, A.sc, \
+                     (const double *)drvpart, T, (const double *)P, R, A.b, gpart, A.ctrl, (const double *)xbuf, IT_
+    // S rows of T + partial Gram matrices; a sharded solve exchanges the tile sums first.  A host-side failure of this rank between two
+    // collectives must not leave the peers in the all-reduce: it still joins, with the abort word set, and every rank leaves together.
+    auto rows = [&](bool init, int itn, hipEvent_t e2, hipEvent_t e3) -> int {
+        if (sharded) {
+            hipLaunchKernelGGL(k_xtb_fold_local, dim3(std::max(A.nK, 1)), dim3(XT_NT), 0, st, A.ns, A.nK, A.nW, so, A.wrange, A.nitem_w, (const double *)rowpartB,
+                               (const double *)colpartB, xbuf, (const XCtrl *)A.ctrl, comm_rank() == 0 ? 1 : 0, A.w_lo, A.w_hi);
+            if (hipGetLastError() != hipSuccess || local_fail) {
+                if (!local_fail) local_fail = dkmc_fail(92, "block-CG: launch failed between two collectives", __FILE__, __LINE__);
+                hipLaunchKernelGGL(k_xtb_abort_word, dim3(1), dim3(1), 0, st, A.ctrl, xbuf, (size_t)A.ns * so + 1);
+            }
+            if (int rcx = comm_allreduce_sum_f64(xbuf, xcount)) return rcx;
+            if (init) hipLaunchKernelGGL((k_xtb_rows<1, 1>), dim3(ng), dim3(XT_NT), 0, st, XB_ROWS_ARGS(itn));
+            else hipExtLaunchKernelGGL((k_xtb_rows<0, 1>), dim3(ng), dim3(XT_NT), 0, st, e2, e3, 0, XB_ROWS_ARGS(itn));
+        } else {
+            if (init) hipLaunchKernelGGL((k_xtb_rows<1, 0>), dim3(ng), dim3(XT_NT), 0, st, XB_ROWS_ARGS(itn));
+            else hipExtLaunchKernelGGL((k_xtb_rows<0, 0>), dim3(ng), dim3(XT_NT), 0, st, e2, e3, 0, XB_ROWS_ARGS(itn));
+        }
+        return 0;
+    };
     // ---- R = A Y0 - B ; first directions ----
     product(nullptr, nullptr);
-    hipLaunchKernelGGL((k_xtb_rows<1>), dim3(ng), dim3(XT_NT), 0, st, XB_ROWS_ARGS);
+    if (int rcx = rows(true, -1, nullptr, nullptr)) return rcx;
     hipLaunchKernelGGL(k_xtb_gred, dim3(XB_NG * 16), dim3(XT_NT), 0, st, ng, (const double *)gpart, gfin, (const XCtrl *)A.ctrl);
     hipLaunchKernelGGL(k_xtb_small, dim3(1), dim3(64), 0, st, -1, s, (const double *)gfin, mats, A.ctrl, A.tol2);
     hipLaunchKernelGGL(k_xtb_zero, dim3((unsigned)((pan + 255) / 256)), dim3(256), 0, st, (long long)pan, P);          // Y0 has served: P_{-1} = 0
@@ -801,8 +900,9 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
         for (int bq = 0; bq < batch; ++bq, ++it) {
             const bool pb = prof && bq < 8 * XT_PROF_STRIDE && (bq % XT_PROF_STRIDE == 0);
             const int sl = bq / XT_PROF_STRIDE;
+            if (g_xtb_fault_iter >= 0 && sharded && it >= g_xtb_fault_iter) { g_xtb_fault_iter = -1; local_fail = dkmc_fail(91, "injected fault (block-CG iteration)", __FILE__, __LINE__); }
             product(pb ? evs[4 * sl] : nullptr, pb ? evs[4 * sl + 1] : nullptr);
-            hipExtLaunchKernelGGL((k_xtb_rows<0>), dim3(ng), dim3(XT_NT), 0, st, pb ? evs[4 * sl + 2] : nullptr, pb ? evs[4 * sl + 3] : nullptr, 0, XB_ROWS_ARGS);
+            if (int rcx = rows(false, it, pb ? evs[4 * sl + 2] : nullptr, pb ? evs[4 * sl + 3] : nullptr)) return rcx;
             hipLaunchKernelGGL(k_xtb_gred, dim3(XB_NG * 16), dim3(XT_NT), 0, st, ng, (const double *)gpart, gfin, (const XCtrl *)A.ctrl);
             hipLaunchKernelGGL(k_xtb_small, dim3(1), dim3(64), 0, st, it, s, (const double *)gfin, mats, A.ctrl, A.tol2);
             hipLaunchKernelGGL(k_xtb_step, dim3(gs), dim3(XT_NT), 0, st, m, it, (const double *)mats, y0, R, P, (const double *)T, A.sc, A.nsrank, QS, (const XCtrl *)A.ctrl);
@@ -812,6 +912,8 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
         if (e.x_iter_hint > 12) batch = 4; else if (batch < 64) batch *= 2;
     }
 #undef XB_ROWS_ARGS
+    if (local_fail) return local_fail;                                         // the peers were told (abort word)
+    if (h.aborted) return dkmc_fail(46, "a peer rank aborted the sharded current solve", __FILE__, __LINE__);
     if (e.err_code) return e.err_code;
     HIPCHK(hipMemcpyAsync(A.y, y0, (size_t)m * 8, hipMemcpyDeviceToDevice, st));
     e.x_iter_hint = h.iters;
@@ -882,9 +984,9 @@ extern "C" int dkmc_xtb_check_product(int width, double *max_abs_diff, double *m
                        (int)X.sub_base, (const double *)g_xb.tval, (const double *)QS, X.nW, rowpartB, colpartB, (const XCtrl *)ctrl)
     if (so == 4) XB_APPLY(1); else if (so == 8) XB_APPLY(2); else if (so == 12) XB_APPLY(3); else XB_APPLY(4);
 #undef XB_APPLY
-    hipLaunchKernelGGL((k_xtb_rows<1>), dim3(ng), dim3(XT_NT), 0, st, ns, X.nK, X.nW, m, s, so, (const int2 *)g_xb.wrange, (const int *)g_xb.nitem_w, (const double *)rowpartB,
+    hipLaunchKernelGGL((k_xtb_rows<1, 0>), dim3(ng), dim3(XT_NT), 0, st, ns, X.nK, X.nW, m, s, so, (const int2 *)g_xb.wrange, (const int *)g_xb.nitem_w, (const double *)rowpartB,
                        (const double *)colpartB, (const int *)g_xb.srow, (const double *)sS, (const int *)g_xb.nsrank, (const double *)sc, (const double *)drvpart, T,
-                       (const double *)P, R, (const double *)rhs, gpart, (const XCtrl *)ctrl);
+                       (const double *)P, R, (const double *)rhs, gpart, ctrl, (const double *)nullptr, -1);
     KCHK();
     const int gb = (ns + 255) / 256;
     for (int v = 0; v < so; ++v) {

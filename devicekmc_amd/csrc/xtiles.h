@@ -67,6 +67,7 @@ struct XtbArgs {
     const double *b;                              // scaled right-hand side
     double *y;                                    // in: scaled start vector y / s; out: scaled solution
     XCtrl *ctrl; double tol2; bool nt_loads;
+    bool sharded; int w_lo, w_hi;                 // sharded solve (comm.hip): windows of this rank's tiles
 };
 int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out);
 __global__ void k_xt_vec_mul(int m, double *__restrict__ y, const double *__restrict__ s);

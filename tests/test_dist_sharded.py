@@ -110,7 +110,11 @@ def test_two_ranks_lockstep_bit_identical():
     tot = gt0[3]["xt_subblocks"]
     assert tot == gt1[3]["xt_subblocks"] > 0 and gt0[3]["xt_local_subblocks"] + gt1[3]["xt_local_subblocks"] == tot
     assert abs(gt0[3]["xt_local_subblocks"] - gt1[3]["xt_local_subblocks"]) <= 8 * 16          # balanced up to one work item
-    assert gt0[3]["comm_count_per_rank"] == gt0[3]["xt_ns"] + 2                                 # |S| row sums + the stop decision + the abort word per all-reduce
+    # per all-reduce of the block-CG (default width 16): |S| x 16 tile sums + the stop decision + the abort word
+    # (at the 1e-10 of this test the s x s systems can lose definiteness in the last sweeps -- the second step here does: the solve then finishes in the
+    # single-vector loop, |S| + 2 doubles per exchange, on every rank alike: they hold the same Gram matrices)
+    assert gt0[3]["xb_width"] == 16 and gt0[3]["xb_fallback"] == gt1[3]["xb_fallback"]
+    assert gt0[3]["comm_count_per_rank"] == (16 if not gt0[3]["xb_fallback"] else 1) * gt0[3]["xt_ns"] + 2, (gt0[3]["xb_fallback"], gt0[3]["comm_count_per_rank"], gt0[1])
     nseg = got0[3]["spmv_segments"]
     assert got0[3]["comm_local_segments"] + got1[3]["comm_local_segments"] == nseg > 0      # the ranks split the segments
     assert abs(got0[3]["comm_local_segments"] - got1[3]["comm_local_segments"]) <= 64      # balanced up to one row
@@ -132,9 +136,12 @@ def _fault_worker(rank, world, port, q):
     gb = dev.make_gpubuf("cuda:0")
     dev.setLaplacePotential(gb, p, Vd); gb.sync_HostToGPU(dev)
     seen = []
-    for phase, it in ((1, 0), (2, 5), (0, 0)):                  # fault in the assembly, fault on the host side of CG iteration 5, clean step
+    # fault in the assembly; on the host side of block-CG iteration 5 (the default loop); on the host side of iteration 5 of the
+    # single-vector loop (dkmc_set_x_block(1)); clean step
+    for phase, it in ((1, 0), (3, 5), (2, 5), (0, 0)):
         dev.updateCharge(gb); dev.updatePotential(gb, p, Vd, 0)
         sim.executeKMCStep(gb, dev)
+        L.dkmc_set_x_block(1 if phase == 2 else 16)
         if rank == 1 and phase:
             L.dkmc_debug_inject_fault(phase, it)
         try:
@@ -151,8 +158,9 @@ def _fault_worker(rank, world, port, q):
 
 def test_sharded_error_path_returns_on_every_rank():
     """A rank-local failure inside a sharded current solve must not leave the peers blocked in a collective.  Rank 1 fails once in the
-    assembly of X (before the first collective: the ranks agree on the outcome of the set-up, comm_agree) and once on the host side of a
-    CG iteration (the abort word travels with the next all-reduce): both times BOTH ranks return an error from update_power -- the
+    assembly of X (before the first collective: the ranks agree on the outcome of the set-up, comm_agree) and once on the host side of an
+    iteration of each CG loop, the block-CG (default) and the single-vector one (the abort word travels with the next all-reduce): every
+    time BOTH ranks return an error from update_power -- the
     failing rank its own, the peer "a peer rank ..." -- and the next, clean superstep runs on both and gives the same current."""
     import __graft_entry__ as g
     g.build()
@@ -164,10 +172,11 @@ def test_sharded_error_path_returns_on_every_rank():
     out = sorted((q.get(timeout=300) for _ in range(world)), key=lambda t: t[0])
     for p in procs: p.join(60); assert p.exitcode == 0
     (_, s0), (_, s1) = out
-    assert [k for k, _ in s0] == [1, 1, 0] and [k for k, _ in s1] == [1, 1, 0], (s0, s1)
+    assert [k for k, _ in s0] == [1, 1, 1, 0] and [k for k, _ in s1] == [1, 1, 1, 0], (s0, s1)
     assert "peer rank" in s0[0][1] and "injected fault (assembly" in s1[0][1]
-    assert "peer rank" in s0[1][1] and "injected fault (CG iteration" in s1[1][1]
-    assert s0[2][1] == s1[2][1] and s0[2][1] != 0.0
+    assert "peer rank" in s0[1][1] and "injected fault (block-CG iteration" in s1[1][1]
+    assert "peer rank" in s0[2][1] and "injected fault (CG iteration" in s1[2][1]
+    assert s0[3][1] == s1[3][1] and s0[3][1] != 0.0
 
 
 def _solo_worker(rank, q, nsteps):
@@ -233,16 +242,21 @@ def test_rccl_transport_one_rank():
         lib.load().dkmc_comm_info(C.byref(n), C.byref(r), C.byref(t))
         assert (n.value, r.value, t.value) == (1, 0, 1)
         got = _supersteps(2)
-        got_t = _supersteps(1, fmt=1, big=True)               # all-reduce variant (ncclAllReduce in place), 85 k sites
-    finally:
-        parallel.detach_solver_comm()
-    # (a sharded solve runs the single-vector loop; the one-GPU run it is compared with bit for bit must run it too, not the block-CG default)
-    lib.load().dkmc_set_x_block(1)
-    try:
-        ref_t = _supersteps(1, fmt=1, big=True)
+        got_t = _supersteps(1, fmt=1, big=True)               # all-reduce variant (ncclAllReduce in place), 85 k sites, block-CG (default)
+        lib.load().dkmc_set_x_block(1)
+        got_t1 = _supersteps(1, fmt=1, big=True)              # ... and the single-vector loop
     finally:
         lib.load().dkmc_set_x_block(16)
-    assert got_t[0] == ref_t[0] and got_t[3]["spmv_tiles"] > 0     # one rank: the all-reduce is the identity, same bits as without it
+        parallel.detach_solver_comm()
+    ref_t = _supersteps(1, fmt=1, big=True)
+    lib.load().dkmc_set_x_block(1)
+    try:
+        ref_t1 = _supersteps(1, fmt=1, big=True)
+    finally:
+        lib.load().dkmc_set_x_block(16)
+    # one rank: the all-reduce is the identity and the exchange buffer holds the sums the one-GPU kernels form: same bits as without it, in both loops
+    assert got_t[0] == ref_t[0] and got_t[1] == ref_t[1] and got_t[3]["spmv_tiles"] > 0 and got_t[3]["xb_width"] == 16
+    assert got_t1[0] == ref_t1[0] and got_t1[1] == ref_t1[1] and got_t1[3]["xb_width"] == 1
     assert got_t[3]["xt_local_subblocks"] == got_t[3]["xt_subblocks"]
     assert got[0] == ref[0] and got[1] == ref[1]
     for name in ref[2]:

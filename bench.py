@@ -313,6 +313,32 @@ def summary(sim, elapsed, steps):
     }
 
 
+def strong_scaling_model_block(sim, roof, res):
+    """Coarse model of the sharded block-CG from ONE-GPU measurements: per sweep the tile x panel kernel scales with the rank's share of the
+    tiles (1 / N; the sharded single-vector solve measures 0.93-0.98 of that on its shares), everything else of a sweep (neighbour part, row
+    kernel, Gram reduction, s x s algebra, panel updates) is replicated, and one all-gather of |S| x so doubles per rank is added at an ASSUMED
+    rate.  No multi-GPU run stands behind it."""
+    st = sim.host.get_stats()
+    iters = res["per_step"]["cg_iters_X"]
+    step_ms = res["ms_per_step"]
+    apply_us = roof["avg_launch_us"]
+    sweep_us = res["split_ms"]["current"] * 1e3 / max(iters, 1)
+    other_us = max(sweep_us - apply_us, 0.0)
+    so = 4 * ((int(st["xb_width"]) + 3) // 4)
+    payload = (int(st["xt_ns"]) * so + 2) * 8.0
+    rows = {}
+    for n in (1, 2, 4, 8):
+        # every rank receives n - 1 slots over its n - 1 (of 7) xGMI links in parallel: payload / link rate + a latency term
+        xchg = 0.0 if n == 1 else payload / 100e9 * 1e6 + 20.0
+        sw = apply_us / n + other_us + xchg
+        tn = step_ms - iters * (sweep_us - sw) * 1e-3
+        rows[n] = {"apply_us": round(apply_us / n, 1), "replicated_us_per_sweep": round(other_us, 1), "exchange_us_assumed": round(xchg, 1),
+                   "exchange_bytes_per_rank": payload, "modelled_ms_per_step": round(tn, 1), "modelled_speedup": round(step_ms / tn, 2)}
+    return {"what": "coarse: apply kernel / N + replicated rest of a sweep + an ASSUMED all-gather (payload / 100 GB/s per link + 20 us); nothing here was run on more than one GPU",
+            "cg_sweeps_X_per_step": iters, "single_gpu_ms_per_step": step_ms, "by_n_gpus": rows,
+            "note": "the replicated part of a sweep (neighbour part, row kernel, panel updates) caps the speed-up near apply / rest + 1; sharding those rows is the next step"}
+
+
 ALLREDUCE_US_ASSUMED = {1: 0.0, 2: 25.0, 4: 40.0, 8: 60.0}     # in-place all-reduce of |S| + 1 doubles (0.74 MB at 9.4e5 sites) over xGMI: ASSUMED, not measured
 
 
@@ -632,6 +658,8 @@ def main():
         if n != args.steps:
             out["steps_requested"] = args.steps
         out.update(roofs)
+        if big and sim.x_block > 1 and "roofline" in out:
+            out["strong_scaling_model"] = strong_scaling_model_block(sim, out["roofline"], res)
         # ---- same simulation, optional unscaled warm start of the current solve (never `value`) ----
         if args.warm_start == 0 and not args.no_alt:
             sim.L.dkmc_set_current_warm_start(1)

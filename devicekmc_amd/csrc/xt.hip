@@ -961,7 +961,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
     double *xbuf = nullptr;
     auto assemble = [&]() -> int {
         if (g_fault_phase == 1) { g_fault_phase = 0; return dkmc_fail(90, "injected fault (assembly of X)", __FILE__, __LINE__); }
-        if (sharded) { xbuf = (double *)scratch(S_CG_XCHG, ((size_t)ns * (e.x_block > 1 ? 16 : 1) + 2) * 8); if (!xbuf) return e.err_code; if (ns > 0) { rc = xt_side_init(); if (rc) return rc; } }
+        if (sharded) { xbuf = (double *)scratch(S_CG_XCHG, ((size_t)ns * (e.x_block > 1 ? 16 : 1) + 2) * (e.x_block > 1 ? comm_nranks() : 1) * 8); if (!xbuf) return e.err_code; if (ns > 0) { rc = xt_side_init(); if (rc) return rc; } }
         // ---- sparse part Xs: neighbour pattern of every row + values (same kernels as the CSR path, all rows) ----
         cnt = (int *)scratch(S_X_CNT, (size_t)(Nsub + 4) * 4);
         rp = (xrp_t *)scratch(S_X_ROWPTR, (size_t)(Nsub + 4) * sizeof(xrp_t));
@@ -1230,7 +1230,8 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
     }
     hipLaunchKernelGGL(k_xt_vec_mul, dim3(nbr), dim3(256), 0, st, m, y, (const double *)sc);
     KCHK();
-    if (sharded) { rc = comm_bcast0_f64(y, (size_t)m); if (rc) return rc; }        // the solution every later phase starts from: rank 0's bits
+    // the solution every later phase starts from: rank 0's bits (the block-CG adds the ranks' slots in rank order on every rank: same bits already)
+    if (sharded && !solved) { rc = comm_bcast0_f64(y, (size_t)m); if (rc) return rc; }
     HIPCHK(hipMemcpyAsync(&X.t_upper, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     e.x_iter_hint = h.iters;

@@ -327,20 +327,29 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_neigh(int m, const xrp_t *__restr
         }
         return;
     }
+    // atom rows (<= nn + 3 entries): the 16 lanes of a row first fetch its entries, one or two per lane, and fold the column's scaling into the
+    // value; every entry is then handed round the group (shuffles) and all 16 panel reads of a batch are issued together -- three dependent
+    // memory rounds per row instead of two per four entries (26 -> 12 us per sweep at 85 k sites)
     const int row = 2 + ((int)blockIdx.x - 2 * XB_DSPLIT) * 16 + g;
-    if (row >= m) return;
-    const xrp_t p0 = rp[row], p1 = rp[row + 1];
+    const bool ok = row < m;
+    const xrp_t p0 = ok ? rp[row] : 0, p1 = ok ? rp[row + 1] : 0;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    xrp_t p = p0;
-    for (; p + 3 < p1; p += 4) {
-        const int c0 = ci[p], c1 = ci[p + 1], c2 = ci[p + 2], c3 = ci[p + 3];
-        const double a0 = val[p], a1 = val[p + 1], a2 = val[p + 2], a3 = val[p + 3];
-        s0 += a0 * (sc[c0] * P[(size_t)c0 * XB_SP + v]); s1 += a1 * (sc[c1] * P[(size_t)c1 * XB_SP + v]);
-        s2 += a2 * (sc[c2] * P[(size_t)c2 * XB_SP + v]); s3 += a3 * (sc[c3] * P[(size_t)c3 * XB_SP + v]);
+    for (xrp_t base = p0; base < p1; base += 16) {
+        const xrp_t pe = base + v;
+        const int cm = pe < p1 ? ci[pe] : -1;
+        const double wm = cm >= 0 ? val[pe] * sc[cm] : 0.0;
+        double x[16]; double w[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int cu = __shfl(cm, u, 16);
+            w[u] = __shfl(wm, u, 16);
+            x[u] = cu >= 0 ? P[(size_t)cu * XB_SP + v] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) { s0 += w[u] * x[u]; s1 += w[u + 1] * x[u + 1]; s2 += w[u + 2] * x[u + 2]; s3 += w[u + 3] * x[u + 3]; }
     }
-    for (; p < p1; ++p) { const int c0 = ci[p]; s0 += val[p] * (sc[c0] * P[(size_t)c0 * XB_SP + v]); }
     const double s = (s0 + s1) + (s2 + s3);
-    T[(size_t)row * XB_SP + v] = nsrank[row] < 0 ? sc[row] * s : s;
+    if (ok) T[(size_t)row * XB_SP + v] = nsrank[row] < 0 ? sc[row] * s : s;
 }
 
 // ---- row kernel: partial sums -> S rows of T, then the partial Gram matrices of this workgroup's rows ------------------------------------
@@ -360,6 +369,19 @@ __device__ __forceinline__ double xtb_list_sum(const double *__restrict__ p, siz
         for (int u = 0; u < 16; u += 4) { a0 += x[u]; a1 += x[u + 1]; a2 += x[u + 2]; a3 += x[u + 3]; }
     }
     return (a0 + a1) + (a2 + a3);
+}
+// two lists of the same shape (the thread's rows r4 and r4 + 16, `off` doubles apart): the loads of both are in flight together
+__device__ __forceinline__ void xtb_list_sum2(const double *__restrict__ p, size_t stride, size_t off, int first, int n, double &sa, double &sb)
+{
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+    for (int c = first; c < n; c += 16) {
+        double x[16], y[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int cu = c + u; const bool ok = cu < n; x[u] = ok ? p[(size_t)cu * stride] : 0.0; y[u] = ok ? p[(size_t)cu * stride + off] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 16; u += 4) { a0 += x[u]; a1 += x[u + 1]; a2 += x[u + 2]; a3 += x[u + 3]; b0 += y[u]; b1 += y[u + 1]; b2 += y[u + 2]; b3 += y[u + 3]; }
+    }
+    sa = (a0 + a1) + (a2 + a3); sb = (b0 + b1) + (b2 + b3);
 }
 // ---- sharded solve: this rank's tile sums of every S row -> the exchange buffer xbuf[ns][so]; behind them the control words: rank 0's stop
 // decision and any rank's abort word.  [w_lo, w_hi): windows that can hold this rank's partial sums (every other cell of its arrays is zero)
@@ -381,8 +403,10 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_fold_local(int ns, int nK, int nW
             const double *rpp = rowpartB + ((size_t)k * nW * XT_R + r4) * so + v;
             const double *cpp = colpartB + ((size_t)cbase * XT_C + (XT_R * (k % (XT_C / XT_R)) + r4)) * so + v;
             const size_t rs = (size_t)XT_R * so, cs = (size_t)XT_C * so;
-            tA = xtb_list_sum(cpp, cs, 0, nc, 1) + xtb_list_sum(rpp, rs, wr.x, wr.y, 1);
-            tB = xtb_list_sum(cpp + (size_t)16 * so, cs, 0, nc, 1) + xtb_list_sum(rpp + (size_t)16 * so, rs, wr.x, wr.y, 1);
+            double cA, cB, rA_, rB_;
+            xtb_list_sum2(cpp, cs, (size_t)16 * so, 0, nc, cA, cB);
+            xtb_list_sum2(rpp, rs, (size_t)16 * so, wr.x, wr.y, rA_, rB_);
+            tA = cA + rA_; tB = cB + rB_;
             const int sA = XT_R * k + r4, sB = sA + 16;
             if (sA < ns) xbuf[(size_t)sA * so + v] = tA;
             if (sB < ns) xbuf[(size_t)sB * so + v] = tB;
@@ -396,23 +420,30 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_fold_local(int ns, int nK, int nW
 __global__ void k_xtb_abort_word(XCtrl *ctrl, double *xbuf, size_t slot) { ctrl->abort_local = 1; xbuf[slot] = 1.0; }
 __global__ void k_xtb_set_sharded(XCtrl *ctrl) { ctrl->sharded = 1; }
 
-// SH: sharded solve -- the tile sums of the S rows come all-reduced in xbuf[ns][so]; xbuf[ns so] carries rank 0's stop decision and
-// xbuf[ns so + 1] the abort word, which every rank turns into `done` here, in the same iteration (see k_xt_rows_apply)
+// SH: sharded solve -- xbuf holds, after the all-gather, one slot of ns so + 2 doubles per rank: that rank's tile sums of the S rows, its stop
+// decision and its abort word.  Every rank adds the slots IN RANK ORDER: the same bits everywhere by construction (no transport decides the
+// grouping of the additions, nothing has to be re-published from rank 0), and turns rank 0's stop decision / any rank's abort word into `done`
+// here, in the same iteration.
 template <int INIT, int SH = 0>
 __global__ __launch_bounds__(XT_NT) void k_xtb_rows(int ns, int nK, int nW, int m, int s, int so, const int2 *__restrict__ wrange, const int *__restrict__ nitem_w,
                                                     const double *__restrict__ rowpartB, const double *__restrict__ colpartB,
                                                     const int *__restrict__ srow, const double *__restrict__ sS, const int *__restrict__ nsrank,
                                                     const double *__restrict__ sc, const double *__restrict__ drvpart, double *__restrict__ T,
                                                     const double *__restrict__ P, double *__restrict__ R, const double *__restrict__ b,
-                                                    double *__restrict__ gpart, XCtrl *ctrl, const double *__restrict__ xbuf, int it)
+                                                    double *__restrict__ gpart, XCtrl *ctrl, const double *__restrict__ xbuf, int it, int nr)
 {
-    __shared__ double lg[4][XB_NG][4][64];                                     // the four waves' Gram accumulators (48 KiB)
+    const size_t xslot = (size_t)ns * so + 2;
+    __shared__ double lg[4][XB_NG / 2][4][64];                                 // the four waves' Gram accumulators, three matrices at a time (24 KiB)
     __shared__ int sdone;
     if (threadIdx.x == 0) {
         sdone = ctrl->done;
-        if (SH && !sdone && (xbuf[(size_t)ns * so] != 0.0 || xbuf[(size_t)ns * so + 1] != 0.0)) {
-            sdone = 1;
-            if (blockIdx.x == 0) { ctrl->done = it + 1; if (xbuf[(size_t)ns * so + 1] != 0.0) ctrl->aborted = 1; }     // stops this iteration's step kernel too
+        if (SH && !sdone) {
+            bool ab = false;
+            for (int r = 0; r < nr; ++r) ab |= xbuf[r * xslot + (size_t)ns * so + 1] != 0.0;
+            if (xbuf[(size_t)ns * so] != 0.0 || ab) {                         // rank 0's stop decision; anybody's abort word
+                sdone = 1;
+                if (blockIdx.x == 0) { ctrl->done = it + 1; if (ab) ctrl->aborted = 1; }     // stops this iteration's step kernel too
+            }
         }
     }
     __syncthreads();
@@ -431,13 +462,20 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_rows(int ns, int nK, int nW, int 
         double tA = 0.0, tB = 0.0;
         const int sA = XT_R * k + r4, sB = sA + 16;
         if (SH) {
-            if (v < so) { tA = sA < ns ? xbuf[(size_t)sA * so + v] : 0.0; tB = sB < ns ? xbuf[(size_t)sB * so + v] : 0.0; }
+            if (v < so) {
+                for (int r = 0; r < nr; ++r) {
+                    if (sA < ns) tA += xbuf[r * xslot + (size_t)sA * so + v];
+                    if (sB < ns) tB += xbuf[r * xslot + (size_t)sB * so + v];
+                }
+            }
         } else if (v < so) {
             const double *rpp = rowpartB + ((size_t)k * nW * XT_R + r4) * so + v;
             const double *cpp = colpartB + ((size_t)cbase * XT_C + (XT_R * (k % (XT_C / XT_R)) + r4)) * so + v;
             const size_t rs = (size_t)XT_R * so, cs = (size_t)XT_C * so;
-            tA = xtb_list_sum(cpp, cs, 0, nc, 1) + xtb_list_sum(rpp, rs, wr.x, wr.y, 1);
-            tB = xtb_list_sum(cpp + (size_t)16 * so, cs, 0, nc, 1) + xtb_list_sum(rpp + (size_t)16 * so, rs, wr.x, wr.y, 1);
+            double cA, cB, rA_, rB_;
+            xtb_list_sum2(cpp, cs, (size_t)16 * so, 0, nc, cA, cB);
+            xtb_list_sum2(rpp, rs, (size_t)16 * so, wr.x, wr.y, rA_, rB_);
+            tA = cA + rA_; tB = cB + rB_;
         }
         double pA = 0.0, pB = 0.0, rA = 0.0, rB = 0.0;
         if (sA < ns) {
@@ -494,13 +532,17 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_rows(int ns, int nK, int nW, int 
     }
     // ---- one partial per workgroup: the four waves added in a fixed order; entry (register u, lane l) is (i = l / 16 + 4 u, j = l % 16) ----
 #pragma unroll
-    for (int g = 0; g < XB_NG; ++g)
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 4; ++u) lg[wv][g][u][lane] = G[g][u];
-    __syncthreads();
-    for (int e = threadIdx.x; e < XB_NG * 256; e += XT_NT) {
-        const int g = e >> 8, u = (e >> 6) & 3, l = e & 63;
-        gpart[(size_t)blockIdx.x * (XB_NG * 256) + e] = (lg[0][g][u][l] + lg[1][g][u][l]) + (lg[2][g][u][l] + lg[3][g][u][l]);
+        for (int g = 0; g < XB_NG / 2; ++g)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) lg[wv][g][u][lane] = G[h * (XB_NG / 2) + g][u];
+        __syncthreads();
+        for (int e = threadIdx.x; e < (XB_NG / 2) * 256; e += XT_NT) {
+            const int g = e >> 8, u = (e >> 6) & 3, l = e & 63;
+            gpart[(size_t)blockIdx.x * (XB_NG * 256) + h * (XB_NG / 2) * 256 + e] = (lg[0][g][u][l] + lg[1][g][u][l]) + (lg[2][g][u][l] + lg[3][g][u][l]);
+        }
     }
 }
 
@@ -797,6 +839,23 @@ __global__ void k_xtb_zero(long long n, double *__restrict__ p)
     if (i < n) p[i] = 0.0;
 }
 
+// Second stream of the block loop on large systems: the neighbour part (an L2 / Infinity-Cache gather, 0.3 ms per sweep at 9.4e5 sites) runs
+// BESIDE the tile x panel kernel (one wave per SIMD on the matrix pipe) instead of behind it.  Events from a ring: the host runs a whole
+// batch ahead.  On small systems the two cross-stream edges cost more than the overlap gains (xt.hip measured ~15 us per iteration).
+#define XB_SIDE_RING 64
+struct XbSide { hipStream_t st = nullptr; hipEvent_t a[XB_SIDE_RING], b[XB_SIDE_RING]; int device = -1; unsigned seq = 0; bool ready = false; };
+static XbSide g_xb_side;
+static int xtb_side_init()
+{
+    XbSide &S = g_xb_side; const int dev = eng().device;
+    if (S.ready && S.device == dev) return 0;
+    if (S.ready) { (void)hipStreamDestroy(S.st); for (int i = 0; i < XB_SIDE_RING; ++i) { (void)hipEventDestroy(S.a[i]); (void)hipEventDestroy(S.b[i]); } S.ready = false; }
+    HIPCHK(hipStreamCreateWithFlags(&S.st, hipStreamNonBlocking));
+    for (int i = 0; i < XB_SIDE_RING; ++i) { HIPCHK(hipEventCreateWithFlags(&S.a[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&S.b[i], hipEventDisableTiming)); }
+    S.device = dev; S.seq = 0; S.ready = true;
+    return 0;
+}
+
 // test aid: make this rank fail once on the host side of block-CG iteration `iteration` of a sharded solve (dkmc_debug_inject_fault(3, it))
 int g_xtb_fault_iter = -1;
 
@@ -809,7 +868,7 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
     const int m = A.m, s = A.s, so = 4 * ((s + 3) / 4);                       // vector groups of four: the matrix instruction's width
     const size_t pan = (size_t)m * XB_SP;
     const long long ncell = (long long)A.nK * A.nW;
-    const int ng = std::max(128, std::min(A.nK, 1024));                                     // row-kernel workgroups = partial Gram matrices
+    const int ng = std::max(128, std::min(A.nK, 4096));                                     // row-kernel workgroups = partial Gram matrices (one row block each up to 1.3e5 S rows)
     double *panels = (double *)scratch(S_XTB_PANELS, (pan * 3 + m + 16) * 8);
     double *QS = (double *)scratch(S_XTB_QS, (size_t)A.ns_pad * XB_SP * 8);
     double *rowpartB = (double *)scratch(S_XTB_ROWPART, (size_t)(ncell + 1) * XT_R * so * 8);
@@ -823,13 +882,15 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
     HIPCHK(hipMemsetAsync(rowpartB, 0, (size_t)(ncell + 1) * XT_R * so * 8, st));
     HIPCHK(hipMemsetAsync(colpartB, 0, (size_t)(A.nrecords + 1) * XT_C * so * 8, st));
     HIPCHK(hipMemsetAsync(A.ctrl, 0, sizeof(XCtrl), st));
-    // sharded solve (comm.hip): this rank streams its share of the tiles; the tile sums of the S rows are completed by ONE all-reduce of
-    // ns x so doubles (+ two control words) per sweep -- a sixteenth of the exchanges of the single-vector loop at 16 times the payload
+    // sharded solve (comm.hip): this rank streams its share of the tiles; the tile sums of the S rows are completed by ONE all-gather of
+    // ns x so doubles (+ two control words) per rank and sweep, added in rank order by every rank (k_xtb_rows): a sixteenth of the
+    // exchanges of the single-vector loop, and bit-identical results on every rank by construction
     const bool sharded = A.sharded;
+    const int nr = sharded ? comm_nranks() : 1, me = sharded ? comm_rank() : 0;
     double *xbuf = nullptr;
     const size_t xcount = (size_t)A.ns * so + 2;
     if (sharded) {
-        xbuf = (double *)scratch(S_CG_XCHG, xcount * 8);
+        xbuf = (double *)scratch(S_CG_XCHG, xcount * nr * 8);
         if (!xbuf) return e.err_code;
         hipLaunchKernelGGL(k_xtb_set_sharded, dim3(1), dim3(1), 0, st, A.ctrl);
     }
@@ -842,7 +903,19 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
     static hipEvent_t evs[4 * 8]; static bool evs_ready = false;
     if (prof && !evs_ready) { for (auto &ev : evs) HIPCHK(hipEventCreate(&ev)); evs_ready = true; }
     double prof_long_ms = 0.0, prof_short_ms = 0.0; int prof_long_n = 0, prof_short_n = 0;
+    // neighbour part beside the tile kernel (see XbSide): only in a sharded solve, where a rank's tile pass is 1 / N of the sweep and the
+    // (replicated) neighbour part would otherwise be a serial 0.3 ms behind it.  On ONE GPU the overlap was measured and does not pay: the two
+    // kernels share the memory system, the tile pass slows by what the neighbour part takes (9.4e5 sites: 3.95 + 0 against 3.65 + 0.32 ms).
+    const bool side = sharded && m > 20000 && ntb > 0 && xtb_side_init() == 0;
     auto product = [&](hipEvent_t e0, hipEvent_t e1) {
+        int sl = 0;
+        if (side) {
+            XbSide &S = g_xb_side; sl = (int)(S.seq++ % XB_SIDE_RING);
+            (void)hipEventRecord(S.a[sl], st);                                 // P of the previous step (and the stop word) are final
+            (void)hipStreamWaitEvent(S.st, S.a[sl], 0);
+            hipLaunchKernelGGL(k_xtb_neigh, dim3(nnb), dim3(XT_NT), 0, S.st, m, A.rp, A.ci, A.val, (const double *)P, A.sc, A.nsrank, (const XCtrl *)A.ctrl, T, drvpart);
+            (void)hipEventRecord(S.b[sl], S.st);
+        }
         if (ntb > 0) {
 #define XB_APPLY(NTL_, NG_) hipExtLaunchKernelGGL((k_xtb_apply<NTL_, NG_>), dim3(ntb), dim3(XT_NT), 0, st, e0, e1, 0, A.item_n, A.items, A.tiles, A.sub_base, A.tval, \
                                                   (const double *)QS, A.nW, rowpartB, colpartB, (const XCtrl *)A.ctrl)
@@ -850,21 +923,22 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
             else { if (so == 4) XB_APPLY(0, 1); else if (so == 8) XB_APPLY(0, 2); else if (so == 12) XB_APPLY(0, 3); else XB_APPLY(0, 4); }
 #undef XB_APPLY
         }
-        hipLaunchKernelGGL(k_xtb_neigh, dim3(nnb), dim3(XT_NT), 0, st, m, A.rp, A.ci, A.val, (const double *)P, A.sc, A.nsrank, (const XCtrl *)A.ctrl, T, drvpart);
+        if (side) (void)hipStreamWaitEvent(st, g_xb_side.b[sl], 0);           // the sparse sums are in T before the row kernel reads them
+        else hipLaunchKernelGGL(k_xtb_neigh, dim3(nnb), dim3(XT_NT), 0, st, m, A.rp, A.ci, A.val, (const double *)P, A.sc, A.nsrank, (const XCtrl *)A.ctrl, T, drvpart);
     };
 #define XB_ROWS_ARGS(IT_) A.ns, A.nK, A.nW, m, s, so, A.wrange, A.nitem_w, (const double *)rowpartB, (const double *)colpartB, A.srow, A.sS, A.nsrank, A.sc, \
-                     (const double *)drvpart, T, (const double *)P, R, A.b, gpart, A.ctrl, (const double *)xbuf, IT_
+                     (const double *)drvpart, T, (const double *)P, R, A.b, gpart, A.ctrl, (const double *)xbuf, IT_, nr
     // S rows of T + partial Gram matrices; a sharded solve exchanges the tile sums first.  A host-side failure of this rank between two
     // collectives must not leave the peers in the all-reduce: it still joins, with the abort word set, and every rank leaves together.
     auto rows = [&](bool init, int itn, hipEvent_t e2, hipEvent_t e3) -> int {
         if (sharded) {
             hipLaunchKernelGGL(k_xtb_fold_local, dim3(std::max(A.nK, 1)), dim3(XT_NT), 0, st, A.ns, A.nK, A.nW, so, A.wrange, A.nitem_w, (const double *)rowpartB,
-                               (const double *)colpartB, xbuf, (const XCtrl *)A.ctrl, comm_rank() == 0 ? 1 : 0, A.w_lo, A.w_hi);
+                               (const double *)colpartB, xbuf + me * xcount, (const XCtrl *)A.ctrl, 1, A.w_lo, A.w_hi);
             if (hipGetLastError() != hipSuccess || local_fail) {
                 if (!local_fail) local_fail = dkmc_fail(92, "block-CG: launch failed between two collectives", __FILE__, __LINE__);
-                hipLaunchKernelGGL(k_xtb_abort_word, dim3(1), dim3(1), 0, st, A.ctrl, xbuf, (size_t)A.ns * so + 1);
+                hipLaunchKernelGGL(k_xtb_abort_word, dim3(1), dim3(1), 0, st, A.ctrl, xbuf + me * xcount, (size_t)A.ns * so + 1);
             }
-            if (int rcx = comm_allreduce_sum_f64(xbuf, xcount)) return rcx;
+            if (int rcx = comm_allgather_f64(xbuf, xcount)) return rcx;
             if (init) hipLaunchKernelGGL((k_xtb_rows<1, 1>), dim3(ng), dim3(XT_NT), 0, st, XB_ROWS_ARGS(itn));
             else hipExtLaunchKernelGGL((k_xtb_rows<0, 1>), dim3(ng), dim3(XT_NT), 0, st, e2, e3, 0, XB_ROWS_ARGS(itn));
         } else {
@@ -963,7 +1037,7 @@ extern "C" int dkmc_xtb_check_product(int width, double *max_abs_diff, double *m
     double *QS = (double *)scratch(S_XTB_QS, (size_t)X.ns_pad * XB_SP * 8);
     double *rowpartB = (double *)scratch(S_XTB_ROWPART, (size_t)(ncell + 1) * XT_R * so * 8);
     double *colpartB = (double *)scratch(S_XTB_COLPART, (size_t)(nrec + 1) * XT_C * so * 8);
-    double *gpart = (double *)scratch(S_XTB_GRAM, (size_t)1024 * XB_NG * 256 * 8);
+    double *gpart = (double *)scratch(S_XTB_GRAM, (size_t)4096 * XB_NG * 256 * 8);
     double *small = (double *)scratch(S_XTB_SMALL, (size_t)(4 * 256 + 2 * XB_DSPLIT * XB_SP + XB_NG * 256) * 8);
     double *tmp = (double *)scratch(S_XT_T_MISC, (size_t)4 * X.ns_pad * 8);
     XCtrl *ctrl = (XCtrl *)scratch(S_MISC2, 256);
@@ -986,7 +1060,7 @@ extern "C" int dkmc_xtb_check_product(int width, double *max_abs_diff, double *m
 #undef XB_APPLY
     hipLaunchKernelGGL((k_xtb_rows<1, 0>), dim3(ng), dim3(XT_NT), 0, st, ns, X.nK, X.nW, m, s, so, (const int2 *)g_xb.wrange, (const int *)g_xb.nitem_w, (const double *)rowpartB,
                        (const double *)colpartB, (const int *)g_xb.srow, (const double *)sS, (const int *)g_xb.nsrank, (const double *)sc, (const double *)drvpart, T,
-                       (const double *)P, R, (const double *)rhs, gpart, ctrl, (const double *)nullptr, -1);
+                       (const double *)P, R, (const double *)rhs, gpart, ctrl, (const double *)nullptr, -1, 1);
     KCHK();
     const int gb = (ns + 255) / 256;
     for (int v = 0; v < so; ++v) {

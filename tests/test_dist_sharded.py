@@ -110,7 +110,7 @@ def test_two_ranks_lockstep_bit_identical():
     tot = gt0[3]["xt_subblocks"]
     assert tot == gt1[3]["xt_subblocks"] > 0 and gt0[3]["xt_local_subblocks"] + gt1[3]["xt_local_subblocks"] == tot
     assert abs(gt0[3]["xt_local_subblocks"] - gt1[3]["xt_local_subblocks"]) <= 8 * 16          # balanced up to one work item
-    # per all-reduce of the block-CG (default width 16): |S| x 16 tile sums + the stop decision + the abort word
+    # per rank and all-gather of the block-CG (default width 16): |S| x 16 tile sums + the stop decision + the abort word
     # (at the 1e-10 of this test the s x s systems can lose definiteness in the last sweeps -- the second step here does: the solve then finishes in the
     # single-vector loop, |S| + 2 doubles per exchange, on every rank alike: they hold the same Gram matrices)
     assert gt0[3]["xb_width"] == 16 and gt0[3]["xb_fallback"] == gt1[3]["xb_fallback"]

@@ -120,7 +120,7 @@ __global__ void k_xt_wrange(int nK, int nW, const unsigned *__restrict__ cmask, 
 // (measured at a 1/8 share of the 9.4e5-site stack: 426 us per launch untapered against 357 us at the full-size rate).
 #define XT_MAXRANKS 64
 #define XT_TAPER 2048
-struct XSplit { int n; int tb[XT_MAXRANKS + 1]; int item_lo[XT_MAXRANKS + 1]; int max_items_per_strip; int nitems;
+struct XSplit { int n; int taper; int tb[XT_MAXRANKS + 1]; int item_lo[XT_MAXRANKS + 1]; int max_items_per_strip; int nitems;
                 int soff[XT_MAXRANKS + 1], w_first[XT_MAXRANKS + 1], w_last[XT_MAXRANKS + 1]; };   // per share boundary r: sub-block offset and window of tile tb[r]; window of tile tb[r] - 1
 __global__ void k_xt_split(int ntiles, long long nsub_total, const XTile *__restrict__ tiles, int n, XSplit *sp)
 {
@@ -135,14 +135,15 @@ __global__ void k_xt_split(int ntiles, long long nsub_total, const XTile *__rest
         t = lo;
     }
     sp->tb[r] = t;
-    if (r == 0) { sp->n = n; sp->max_items_per_strip = 0; }
+    // (runs shrink towards the end of a share only where a share is long enough for that to matter: small systems keep their run length)
+    if (r == 0) { sp->n = n; sp->max_items_per_strip = 0; sp->taper = (ntiles / n >= 8 * XT_TAPER) ? XT_TAPER : 0; }
 }
 __device__ __forceinline__ int xt_run_len(int t, int t1, int kc, const XSplit *sp)
 {
     int r = 0;
     while (r + 1 < sp->n && t >= sp->tb[r + 1]) ++r;
     const int end = sp->tb[r + 1], d = end - 1 - t;
-    const int sh = d / XT_TAPER;
+    const int sh = sp->taper ? d / sp->taper : 5;
     int len = sh >= 5 ? kc : min(kc, 1 << sh);
     return max(1, min(len, min(end, t1) - t));
 }
@@ -1022,6 +1023,9 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         // tiles per work item: ~4 k items per GPU.  Measured at 234 975 sites (19 372 tiles): 2 / 4 / 8 / 16 tiles per item -> 198 / 188 / 206 /
         // 222 us per launch (more items: ~2 us of start-up chain per wave round; fewer: the last waves stream alone, latency-bound)
         X.kc = std::max(1, std::min(XT_MAXKC, ntiles / nr / 4096));
+        // the block-CG's tile kernel runs ONE workgroup of four waves per CU: a small system (85 k sites: 1 868 tiles) is one wave round of
+        // two-tile runs (234 workgroups) instead of 1.9 rounds of single tiles (36 -> 2x us per sweep)
+        if (e.x_block > 1 && ntiles <= 2048 * nr) X.kc = std::max(1, std::min(XT_MAXKC, (ntiles + 1024 * nr - 1) / (1024 * nr)));
         tiles = (XTile *)scratch(S_XT_TILES, (size_t)(ntiles + 1) * sizeof(XTile));
         wrange = (int2 *)scratch(S_XT_WRANGE, (size_t)(nK + 4) * sizeof(int2));
         if (!tiles || !wrange) return e.err_code;

@@ -157,6 +157,28 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
                 Yr[0][g_] = XB_MFMA4(R.a0[h_].y, R.bc[h_][g_].y, Yr[0][g_]); Yr[1][g_] = XB_MFMA4(R.a1[h_].y, R.bc[h_][g_].y, Yr[1][g_]); \
             } else { Yr[0][g_] += R.a0[h_].x + R.bc[h_][g_].x; Yr[1][g_] += R.a1[h_].y + R.bc[h_][g_].y; }                       \
         }
+    // variant 3 (measurement): stages of ONE k-pair (16 matrix instructions at s = 16) instead of two: half the staging registers
+    struct RowOps1 { dbl2 a0, a1, bc[NG]; };
+#define XB_RD1(R, q, bufi, kk_)                                                                                                \
+    {                                                                                                                           \
+        const double *img_ = tsw + (bufi) * XT_SUB;                                                                             \
+        const int sw_ = (8 * (kk_) + 2 * rr) ^ (cc << 1);                                                                       \
+        R.a0 = *reinterpret_cast<const dbl2 *>(img_ + roff + sw_);                                                              \
+        R.a1 = *reinterpret_cast<const dbl2 *>(img_ + roff + 512 + sw_);                                                        \
+        _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_) R.bc[g_] = *reinterpret_cast<const dbl2 *>(qc + qoff[g_] + (16 * (q) + 4 * (kk_)) * 32); \
+    }
+#define XB_ROW1(R)                                                                                                             \
+    _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_) {                                                                         \
+        Yr[0][g_] = XB_MFMA4(R.a0.x, R.bc[g_].x, Yr[0][g_]); Yr[1][g_] = XB_MFMA4(R.a1.x, R.bc[g_].x, Yr[1][g_]);               \
+        Yr[0][g_] = XB_MFMA4(R.a0.y, R.bc[g_].y, Yr[0][g_]); Yr[1][g_] = XB_MFMA4(R.a1.y, R.bc[g_].y, Yr[1][g_]);               \
+    }
+#define XB_COLQ(vv, q, j0)                                                                                                     \
+    _Pragma("unroll") for (int j_ = (j0); j_ < (j0) + 2; ++j_)                                                                  \
+        _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_) {                                                                     \
+            Yc[q][0][g_] = XB_MFMA4(vv[j_].x, br[j_][g_], Yc[q][0][g_]);                                                        \
+            Yc[q][1][g_] = XB_MFMA4(vv[j_].y, br[j_][g_], Yc[q][1][g_]);                                                        \
+        }
+#define XB_SB() __builtin_amdgcn_sched_barrier(0);
 #define XB_COL(vv, q, bufi)                                                                                                    \
     {                                                                                                                           \
         double *img_ = tsw + (bufi) * XT_SUB;                                                                                   \
@@ -164,6 +186,11 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                                  \
         __builtin_amdgcn_wave_barrier();                                                                                        \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                                  \
+        if (variant == 3) {                                                                                                     \
+            XB_RD1(Ra, q, bufi, 0) XB_SB() XB_COLQ(vv, q, 0) XB_SB() XB_RD1(Rb, q, bufi, 1) XB_SB() XB_ROW1(Ra) XB_SB()         \
+            XB_COLQ(vv, q, 2) XB_SB() XB_RD1(Ra, q, bufi, 2) XB_SB() XB_ROW1(Rb) XB_SB() XB_COLQ(vv, q, 4) XB_SB()              \
+            XB_RD1(Rb, q, bufi, 3) XB_SB() XB_ROW1(Ra) XB_SB() XB_COLQ(vv, q, 6) XB_SB()                                        \
+        } else {                                                                                                                \
         XB_RDROW(R0, q, bufi, 0)                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                                      \
         XB_COLH(vv, q, 0)                                                                                                       \
@@ -174,11 +201,12 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
         __builtin_amdgcn_sched_barrier(0);                                                                                      \
         XB_COLH(vv, q, 4)                                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        }                                                                                                                       \
     }
 #define XB_ROW(q, bufi)                                                                                                        \
     {                                                                                                                           \
-        XB_ROWH(R1)                                                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                                      \
+        if (variant == 3) { XB_ROW1(Rb) XB_SB() }                                                                               \
+        else { XB_ROWH(R1) __builtin_amdgcn_sched_barrier(0); }                                                                 \
     }
 #define XB_SUBBLOCK(vv, q, bufi) XB_COL(vv, q, bufi) XB_ROW(q, bufi)
     // The stream is pipelined ACROSS tiles: the first two sub-blocks of the next tile of the run (contiguous in the store) and its panel
@@ -187,6 +215,7 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
     XTile td; td.k = it.k0; td.w = it.w; td.mask = it.mask0; td.soff = it.soff0;
     double br[8][NG];
     RowOps R0, R1;
+    RowOps1 Ra, Rb;
     if (it.t0 < it.t1) XB_LDBR(td.k)
     // row sums of a tile: D[i][j] of block n of Yr[mb][g]: row 16 mb + 4 n + i (i = rr, n = blk), vector 4 g + jv
 #define XB_ROWSUMS()                                                                                                           \
@@ -265,6 +294,10 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
 #undef XB_LDBR
 #undef XB_COL
 #undef XB_ROW
+#undef XB_RD1
+#undef XB_ROW1
+#undef XB_COLQ
+#undef XB_SB
 #undef XB_RDROW
 #undef XB_COLH
 #undef XB_ROWH
@@ -1103,7 +1136,7 @@ extern "C" int dkmc_xtb_time_apply(int width, int variant, int reps, double *us)
         if (so == 4) XB_APPLY(1, 0);
         else if (so == 8) { if (variant == 1) XB_APPLY(2, 1); else if (variant == 2) XB_APPLY(2, 2); else XB_APPLY(2, 0); }
         else if (so == 12) XB_APPLY(3, 0);
-        else { if (variant == 1) XB_APPLY(4, 1); else if (variant == 2) XB_APPLY(4, 2); else XB_APPLY(4, 0); }
+        else { if (variant == 1) XB_APPLY(4, 1); else if (variant == 2) XB_APPLY(4, 2); else if (variant == 3) XB_APPLY(4, 3); else XB_APPLY(4, 0); }
 #undef XB_APPLY
     }
     HIPCHK(hipEventRecord(e1, st));

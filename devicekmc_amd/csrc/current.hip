@@ -16,7 +16,7 @@
 
 // tiled X (xt.hip)
 int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEntry *S, const int *aneigh, const int *ancnt, const int *aflag,
-                          const int *srank, const int *atom_site, const TCacheView &TC, double *rhs, double *y, int *iters_out, double *rr_out);
+                          const int *srank, const int *atom_site, double *rhs, double *y, int *iters_out, double *rr_out);
 int xt_power(dkmc_gpubuf *buf, const XParams &P, const int *aflag, const int *atom_site, const double *m, double Vd, double alpha);
 const xrp_t *xt_xs_rp(); const int *xt_xs_col(); const double *xt_xs_val(); bool xt_valid();
 int xt_export_csr(int *rows_out, long long *nnz_out, int *h_rp, int *h_col, double *h_data);
@@ -49,11 +49,12 @@ __global__ void k_tc_mtables(int Na, const int *__restrict__ f, const int *__res
 }
 // every vacancy of S gets a cache row; rows that are new (or whose CB no longer matches) are queued for filling.
 // ctr: [0] rows in use, [1] overflow flag, [2] rows queued
+// [k_lo, k_hi): S ranks whose vacancies get a row (everything for the main part; this rank's column windows for part A of a sharded solve)
 __global__ void k_tc_assign(int ns, const SEntry *__restrict__ S, const int *__restrict__ atom_site, int cap,
-                            int *slot_of_site, double *slot_cb, int *ctr, int2 *queue)
+                            int *slot_of_site, double *slot_cb, int *ctr, int2 *queue, int k_lo, int k_hi)
 {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= ns) return;
+    if (k >= ns || k < k_lo || k >= k_hi) return;
     const SEntry e = S[k];
     if (!(e.flag & AF_V)) return;
     const int site = atom_site[e.idx];
@@ -67,7 +68,8 @@ __global__ void k_tc_assign(int ns, const SEntry *__restrict__ S, const int *__r
     if (fill) { slot_cb[slot] = e.cb; const int q = atomicAdd(&ctr[2], 1); queue[q] = make_int2(slot, e.idx); }
 }
 // one thread per (queued row, metal): the same integral the direct path evaluates
-__global__ __launch_bounds__(256) void k_tc_fill(XParams P, int nq, const int2 *__restrict__ queue, int nM, const int *__restrict__ metal_atom,
+// columns col_lo ... col_lo + nM - 1 of the cache (nM = the part's column count)
+__global__ __launch_bounds__(256) void k_tc_fill(XParams P, int nq, const int2 *__restrict__ queue, int nM, int col_lo, const int *__restrict__ metal_atom,
                                                  const double *__restrict__ ax, const double *__restrict__ ay, const double *__restrict__ az,
                                                  const double *__restrict__ acb, double *__restrict__ vals)
 {
@@ -75,11 +77,31 @@ __global__ __launch_bounds__(256) void k_tc_fill(XParams P, int nq, const int2 *
     const int qi = blockIdx.y;
     if (r >= nM || qi >= nq) return;
     const int2 q = queue[qi];
-    const int a = q.y, b = metal_atom[r];
+    const int a = q.y, b = metal_atom[col_lo + r];
     const double prefac = -(sqrt(2 * P.m_e) / DKMC_HBAR) * (2.0 / 3.0);
     const double dA = site_dist(ax[a], ay[a], az[a], ax[b], ay[b], az[b], P.laty, P.latz, P.pbc);
     const double drop = fabs(acb[a] - acb[b]);
     vals[(size_t)q.x * nM + r] = (drop > P.tol) ? wkb_T(1, 1e-10 * dA, drop, prefac, P.V0) : 0.0;
+}
+// sharded solve: where S splits into left-contact metals | vacancies | right-contact metals, and which right-contact columns sit in this
+// rank's windows.  out[0] = atom index of the first vacancy of S (Na if none), out[1] / out[2] = smallest / largest + 1 metal column whose S
+// rank lies in [c_lo, c_hi) among the columns at or beyond nL (the caller passes nL from a first launch with c range empty).
+__global__ void k_tc_split(int ns, const SEntry *__restrict__ S, const int *__restrict__ mrank_atom, int nL, int c_lo, int c_hi, int *out)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns) return;
+    const SEntry e = S[k];
+    if (e.flag & AF_V) atomicMin(&out[0], e.idx);
+    const int mr = mrank_atom[e.idx];
+    if (mr >= nL && k >= c_lo && k < c_hi) { atomicMin(&out[1], mr); atomicMax(&out[2], mr + 1); }
+}
+// per step: a right-contact column of this rank's windows that the part does not hold -> flags[0] (the part is re-sized)
+__global__ void k_tc_check_cols(int ns, const SEntry *__restrict__ S, const int *__restrict__ mrank_atom, int nL, int c_lo, int c_hi, int col_lo, int ncols, int *flags)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ns || k < c_lo || k >= c_hi) return;
+    const int mr = mrank_atom[S[k].idx];
+    if (mr >= nL && (mr < col_lo || mr >= col_lo + ncols)) flags[0] = 1;
 }
 __global__ void k_fill_i32(int *p, int n, int v) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = v; }
 
@@ -88,6 +110,11 @@ struct TCacheState {
     int *slot_of_site = nullptr, *mrank_atom = nullptr, *metal_atom = nullptr, *ctr = nullptr;
     double *metal_cb = nullptr, *slot_cb = nullptr, *vals = nullptr;
     int2 *queue = nullptr;
+    int col_lo = 0, ncols = 0;          // columns of the main part (one GPU / CSR X: all nM)
+    // part A of a sharded solve on the tiled X (TCacheView): the nL left-contact columns for the vacancies of this rank's windows
+    int sharded = 0, nL = 0, capA = 0;
+    int *slotA_of_site = nullptr, *ctrA = nullptr; double *slotA_cb = nullptr, *valsA = nullptr; int2 *queueA = nullptr;
+    size_t bytes() const { return ((size_t)cap * ncols + (size_t)capA * nL) * 8; }
 };
 // Solver state that outlives a call -- the coefficient cache and the private warm-start copy -- is kept PER GPUBuffers (keyed by
 // its site_x array), so that several devices in one process (e.g. one per crossbar cell) do not share or thrash it.  Up to 8
@@ -133,13 +160,17 @@ static void xstate_select(const void *key)
 }
 static void tc_release()
 {
-    void *ptrs[] = { g_tc.slot_of_site, g_tc.mrank_atom, g_tc.metal_atom, g_tc.ctr, g_tc.metal_cb, g_tc.slot_cb, g_tc.vals, g_tc.queue };
+    void *ptrs[] = { g_tc.slot_of_site, g_tc.mrank_atom, g_tc.metal_atom, g_tc.ctr, g_tc.metal_cb, g_tc.slot_cb, g_tc.vals, g_tc.queue,
+                     g_tc.slotA_of_site, g_tc.ctrA, g_tc.slotA_cb, g_tc.valsA, g_tc.queueA };
     for (void *q : ptrs) if (q) (void)hipFree(q);
     g_tc = TCacheState();
 }
 
-// (re)build the static tables and empty the cache
-static int tc_reset(const XParams &P, int N, const int *aflag, const double *acb, int n_vac)
+// (re)build the static tables and empty the cache.  share != nullptr: a sharded solve on the tiled X -- {c_lo, c_hi} = the S ranks of this
+// rank's column windows; the cache then holds what this rank's tiles read (TCacheView), sized with a window of slack on either side so that
+// the executed events (which shift S ranks by one at a time) do not re-size it every step.
+#define TC_SLACK 256
+static int tc_reset(const XParams &P, int N, const int *aflag, const double *acb, int n_vac, int ns, const SEntry *S, const int *share)
 {
     Engine &e = eng(); hipStream_t st = e.stream;
     HIPCHK(hipStreamSynchronize(st));
@@ -155,56 +186,125 @@ static int tc_reset(const XParams &P, int N, const int *aflag, const double *acb
     HIPCHK(hipStreamSynchronize(st));
     if (nM <= 0) { g_tc.valid = 0; return 0; }
     const int n_vacancies = n_vac - nM > 64 ? n_vac - nM : 64;          // n_vac carries |S| = vacancies + inner-contact metals
-    size_t cap = (size_t)4 * n_vacancies + 256;
+    g_tc.N = N; g_tc.Na = Na; g_tc.nM = nM;
+    HIPCHK(hipMalloc((void **)&g_tc.mrank_atom, (size_t)Na * 4));
+    HIPCHK(hipMalloc((void **)&g_tc.metal_atom, (size_t)nM * 4));
+    HIPCHK(hipMalloc((void **)&g_tc.metal_cb, (size_t)nM * 8));
+    HIPCHK(hipMalloc((void **)&g_tc.ctr, 8 * sizeof(int)));
+    hipLaunchKernelGGL(k_tc_mtables, dim3(nb), dim3(256), 0, st, Na, (const int *)f, (const int *)off, acb, g_tc.mrank_atom, g_tc.metal_cb, g_tc.metal_atom);
+    // ---- which columns, which rows ----
+    int col_lo = 0, ncols = nM, nL = 0, nA = 0;
+    if (share && ns > 0) {
+        int h[3] = {Na, 0x7fffffff, 0};
+        int *d3 = g_tc.ctr + 4;
+        HIPCHK(hipMemcpyAsync(d3, h, sizeof(h), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_tc_split, dim3((ns + 255) / 256), dim3(256), 0, st, ns, S, (const int *)g_tc.mrank_atom, nM, 0, 0, d3);      // first vacancy only
+        int first_vac = Na;
+        HIPCHK(hipMemcpyAsync(&first_vac, d3, sizeof(int), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (first_vac < Na) { HIPCHK(hipMemcpy(&nL, off + first_vac, sizeof(int), hipMemcpyDeviceToHost)); } else nL = nM;      // metals in front of the first vacancy
+        const int c_lo = std::max(0, share[0] - TC_SLACK), c_hi = share[1] > 0x7fffffff - TC_SLACK ? share[1] : share[1] + TC_SLACK;
+        h[0] = Na; h[1] = 0x7fffffff; h[2] = 0;
+        HIPCHK(hipMemcpyAsync(d3, h, sizeof(h), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_tc_split, dim3((ns + 255) / 256), dim3(256), 0, st, ns, S, (const int *)g_tc.mrank_atom, nL, c_lo, c_hi, d3);
+        HIPCHK(hipMemcpyAsync(h, d3, sizeof(h), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (h[2] > h[1]) { col_lo = h[1]; ncols = h[2] - h[1]; } else { col_lo = nL; ncols = 0; }
+        // rows of part A: the vacancies of this rank's windows (+ slack), at most all of them
+        nA = std::min(n_vacancies, std::max(0, std::min(c_hi, ns) - c_lo));
+        g_tc.sharded = 1;
+    }
+    size_t cap = (size_t)4 * n_vacancies + 256, capA = nL > 0 ? (size_t)2 * nA + 256 : 0;
     // budget: a third of the device memory that is free now, between 8 and 128 GiB (1.9e6 sites need 25 GB for one row per vacancy,
-    // 3.8e6 sites 106 GB; the tiles of a rank's share come on top)
+    // 3.8e6 sites 106 GB on ONE GPU; the tiles of a rank's share come on top)
     size_t mem_free = 0, mem_total = 0;
     if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 0;
     size_t budget = std::min((size_t)128 << 30, std::max((size_t)8 << 30, mem_free / 3));
     if (e.tcache_budget >= 0) budget = (size_t)e.tcache_budget;        // dkmc_set_tcache_budget (tests: force the uncached path)
-    if (cap * nM * 8 > budget) cap = budget / ((size_t)nM * 8);
-    if (cap < (size_t)n_vacancies + 16) { g_tc.valid = 0; return 0; }         // does not fit: run uncached
-    g_tc.N = N; g_tc.Na = Na; g_tc.nM = nM; g_tc.cap = (int)cap;
+    if (capA * nL * 8 > budget / 2) { capA = 0; nL = 0; }              // part A does not fit: its pairs are integrated directly
+    const size_t left = budget - capA * nL * 8;
+    if (ncols > 0 && cap * ncols * 8 > left) cap = left / ((size_t)ncols * 8);
+    if (ncols > 0 && cap < (size_t)n_vacancies + 16) { g_tc.valid = 0; return 0; }         // does not fit: run uncached
+    if (ncols == 0) cap = 16;
+    g_tc.cap = (int)cap; g_tc.col_lo = col_lo; g_tc.ncols = ncols; g_tc.nL = nL; g_tc.capA = (int)capA;
     HIPCHK(hipMalloc((void **)&g_tc.slot_of_site, (size_t)N * 4));
-    HIPCHK(hipMalloc((void **)&g_tc.mrank_atom, (size_t)Na * 4));
-    HIPCHK(hipMalloc((void **)&g_tc.metal_atom, (size_t)nM * 4));
-    HIPCHK(hipMalloc((void **)&g_tc.metal_cb, (size_t)nM * 8));
     HIPCHK(hipMalloc((void **)&g_tc.slot_cb, cap * 8));
-    HIPCHK(hipMalloc((void **)&g_tc.vals, cap * nM * 8));
+    HIPCHK(hipMalloc((void **)&g_tc.vals, std::max<size_t>(cap * ncols, 1) * 8));
     HIPCHK(hipMalloc((void **)&g_tc.queue, cap * sizeof(int2)));
-    HIPCHK(hipMalloc((void **)&g_tc.ctr, 4 * sizeof(int)));
-    HIPCHK(hipMemsetAsync(g_tc.ctr, 0, 4 * sizeof(int), st));
+    HIPCHK(hipMemsetAsync(g_tc.ctr, 0, 8 * sizeof(int), st));
     hipLaunchKernelGGL(k_fill_i32, dim3((N + 255) / 256), dim3(256), 0, st, g_tc.slot_of_site, N, -1);
-    hipLaunchKernelGGL(k_tc_mtables, dim3(nb), dim3(256), 0, st, Na, (const int *)f, (const int *)off, acb, g_tc.mrank_atom, g_tc.metal_cb, g_tc.metal_atom);
+    if (nL > 0) {
+        HIPCHK(hipMalloc((void **)&g_tc.slotA_of_site, (size_t)N * 4));
+        HIPCHK(hipMalloc((void **)&g_tc.slotA_cb, capA * 8));
+        HIPCHK(hipMalloc((void **)&g_tc.valsA, capA * nL * 8));
+        HIPCHK(hipMalloc((void **)&g_tc.queueA, capA * sizeof(int2)));
+        HIPCHK(hipMalloc((void **)&g_tc.ctrA, 4 * sizeof(int)));
+        HIPCHK(hipMemsetAsync(g_tc.ctrA, 0, 4 * sizeof(int), st));
+        hipLaunchKernelGGL(k_fill_i32, dim3((N + 255) / 256), dim3(256), 0, st, g_tc.slotA_of_site, N, -1);
+    }
     KCHK();
     g_tc.valid = 1;
     return 0;
 }
 
 // per step: validate, assign rows to the current vacancies, fill the new rows.  Leaves g_tc.valid = 0 if the cache cannot be used.
+// share: see tc_reset (nullptr = the whole cache: one GPU, CSR X)
 static int tc_update(const XParams &P, int N, int ns, const SEntry *S, const int *aflag, const int *atom_site,
-                     const double *ax, const double *ay, const double *az, const double *acb, int n_vac_hint)
+                     const double *ax, const double *ay, const double *az, const double *acb, int n_vac_hint, const int *share = nullptr)
 {
     Engine &e = eng(); hipStream_t st = e.stream;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        if (!g_tc.valid || g_tc.N != N || g_tc.Na != P.Na) { int rc = tc_reset(P, N, aflag, acb, n_vac_hint); if (rc) return rc; if (!g_tc.valid) return 0; }
-        int h[4] = {0, 0, 0, 0};
+        if (!g_tc.valid || g_tc.N != N || g_tc.Na != P.Na || g_tc.sharded != (share ? 1 : 0)) {
+            int rc = tc_reset(P, N, aflag, acb, n_vac_hint, ns, S, share); if (rc) return rc; if (!g_tc.valid) return 0;
+        }
+        int h[4] = {0, 0, 0, 0}, hA[4] = {0, 0, 0, 0};
         int *flags = g_tc.ctr + 3;
         HIPCHK(hipMemsetAsync(g_tc.ctr + 1, 0, 3 * sizeof(int), st));
         hipLaunchKernelGGL(k_tc_validate, dim3((P.Na + 255) / 256), dim3(256), 0, st, P.Na, aflag, acb, (const int *)g_tc.mrank_atom,
                            (const double *)g_tc.metal_cb, flags);
-        hipLaunchKernelGGL(k_tc_assign, dim3((ns + 255) / 256), dim3(256), 0, st, ns, S, atom_site, g_tc.cap, g_tc.slot_of_site, g_tc.slot_cb,
-                           g_tc.ctr, g_tc.queue);
+        if (share) hipLaunchKernelGGL(k_tc_check_cols, dim3((ns + 255) / 256), dim3(256), 0, st, ns, S, (const int *)g_tc.mrank_atom, g_tc.nL, share[0], std::min(share[1], ns),
+                                      g_tc.col_lo, g_tc.ncols, flags);
+        if (g_tc.ncols > 0)
+            hipLaunchKernelGGL(k_tc_assign, dim3((ns + 255) / 256), dim3(256), 0, st, ns, S, atom_site, g_tc.cap, g_tc.slot_of_site, g_tc.slot_cb,
+                               g_tc.ctr, g_tc.queue, 0, ns);
+        if (g_tc.nL > 0) {
+            HIPCHK(hipMemsetAsync(g_tc.ctrA + 1, 0, 3 * sizeof(int), st));
+            hipLaunchKernelGGL(k_tc_assign, dim3((ns + 255) / 256), dim3(256), 0, st, ns, S, atom_site, g_tc.capA, g_tc.slotA_of_site, g_tc.slotA_cb,
+                               g_tc.ctrA, g_tc.queueA, share[0], std::min(share[1], ns));
+            HIPCHK(hipMemcpyAsync(hA, g_tc.ctrA, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+        }
         HIPCHK(hipMemcpyAsync(h, g_tc.ctr, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        if (h[3] || h[1]) { g_tc.valid = 0; continue; }               // stale tables or full: rebuild once
-        if (h[2] > 0)
-            hipLaunchKernelGGL(k_tc_fill, dim3((g_tc.nM + 255) / 256, h[2]), dim3(256), 0, st, P, h[2], (const int2 *)g_tc.queue, g_tc.nM,
+        if (h[3] || h[1] || hA[1]) { g_tc.valid = 0; continue; }      // stale tables, a window that left the part, or full: rebuild once
+        if (h[2] > 0 && g_tc.ncols > 0)
+            hipLaunchKernelGGL(k_tc_fill, dim3((g_tc.ncols + 255) / 256, h[2]), dim3(256), 0, st, P, h[2], (const int2 *)g_tc.queue, g_tc.ncols, g_tc.col_lo,
                                (const int *)g_tc.metal_atom, ax, ay, az, acb, g_tc.vals);
+        if (hA[2] > 0)
+            hipLaunchKernelGGL(k_tc_fill, dim3((g_tc.nL + 255) / 256, hA[2]), dim3(256), 0, st, P, hA[2], (const int2 *)g_tc.queueA, g_tc.nL, 0,
+                               (const int *)g_tc.metal_atom, ax, ay, az, acb, g_tc.valsA);
         KCHK();
+        e.stats.tcache_bytes = (long long)g_tc.bytes();
         return 0;
     }
     g_tc.valid = 0;
+    e.stats.tcache_bytes = 0;
+    return 0;
+}
+static void tc_view(TCacheView *TC)
+{
+    TC->enabled = g_tc.valid; TC->nM = g_tc.nM; TC->cap = g_tc.cap; TC->slot_of_site = g_tc.slot_of_site; TC->mrank_atom = g_tc.mrank_atom;
+    TC->vals = g_tc.vals; TC->col_lo = g_tc.col_lo; TC->ncols = g_tc.ncols;
+    TC->nL = g_tc.valid ? g_tc.nL : 0; TC->slotA_of_site = g_tc.slotA_of_site; TC->valsA = g_tc.valsA;
+}
+// the cache as the tiles of THIS rank read it (xt.hip calls this once its share of the tile list is known)
+int tc_prepare_tiled(const XParams &P, dkmc_gpubuf *buf, int ns, const SEntry *S, const int *aflag, const int *srank, const int *atom_site,
+                     int c_lo, int c_hi, int sharded, TCacheView *out)
+{
+    (void)srank;
+    const int share[2] = {c_lo, c_hi};
+    int rc = tc_update(P, buf->N_, ns, S, aflag, atom_site, buf->atom_x, buf->atom_y, buf->atom_z, buf->atom_CB_edge, ns, sharded ? share : nullptr);
+    if (rc) return rc;
+    tc_view(out);
     return 0;
 }
 
@@ -372,14 +472,12 @@ static int update_power_body(dkmc_gpubuf *buf, int n_src, int n_gnd, int nlc, do
     g_last_tiled = e.x_format != 0;
     if (e.x_format != 0) {
         // ---- 3-5 (tiled X, xt.hip): neighbour part as a small CSR, tunnelling block straight into symmetric tiles, solve ----
-        rc = tc_update(P, N, ns, S, aflag, atom_site, buf->atom_x, buf->atom_y, buf->atom_z, buf->atom_CB_edge, ns); if (rc) return rc;
-        TCacheView TC; TC.enabled = g_tc.valid; TC.nM = g_tc.nM; TC.cap = g_tc.cap; TC.slot_of_site = g_tc.slot_of_site;
-        TC.mrank_atom = g_tc.mrank_atom; TC.vals = g_tc.vals;
+        // (the coefficient cache is brought up to date inside, once this rank's share of the tiles is known: tc_prepare_tiled)
         hipLaunchKernelGGL(k_set_rhs, dim3((Na + 2 + 255) / 256), dim3(256), 0, st, rhs, Na + 2, loop_G, Vd);
         if (e.current_warm_start == 1) {
             if (g_warm && g_warm_n == Nsub) HIPCHK(hipMemcpyAsync(m, g_warm, (size_t)Nsub * 8, hipMemcpyDeviceToDevice, st));
         }
-        rc = xt_assemble_and_solve(buf, P, ns, S, aneigh, ancnt, aflag, srank, atom_site, TC, rhs, m, &e.stats.cg_iters_X, &e.stats.cg_rr_X);
+        rc = xt_assemble_and_solve(buf, P, ns, S, aneigh, ancnt, aflag, srank, atom_site, rhs, m, &e.stats.cg_iters_X, &e.stats.cg_rr_X);
         if (rc) return rc;
         rp = xt_xs_rp(); col = xt_xs_col(); data = xt_xs_val();
     } else {
@@ -402,8 +500,7 @@ static int update_power_body(dkmc_gpubuf *buf, int n_src, int n_gnd, int nlc, do
         if (ns > 0) hipLaunchKernelGGL((k_xpat_S<1>), dim3(ns), dim3(XS_NT), 0, st, P, ns, S, aneigh, ancnt, cnt, rp_, col_);
         // ---- 4. values ----
         rc = tc_update(P, N, ns, S, aflag, atom_site, buf->atom_x, buf->atom_y, buf->atom_z, buf->atom_CB_edge, ns); if (rc) return rc;
-        TCacheView TC; TC.enabled = g_tc.valid; TC.nM = g_tc.nM; TC.cap = g_tc.cap; TC.slot_of_site = g_tc.slot_of_site;
-        TC.mrank_atom = g_tc.mrank_atom; TC.vals = g_tc.vals;
+        TCacheView TC; tc_view(&TC);
         hipLaunchKernelGGL((k_xval<16>), dim3((Nsub + 15) / 16), dim3(256), 0, st, P, Nsub, S, 0, inS, rp_, col_, buf->atom_x, buf->atom_y, buf->atom_z,
                            aflag, buf->atom_CB_edge, data_, TC, (const int *)atom_site);
         if (ns > 0) hipLaunchKernelGGL((k_xval<64>), dim3((ns + 3) / 4), dim3(256), 0, st, P, ns, S, 1, inS, rp_, col_, buf->atom_x, buf->atom_y, buf->atom_z,

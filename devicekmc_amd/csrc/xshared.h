@@ -193,8 +193,26 @@ struct TCacheView {
     int enabled, nM, cap;
     const int *slot_of_site;      // [N]   cache row of a site, -1 if none
     const int *mrank_atom;        // [Na]  cache column of an atom, -1 if it is not an inner-contact metal
-    const double *vals;           // [cap][nM]
+    const double *vals;           // [cap][ncols]: columns col_lo ... col_lo + ncols - 1 of every cached vacancy (one GPU: all nM columns)
+    int col_lo, ncols;
+    // Sharded solve on the tiled X only (nL = 0 otherwise): a rank caches what ITS tiles read.  S is in atom order -- left-contact metals,
+    // vacancies, right-contact metals -- and a tile belongs to the rank that owns its COLUMN window, so a rank needs (a) the nL left-contact
+    // columns for the vacancies of its own windows (part A: slotA_of_site, valsA[capA][nL]) and (b) for ALL vacancies the right-contact
+    // columns of its own windows (the part above, col_lo >= nL).  Anything a tile reads outside these is integrated directly: same
+    // function, same bits (tc_lookup misses), so a window that moved since the parts were sized costs time, never correctness.
+    int nL;
+    const int *slotA_of_site;
+    const double *valsA;
 };
+__device__ __forceinline__ bool tc_lookup(const TCacheView &TC, int slot, int slotA, int mr, double &val)
+{
+    if (mr < 0) return false;
+    if (mr < TC.nL) { if (slotA < 0) return false; val = TC.valsA[(size_t)slotA * TC.nL + mr]; return true; }
+    const int c = mr - TC.col_lo;
+    if (slot < 0 || c < 0 || c >= TC.ncols) return false;
+    val = TC.vals[(size_t)slot * TC.ncols + c];
+    return true;
+}
 
 // ---- values (populate_sparse_X_gpu2 :1525-1721 + calc_diagonal_X_gpu :2053-2076) ---------------------
 __device__ __forceinline__ double pow15(double e) { return e * sqrt(e); }
@@ -245,8 +263,9 @@ __device__ __forceinline__ double x_entry(const XParams &P, int i, int c, const 
     if (!kind) return 0.0;
     if (kind == 1 && TC.enabled) {
         const int va = (fa & AF_V) ? i - 2 : b, ma = (fa & AF_V) ? b : i - 2;       // vacancy atom, metal atom
-        const int slot = TC.slot_of_site[atom_site[va]], mr = TC.mrank_atom[ma];
-        if (slot >= 0 && mr >= 0) return -TC.vals[(size_t)slot * TC.nM + mr];
+        const int site = atom_site[va];
+        double cv;
+        if (tc_lookup(TC, TC.slot_of_site[site], TC.nL ? TC.slotA_of_site[site] : -1, TC.mrank_atom[ma], cv)) return -cv;
     }
     return -wkb_T(kind, 1e-10 * dA, fabs(cba - cbb), prefac, P.V0);
 }

@@ -24,39 +24,53 @@
 // completes the rows, with the neighbour part on a second stream beside it; results are re-published from rank 0.
 #include "xtiles.h"
 #include <hip/hip_ext.h>
+int tc_prepare_tiled(const XParams &P, dkmc_gpubuf *buf, int ns, const SEntry *S, const int *aflag, const int *srank, const int *atom_site,
+                     int c_lo, int c_hi, int sharded, TCacheView *out);       // current.hip
 #include <vector>
 #include <algorithm>
 #include <stdlib.h>
 
 // value of the tunnelling entry between two members of S (0 = no entry); symmetric in its two atoms bit for bit
 __device__ __forceinline__ double xt_tvalue(const XParams &P, double prefac, const TCacheView &TC,
-                                            double x1, double y1, double z1, double cb1, int f1, int slot1, int mr1,
-                                            double x2, double y2, double z2, double cb2, int f2, int slot2, int mr2)
+                                            double x1, double y1, double z1, double cb1, int f1, int slot1, int slotA1, int mr1,
+                                            double x2, double y2, double z2, double cb2, int f2, int slot2, int slotA2, int mr2)
 {
     const double d = site_dist(x1, y1, z1, x2, y2, z2, P.laty, P.latz, P.pbc);
     if (d < P.nn_dist) return 0.0;                                   // neighbour pair: direct term, part of Xs
     const int kind = tunnel_kind<AF_MP_VAL>(f1, f2, cb1, cb2, P.tol);
     if (!kind) return 0.0;
     if (kind == 1 && TC.enabled) {
-        const int slot = (f1 & AF_V) ? slot1 : slot2, mr = (f1 & AF_V) ? mr2 : mr1;
-        if (slot >= 0 && mr >= 0) return -TC.vals[(size_t)slot * TC.nM + mr];
+        const bool v1 = f1 & AF_V;
+        double cv;
+        if (tc_lookup(TC, v1 ? slot1 : slot2, v1 ? slotA1 : slotA2, v1 ? mr2 : mr1, cv)) return -cv;
     }
     return -wkb_T(kind, 1e-10 * d, fabs(cb1 - cb2), prefac, P.V0);
 }
 
 // ---- S in solver order ---------------------------------------------------------------------------------------------------
 __global__ void k_xt_snodes(int ns, int ns_pad, const SEntry *__restrict__ S, const double *__restrict__ ax, const double *__restrict__ ay,
-                            const double *__restrict__ az, const int *__restrict__ atom_site, TCacheView TC,
-                            double *sx, double *sy, double *sz, double *scb, int *sflag, int *sslot, int *smr, int *srow)
+                            const double *__restrict__ az, double *sx, double *sy, double *sz, double *scb, int *sflag, int *srow)
 {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= ns_pad) return;
     if (s < ns) {
         const SEntry e = S[s];
         sx[s] = ax[e.idx]; sy[s] = ay[e.idx]; sz[s] = az[e.idx]; scb[s] = e.cb; sflag[s] = e.flag; srow[s] = e.idx + 2;
-        sslot[s] = (TC.enabled && (e.flag & AF_V)) ? TC.slot_of_site[atom_site[e.idx]] : -1;
-        smr[s] = TC.enabled ? TC.mrank_atom[e.idx] : -1;
-    } else { sx[s] = 0; sy[s] = 0; sz[s] = 0; scb[s] = 0; sflag[s] = 0; sslot[s] = -1; smr[s] = -1; srow[s] = -1; }
+    } else { sx[s] = 0; sy[s] = 0; sz[s] = 0; scb[s] = 0; sflag[s] = 0; srow[s] = -1; }
+}
+// rows / columns of the coefficient cache of every member of S (after the cache has been brought up to date for this rank's share)
+__global__ void k_xt_snode_slots(int ns, int ns_pad, const SEntry *__restrict__ S, const int *__restrict__ atom_site, TCacheView TC,
+                                 int *sslot, int *sslotA, int *smr)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= ns_pad) return;
+    int sl = -1, sa = -1, mr = -1;
+    if (s < ns && TC.enabled) {
+        const SEntry e = S[s];
+        if (e.flag & AF_V) { const int site = atom_site[e.idx]; sl = TC.slot_of_site[site]; if (TC.nL) sa = TC.slotA_of_site[site]; }
+        mr = TC.mrank_atom[e.idx];
+    }
+    sslot[s] = sl; sslotA[s] = sa; smr[s] = mr;
 }
 
 // ---- census: which 32 x 32 sub-blocks of the upper triangle hold an entry -----------------------------------------------------
@@ -202,12 +216,12 @@ __global__ __launch_bounds__(XT_NT) void k_xt_fill(XParams P, int ns, const XTil
                                                    double *__restrict__ tval, unsigned long long *__restrict__ nnz_upper)
 {
     __shared__ double rx[XT_R], ry[XT_R], rz[XT_R], rcb[XT_R];
-    __shared__ int rf[XT_R], rslot[XT_R], rmr[XT_R];
+    __shared__ int rf[XT_R], rslot[XT_R], rslotA[XT_R], rmr[XT_R];
     const XTile td = tiles[blockIdx.x];
     const int tid = threadIdx.x;
     if (tid < XT_R) {
         const int s = XT_R * td.k + tid;           // < ns_pad: the arrays are padded
-        rx[tid] = S.x[s]; ry[tid] = S.y[s]; rz[tid] = S.z[s]; rcb[tid] = S.cb[s]; rf[tid] = S.flag[s]; rslot[tid] = S.slot[s]; rmr[tid] = S.mr[s];
+        rx[tid] = S.x[s]; ry[tid] = S.y[s]; rz[tid] = S.z[s]; rcb[tid] = S.cb[s]; rf[tid] = S.flag[s]; rslot[tid] = S.slot[s]; rslotA[tid] = S.slotA[s]; rmr[tid] = S.mr[s];
     }
     __syncthreads();
     const int q = tid >> 5, c = tid & 31;
@@ -217,13 +231,13 @@ __global__ __launch_bounds__(XT_NT) void k_xt_fill(XParams P, int ns, const XTil
         double *dst = tval + ((size_t)(td.soff - sub_base) + sl) * XT_SUB + c;
         const int sc = XT_C * td.w + XT_SBW * q + c;
         const double cx = S.x[sc], cy = S.y[sc], cz = S.z[sc], ccb = S.cb[sc];
-        const int cf = S.flag[sc], cslot = S.slot[sc], cmr = S.mr[sc];
+        const int cf = S.flag[sc], cslot = S.slot[sc], cslotA = S.slotA[sc], cmr = S.mr[sc];
         const double prefac = -(sqrt(2 * P.m_e) / DKMC_HBAR) * (2.0 / 3.0);
         for (int r = 0; r < XT_R; ++r) {
             const int s = XT_R * td.k + r;
             double v = 0.0;
             if (sc > s && cf && rf[r])
-                v = xt_tvalue(P, prefac, TC, rx[r], ry[r], rz[r], rcb[r], rf[r], rslot[r], rmr[r], cx, cy, cz, ccb, cf, cslot, cmr);
+                v = xt_tvalue(P, prefac, TC, rx[r], ry[r], rz[r], rcb[r], rf[r], rslot[r], rslotA[r], rmr[r], cx, cy, cz, ccb, cf, cslot, cslotA, cmr);
             dst[r * XT_SBW] = v;
             cnt += v != 0.0;
         }
@@ -932,8 +946,9 @@ static int xt_side_init()
 
 // Assemble Xs + tiles and solve X m = rhs with the Jacobi-scaled CG.  aneigh/ancnt/aflag/srank/S/atom_site: current.hip steps 1-2.
 int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEntry *S, const int *aneigh, const int *ancnt, const int *aflag,
-                          const int *srank, const int *atom_site, const TCacheView &TC, double *rhs, double *y, int *iters_out, double *rr_out)
+                          const int *srank, const int *atom_site, double *rhs, double *y, int *iters_out, double *rr_out)
 {
+    TCacheView TC{};                     // brought up to date for this rank's share inside assemble() (tc_prepare_tiled, current.hip)
     Engine &e = eng(); hipStream_t st = e.stream;
     XTState &X = g_xt; X.valid = false;
     const int Na = P.Na, Nsub = Na + 1;
@@ -981,21 +996,20 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         hipLaunchKernelGGL((k_xpat_plain<1>), dim3(nbr), dim3(256), 0, st, P, (const int *)nullptr, aneigh, ancnt, cnt, (const xrp_t *)rp, col);
         hipLaunchKernelGGL((k_xval<16>), dim3((Nsub + 15) / 16), dim3(256), 0, st, P, Nsub, (const SEntry *)nullptr, 0, (const int *)nullptr, (const xrp_t *)rp,
                            (const int *)col, (const double *)buf->atom_x, (const double *)buf->atom_y, (const double *)buf->atom_z, aflag,
-                           (const double *)buf->atom_CB_edge, val, TC, atom_site, dpos);
+                           (const double *)buf->atom_CB_edge, val, TCacheView{}, atom_site, dpos);       // (neighbour entries only: no tunnelling integral)
         hipLaunchKernelGGL(k_xt_node_srank, dim3(nbr), dim3(256), 0, st, Nsub, srank, nsrank);
         KCHK();
         g_xb.rp = rp; g_xb.dpos = dpos; g_xb.ci = col; g_xb.val = val; g_xb.nsrank = nsrank;
 
         // ---- S in solver order ----
         sd = (double *)scratch(S_XT_SNODE_D, (size_t)ns_pad * 4 * 8);
-        si = (int *)scratch(S_XT_SNODE_I, (size_t)ns_pad * 4 * 4);
+        si = (int *)scratch(S_XT_SNODE_I, (size_t)ns_pad * 5 * 4);
         if (!sd || !si) return e.err_code;
         SN.x = sd; SN.y = sd + ns_pad; SN.z = sd + 2 * (size_t)ns_pad; SN.cb = sd + 3 * (size_t)ns_pad;
-        SN.flag = si; SN.slot = si + ns_pad; SN.mr = si + 2 * (size_t)ns_pad;
+        SN.flag = si; SN.slot = si + ns_pad; SN.mr = si + 2 * (size_t)ns_pad; SN.slotA = si + 4 * (size_t)ns_pad;
         srow = si + 3 * (size_t)ns_pad;
         hipLaunchKernelGGL(k_xt_snodes, dim3((ns_pad + 255) / 256), dim3(256), 0, st, ns, ns_pad, S, (const double *)buf->atom_x, (const double *)buf->atom_y,
-                           (const double *)buf->atom_z, atom_site, TC, sd, sd + ns_pad, sd + 2 * (size_t)ns_pad, sd + 3 * (size_t)ns_pad,
-                           si, si + ns_pad, si + 2 * (size_t)ns_pad, srow);
+                           (const double *)buf->atom_z, sd, sd + ns_pad, sd + 2 * (size_t)ns_pad, sd + 3 * (size_t)ns_pad, si, srow);
         g_xb.S = SN; g_xb.srow = srow;
 
         // ---- census -> tile list -> work items ----
@@ -1047,6 +1061,11 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         e.stats.comm_ranks = sharded ? comm_nranks() : 0;
         e.stats.comm_count_per_rank = sharded ? ns + 2 : 0;
         e.stats.comm_local_segments = X.item_n;
+
+        // ---- coefficient cache, brought up to date for what THIS rank's tiles read (its column windows; everything on one GPU) ----
+        rc = tc_prepare_tiled(P, buf, ns, S, aflag, srank, atom_site, sharded ? XT_C * X.w_lo : 0, sharded ? XT_C * X.w_hi : 0x7fffffff, sharded ? 1 : 0, &TC);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_xt_snode_slots, dim3((ns_pad + 255) / 256), dim3(256), 0, st, ns, ns_pad, S, atom_site, TC, si + ns_pad, si + 4 * (size_t)ns_pad, si + 2 * (size_t)ns_pad);
 
         // ---- storage + fill ----
         tval = (double *)scratch(S_XT_TVAL, (size_t)(X.sub_n + 4) * XT_SUB * 8);       // (slack: the block-CG product requests two sub-blocks beyond a full tile)

@@ -24,6 +24,7 @@ struct XCtrl { double rr[2]; int done_local, sharded; int done; int iters; int a
 struct SNodes {                      // S in rank order, padded to a multiple of XT_C (flag 0 = no entries)
     const double *x, *y, *z, *cb;
     const int *flag, *slot, *mr;     // class flags; row of the coefficient cache (vacancies) / column (metals), -1 if none
+    const int *slotA;                // row of the cache's part A (sharded solve: left-contact columns of this rank's vacancies), -1 if none
 };
 
 struct XTState {

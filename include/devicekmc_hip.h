@@ -98,6 +98,7 @@ typedef struct dkmc_stats {
     long long pair_evaluated;              /* (site, charged site) pairs inside the screening cut-off of the last pair sum (profiling on) */
     long long pair_tested;                 /* pairs whose distance was tested (all N x N_charged without the cell list; the 3 x 3 columns with it) */
     long long xt_records;                  /* records of column partial sums one matrix-vector product writes (= runs; runs / 4 on one GPU, where the four waves of a workgroup share one) */
+    long long tcache_bytes;                /* bytes of tunnelling-coefficient cache THIS rank holds (sharded solve on the tiled X: what its tiles read) */
     int xb_width, xb_fallback;             /* block-CG width of the last current solve (1 = single-vector loop); 1 if the block loop lost definiteness and the single-vector loop finished the solve */
 } dkmc_stats;
 

@@ -115,6 +115,10 @@ def test_two_ranks_lockstep_bit_identical():
     # single-vector loop, |S| + 2 doubles per exchange, on every rank alike: they hold the same Gram matrices)
     assert gt0[3]["xb_width"] == 16 and gt0[3]["xb_fallback"] == gt1[3]["xb_fallback"]
     assert gt0[3]["comm_count_per_rank"] == (16 if not gt0[3]["xb_fallback"] else 1) * gt0[3]["xt_ns"] + 2, (gt0[3]["xb_fallback"], gt0[3]["comm_count_per_rank"], gt0[1])
+    # the tunnelling-coefficient cache is sharded with the tiles: a rank holds the left-contact columns of its own vacancies and the
+    # right-contact columns of its own windows for all vacancies -- together about what one GPU holds, each well under it
+    one, b0, b1 = ref_tiles[3]["tcache_bytes"], gt0[3]["tcache_bytes"], gt1[3]["tcache_bytes"]
+    assert one > 0 and 0 < b0 < 0.8 * one and 0 < b1 < 0.8 * one and b0 + b1 < 1.5 * one, (one, b0, b1)
     nseg = got0[3]["spmv_segments"]
     assert got0[3]["comm_local_segments"] + got1[3]["comm_local_segments"] == nseg > 0      # the ranks split the segments
     assert abs(got0[3]["comm_local_segments"] - got1[3]["comm_local_segments"]) <= 64      # balanced up to one row

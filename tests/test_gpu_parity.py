@@ -885,6 +885,9 @@ def test_tiled_X_edge_cases(cell_2p5, hip, case):
         p.num_layers_contact = 100          # (nlc - 1) * n_src exceeds the atom count: the inner-contact window is empty
     out = {}
     try:
+        # two STORAGE forms of X under the same CG: the single-vector loop on both sides (the CSR form has no block loop; block against
+        # single-vector is tests/test_gpu_block_cg.py, with the tolerances two different iterate sequences need)
+        L.dkmc_set_x_block(1)
         for fmt in (0, 1):
             L.dkmc_set_x_format(fmt)
             dev = host.Device(cell_2p5, p); gb = dev.make_gpubuf("cuda:0")
@@ -901,7 +904,7 @@ def test_tiled_X_edge_cases(cell_2p5, hip, case):
             rec[1] = get(gb, "site_power").copy()
             out[fmt] = rec
     finally:
-        L.dkmc_set_x_format(1)
+        L.dkmc_set_x_format(1); L.dkmc_set_x_block(16)
     (i0, pw0, (rp0, ci0, d0), nnz0, m0), (i1, pw1, (rp1, ci1, d1), nnz1, m1) = out[0], out[1]
     if case == "empty_S":
         assert host.get_stats()["xt_ns"] == 0

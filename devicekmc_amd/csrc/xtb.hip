@@ -77,7 +77,8 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
                  const double *__restrict__ QS, int nW, double *__restrict__ rowpartB, double *__restrict__ colpartB, const XCtrl *ctrl)
 {
     // variant (measurement aid, dkmc_xtb_time_apply; 0 in every solve): 1 = no matrix instructions (stream + LDS traffic only), 2 = the
-    // tile stream is not re-read (matrix instructions + LDS traffic only); the results of 1 and 2 are meaningless
+    // tile stream is not re-read (matrix instructions + LDS traffic only), 3 = operand stages of one k-pair, 4 = no LDS traffic (the row
+    // sums replaced by as many products on the loaded registers); the results of 1, 2 and 4 are meaningless
     constexpr int so = 4 * NG;                                                 // vectors per row of the partial-sum arrays
     __shared__ __attribute__((aligned(16))) double qc[XT_C * XB_SP];          // the strip's 256 panel rows in QS order (32 KiB)
     __shared__ __attribute__((aligned(16))) double ts[4 * 2 * XT_SUB];        // per wave: two sub-block images (2 x 8 KiB)
@@ -182,11 +183,17 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
 #define XB_COL(vv, q, bufi)                                                                                                    \
     {                                                                                                                           \
         double *img_ = tsw + (bufi) * XT_SUB;                                                                                   \
-        _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) *reinterpret_cast<dbl2 *>(img_ + woff[j_]) = vv[j_];                   \
+        if (variant != 4) { _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) *reinterpret_cast<dbl2 *>(img_ + woff[j_]) = vv[j_]; } \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                                  \
         __builtin_amdgcn_wave_barrier();                                                                                        \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                                  \
-        if (variant == 3) {                                                                                                     \
+        if (variant == 4) {                                                                                                     \
+            XB_COLH(vv, q, 0) XB_COLH(vv, q, 4)                                                                                 \
+            _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_)                                                                    \
+                _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_) {                                                             \
+                    Yr[0][g_] = XB_MFMA4(vv[j_].x, br[j_][g_], Yr[0][g_]); Yr[1][g_] = XB_MFMA4(vv[j_].y, br[j_][g_], Yr[1][g_]); \
+                }                                                                                                               \
+        } else if (variant == 3) {                                                                                              \
             XB_RD1(Ra, q, bufi, 0) XB_SB() XB_COLQ(vv, q, 0) XB_SB() XB_RD1(Rb, q, bufi, 1) XB_SB() XB_ROW1(Ra) XB_SB()         \
             XB_COLQ(vv, q, 2) XB_SB() XB_RD1(Ra, q, bufi, 2) XB_SB() XB_ROW1(Rb) XB_SB() XB_COLQ(vv, q, 4) XB_SB()              \
             XB_RD1(Rb, q, bufi, 3) XB_SB() XB_ROW1(Ra) XB_SB() XB_COLQ(vv, q, 6) XB_SB()                                        \
@@ -205,7 +212,8 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
     }
 #define XB_ROW(q, bufi)                                                                                                        \
     {                                                                                                                           \
-        if (variant == 3) { XB_ROW1(Rb) XB_SB() }                                                                               \
+        if (variant == 4) { }                                                                                                   \
+        else if (variant == 3) { XB_ROW1(Rb) XB_SB() }                                                                          \
         else { XB_ROWH(R1) __builtin_amdgcn_sched_barrier(0); }                                                                 \
     }
 #define XB_SUBBLOCK(vv, q, bufi) XB_COL(vv, q, bufi) XB_ROW(q, bufi)
@@ -1136,7 +1144,7 @@ extern "C" int dkmc_xtb_time_apply(int width, int variant, int reps, double *us)
         if (so == 4) XB_APPLY(1, 0);
         else if (so == 8) { if (variant == 1) XB_APPLY(2, 1); else if (variant == 2) XB_APPLY(2, 2); else XB_APPLY(2, 0); }
         else if (so == 12) XB_APPLY(3, 0);
-        else { if (variant == 1) XB_APPLY(4, 1); else if (variant == 2) XB_APPLY(4, 2); else if (variant == 3) XB_APPLY(4, 3); else XB_APPLY(4, 0); }
+        else { if (variant == 1) XB_APPLY(4, 1); else if (variant == 2) XB_APPLY(4, 2); else if (variant == 3) XB_APPLY(4, 3); else if (variant == 4) XB_APPLY(4, 4); else XB_APPLY(4, 0); }
 #undef XB_APPLY
     }
     HIPCHK(hipEventRecord(e1, st));

@@ -18,8 +18,8 @@ sim.step(False)
 st = sim.host.get_stats()
 out = {"workload": name, "sites": int(sim.s.N), "subblocks": int(st["xt_subblocks"]), "tile_bytes": 8192 * int(st["xt_subblocks"])}
 for w in widths:
-    for variant, what in ((0, "kernel"), (1, "no_matrix_instructions"), (2, "no_tile_stream"), (3, "kernel_one_kpair_stages")):
-        if variant == 3 and w <= 12:
+    for variant, what in ((0, "kernel"), (1, "no_matrix_instructions"), (2, "no_tile_stream"), (3, "kernel_one_kpair_stages"), (4, "no_lds_traffic")):
+        if variant >= 3 and w <= 12:
             continue
         us = C.c_double(0)
         check(sim.L.dkmc_xtb_time_apply(w, variant, 5, C.byref(us)))

@@ -271,15 +271,21 @@ def rooflines(sim, local_share=1.0):
         m, nnz = sim.s.N - 2 * sim.p.num_atoms_first_layer, int(sim.gb.c.Device_nnz)
         if sim.p.cb_edge_domain == "atoms":
             pass        # (the potential system is over every site in both domains; only the CB-edge solve changes)
-        # bytes the three kernels move: 4 B per stored entry (column | class bit, no value array) + row pointers + 15 vector touches of 8 B
-        b = 4.0 * nnz + 4.0 * (m + 1) + 120.0 * m
+        # bytes the two kernels of an iteration move (the library's own count, dkmc_stats.kcg_bytes): CSR positions: 4 B per stored entry
+        # (column | class bit, no value array) + row pointers + 15 vector touches of 8 B; blocked form (systems up to 262 144 rows):
+        # 4 B per padded entry + 8 B per column of every block's LDS window + 14 vector touches
+        blocked = bool(st["kcg_blocked"])
+        b = float(st["kcg_bytes"]) if st["kcg_bytes"] > 0 else 4.0 * nnz + 4.0 * (m + 1) + 120.0 * m
         b_csr = 12.0 * nnz + 4.0 * (m + 1) + 96.0 * m
         us = pr["kcg_ms"] / pr["kcg_iters"] * 1e3
-        out["roofline_K_cg"] = {"bound": "hbm", "kernel": "one CG iteration on K (k_kc_apply + k_kc_update + k_kc_direction)", "achieved": round(b / us / 1e3, 1),
+        out["roofline_K_cg"] = {"bound": "hbm", "kernel": "one CG iteration on K (%s + k_kc_step)" % ("k_kb_apply, blocked form" if blocked else "k_kc_apply"),
+                                "achieved": round(b / us / 1e3, 1),
                                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(b / us / 1e3 / HBM_PEAK_GBS, 4), "traffic": None,
                                 "us_per_iteration": round(us, 2), "iterations_timed": pr["kcg_iters"], "algorithmic_bytes_per_iteration": b,
-                                "note": "achieved / frac count the bytes this formulation moves (4 nnz + 4 (m + 1) + 120 m); csr_equivalent_* prices the "
-                                        "same iteration at the bytes of the reference's CSR formulation (SURVEY 8d: 12 nnz + 4 (m + 1) + 96 m)",
+                                "blocked_form": blocked,
+                                "note": "achieved / frac count the bytes this formulation moves; csr_equivalent_* prices the same iteration at the bytes of "
+                                        "the reference's CSR formulation (SURVEY 8d: 12 nnz + 4 (m + 1) + 96 m). Below ~2e5 rows the iteration is two "
+                                        "dependent launches of a few microseconds each, bound by launch + memory latency, not by bytes (DESIGN 4)",
                                 "csr_equivalent_bytes_per_iteration": b_csr, "csr_equivalent_GBps": round(b_csr / us / 1e3, 1)}
     if pr["pair_n"] > 0 and st["n_charged"] > 0:
         # pair sum: 64 fp64 flops per evaluated (site, charged site) pair; pairs beyond the screening cut-off
@@ -594,6 +600,7 @@ def main():
     ap.add_argument("--no-cpp-host", action="store_true", help="N = 1: skip the cross-check line through the C++ host driver")
     ap.add_argument("--no-pmc", action="store_true", help="N = 1: do not measure roofline.traffic (two rocprofv3 --pmc child runs)")
     ap.add_argument("--no-log-tolerance", action="store_true", help="N = 1: skip the at_log_tolerance block")
+    ap.add_argument("--k-blocked", type=int, default=1, help="dkmc_set_k_blocked: 1 = library default (K-CG on the blocked form up to 262 144 rows), 0 = CSR positions")
     ap.add_argument("--x-block", type=int, default=16, help="dkmc_set_x_block: 16 = library default (block-CG), 1 = the reference's single-vector CG on X")
     ap.add_argument("--cg-tol", type=float, default=None, help="override the CG tolerance (default: the reference's 1e-6)")
     ap.add_argument("--budget", type=float, default=420.0, help="time budget [s] for the timed steps of seconds-per-step workloads")
@@ -628,6 +635,7 @@ def main():
     global X_BLOCK
     X_BLOCK = args.x_block
     _dlib.load().dkmc_set_x_block(args.x_block)
+    _dlib.load().dkmc_set_k_blocked(args.k_blocked)
     ncores = min(16, os.cpu_count() or 1)         # the box's CPU share for one GPU; more threads only add contention
     out = None
 

@@ -96,6 +96,14 @@ __device__ __forceinline__ double block_sum_all(double v, double *red)
     return s;
 }
 
+// blocked form of a K pattern (kcg.hip: kblocked_build, once per pattern; device arrays)
+struct KBlocked {
+    int m, R, nb, total, maxwin;
+    long long winsum;   // columns in all windows together
+    int *perm;          // [m] row of the blocked order -> row of the pattern
+    int *pcol;          // [total] columns in the blocked order, rows padded to 64 / 32 entries with the row itself, diagonal left out
+    int4 *blk;          // [nb] {first column of the window, columns in the window, first int of the block in pcol, rows padded to 64}
+};
 // ---- host side ---------------------------------------------------------------------------------
 struct Engine {
     hipStream_t stream = nullptr;
@@ -106,6 +114,7 @@ struct Engine {
     int cb_edge_domain = 0;        // 0: CB-edge system over every site (snapshot source); 1: over atoms only (dkmc_set_cb_edge_domain)
     long long tcache_budget = -1;  // bytes the tunnelling-coefficient cache may take; -1 = a third of the free device memory, 8-128 GiB (dkmc_set_tcache_budget)
     double pair_cut = 6.5;         // screening cut-off of the pair sum in units of sigma sqrt 2 (dkmc_set_pair_cutoff; 0 = all pairs like the reference)
+    int k_blocked = 1;             // build the blocked form of K patterns (dkmc_set_k_blocked; kcg.hip)
     int x_block = 16;              // block-CG width of the current solve on the tiled X (dkmc_set_x_block; xtb.hip): 16 by default, 1 = the reference's single-vector loop (its iterate sequence)
     int x_format = 1;              // 1: tiled X (xt.hip, default); 0: CSR X as the reference stores it (current.hip + cg.hip)
     int x_iter_hint = 0;           // iteration count of the previous CG solve of X (sizes the first launch batch)

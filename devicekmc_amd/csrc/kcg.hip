@@ -11,6 +11,8 @@
 //     per row (row pointers -> columns -> q) instead of one per 16 entries.
 // Bytes per iteration: 4 nnz + 4 (m + 1) + 15 vector touches of 8 m  (CSR formulation, SURVEY 8d: 12 nnz + 4 (m + 1) + 96 m).
 #include "common.h"
+#include <algorithm>
+#include <vector>
 
 #define KC_NT 256
 struct KCtrl { double rr[2]; double pad; int done; int iters; };
@@ -81,14 +83,48 @@ __global__ void k_kc_scale(int m, const double *__restrict__ diag, double *__res
     q[i] = sv * ys;
 }
 
-// t = S K q (q = S p): 8 lanes per row.  MODE 0: + partial p.t (iteration).  MODE 1: r = t - b, p = -r, partial r.r (start).
+// One iteration = TWO launches (round 4; three before: apply, update, direction -- at 1.1e5 rows, the reference's crossbar, every launch is
+// latency-bound and the K solve is the whole superstep).  k_kc_apply forms t = S K q and the partial sums of p.t, r.t and t.t;
+// k_kc_step reduces them together with the partial sums of the TRUE r.r its predecessor left, and does the whole vector update:
+//     alpha = rr / p.t ; y += alpha p ; r' = r + alpha t ; rr' = rr + alpha (2 r.t + alpha t.t)  (= r'.r' in exact arithmetic: it only
+//     feeds beta, the rr of the next iteration is summed from r' itself, so nothing drifts) ; beta = rr' / rr ; p = beta p - r' ; q = s p.
+// The stop test is the reference's, on the summed r.r (iterative_solvers_gpu.cu:440-456); it is evaluated by the k_kc_step that follows,
+// which then changes nothing: same number of updates as the reference's loop, one product more.
+#define KC_NPA 2048         // partial sums per quantity of k_kc_apply (= its largest grid)
+#define KC_NP 512           // partial sums of r.r (= the largest grid of k_kc_step)
+template <int NT, int NQ>
+__device__ __forceinline__ void block_sum_n(double (&v)[NQ], double (*red)[NT / 64])
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) red[k][w] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < NT / 64; ++i) s += red[k][i];
+        v[k] = s;
+    }
+}
+// part: p.t | r.t | t.t (KC_NPA each) | r.r read by even iterations | r.r read by odd iterations (KC_NP each)
+#define KC_PART_DOUBLES (3 * KC_NPA + 2 * KC_NP)
+// MODE 0: iteration.  MODE 1: start: r = t - b, p = -r, partial r.r into array 0.
+// t = S K q (q = S p), CSR positions, 8 lanes per row, 4 entries per lane and pass.  The products of a row are added pairwise: t = s (d q - sum)
+// cancels to a small fraction of its terms, and the rounding of that sum is what limits the residual K-CG can reach (at the crossbar log's
+// 1e-12 a left-to-right sum of 16 products per lane needed 820 instead of 735 iterations and moved the KMC time in the fifth digit).
 template <int MODE>
 __global__ __launch_bounds__(KC_NT) void k_kc_apply(int m, const int *__restrict__ rp, const int *__restrict__ cf, const double *__restrict__ diag,
                                                     const double *__restrict__ s, const double *__restrict__ q, double high_G, double low_G,
                                                     const double *__restrict__ pv, double *__restrict__ t, double *__restrict__ part, const KCtrl *ctrl,
                                                     const double *__restrict__ b, double *__restrict__ r, double *__restrict__ p)
 {
-    __shared__ double red[KC_NT / 64];
+    __shared__ double red[3][KC_NT / 64];
     __shared__ int sdone;
     if (MODE == 0) {
         if (threadIdx.x == 0) sdone = ctrl->done;
@@ -96,10 +132,11 @@ __global__ __launch_bounds__(KC_NT) void k_kc_apply(int m, const int *__restrict
         if (sdone) return;
     }
     const int g = threadIdx.x >> 3, l = threadIdx.x & 7;
-    double acc = 0.0;
+    double acc[3] = {0.0, 0.0, 0.0};
     for (int row = blockIdx.x * (KC_NT / 8) + g; row < m; row += gridDim.x * (KC_NT / 8)) {
         const int p0 = rp[row], p1 = rp[row + 1];
-        const double dq = diag[row] * q[row], sv = s[row];
+        const double qr = q[row], dg = diag[row], sv = s[row];
+        const double a1 = MODE == 0 ? pv[row] : b[row], a2 = MODE == 0 ? r[row] : 0.0;      // (requested with the rest, used by lane 0 at the end)
         double sum = 0.0;
         for (int pb = p0 + l; pb < p1; pb += 32) {
             int c[4];
@@ -109,75 +146,230 @@ __global__ __launch_bounds__(KC_NT) void k_kc_apply(int m, const int *__restrict
 #pragma unroll
             for (int u = 0; u < 4; ++u) x[u] = q[c[u] & 0x7fffffff];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) sum += (c[u] & 0x7fffffff) == row ? 0.0 : (c[u] < 0 ? high_G : low_G) * x[u];
+            for (int u = 0; u < 4; ++u) x[u] = (c[u] & 0x7fffffff) == row ? 0.0 : (c[u] < 0 ? high_G : low_G) * x[u];
+            sum += (x[0] + x[1]) + (x[2] + x[3]);
         }
         sum += __shfl_xor(sum, 4, 8); sum += __shfl_xor(sum, 2, 8); sum += __shfl_xor(sum, 1, 8);
         if (l == 0) {
-            const double tv = sv * (dq - sum);
-            if (MODE == 0) { t[row] = tv; acc += pv[row] * tv; }
-            else { const double rv = -b[row] + tv; r[row] = rv; p[row] = -rv; acc += rv * rv; }      // (q = s p: k_kc_q, after every row has read the old q)
+            const double tv = sv * (dg * qr - sum);
+            if (MODE == 0) { t[row] = tv; acc[0] += a1 * tv; acc[1] += a2 * tv; acc[2] += tv * tv; }
+            else { const double rv = -a1 + tv; r[row] = rv; p[row] = -rv; acc[0] += rv * rv; }      // (q = s p: k_kc_q, after every row has read the old q)
         }
     }
-    const double tot = block_sum_all<KC_NT>(acc, red);
-    if (threadIdx.x == 0) part[blockIdx.x] = tot;
+    block_sum_n<KC_NT, 3>(acc, red);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = acc[0];          // (MODE 1: r.r in the p.t array: k_kc_check0 moves the total into slot 0 of the first r.r array, whose other slots are zero)
+        if (MODE == 0) { part[KC_NPA + blockIdx.x] = acc[1]; part[2 * KC_NPA + blockIdx.x] = acc[2]; }
+    }
 }
 
-__device__ __forceinline__ double kc_reduce(const double *part, int n, double *red, const KCtrl *ctrl, bool *done)
+// ---- the blocked form of K (systems up to KB_MAXROWS rows) -------------------------------------------------------------------
+// At 1e5 rows (the reference's crossbar, where the K solve IS the superstep) the product is bound by neither bytes nor launches but by
+// the rate at which the texture path takes scattered 8-byte addresses: one read of q per non-zero, 2.7e6 of them, 0.43 per ns
+// chip-wide.  Site order is the reference's contract and is not spatial (37 % of the entries of a row lie more than 8 192 rows away), so
+// kblocked_build (once per pattern) sorts the ROWS OF K by x -- an internal order: y is gathered on entry and scattered on exit, nothing
+// outside this file sees it -- and cuts them into one block of R rows per CU.  Every column a block touches then lies in one
+// contiguous window of q (R + 2 x the rows within the neighbour distance: 7.7e3 doubles at the crossbar), which the workgroup copies
+// into LDS with coalesced loads and gathers from there.  Rows are stored without row pointers: within a block the rows with more than
+// 32 off-diagonal entries come first, padded to 64, the others padded to 32 (the padding is the row itself, which the product skips);
+// a row's position follows from its index and the block record, so the column loads are issued at once: one global latency + LDS
+// instead of three dependent global latencies.
+#define KB_NT 1024
+#define KB_MAXWIN 14336     // doubles of the LDS window (112 KB)
+#define KB_WREG (KB_MAXWIN / KB_NT)
+__device__ __forceinline__ int kb_row_base(const int4 &bi, int k, int *width)
 {
+    const bool lg = k < bi.w;
+    *width = lg ? 64 : 32;
+    return bi.z + (lg ? k * 64 : bi.w * 64 + (k - bi.w) * 32);
+}
+template <int CB>
+__global__ __launch_bounds__(KC_NT) void k_kb_assemble(int m, int N_left, int R, const int4 *__restrict__ blk, const int *__restrict__ perm,
+                                                       const int *__restrict__ pcol, const int *__restrict__ element, const int *__restrict__ charge,
+                                                       MetalSet ms, double high_G, double low_G,
+                                                       const int *__restrict__ lrp, const int *__restrict__ lci,
+                                                       const int *__restrict__ rrp, const int *__restrict__ rci,
+                                                       double VL, double VR, int *__restrict__ cf, double *__restrict__ diag, double *__restrict__ rhs)
+{
+    const int LPR = 16;
+    const int g = threadIdx.x / LPR, l = threadIdx.x % LPR;
+    const int rb = blockIdx.x * (KC_NT / LPR) + g;           // row in the blocked order
+    if (rb >= m) return;
+    const int bb = rb / R;
+    int width;
+    const int base = kb_row_base(blk[bb], rb - bb * R, &width);
+    const int r = perm[rb], i = N_left + r;
+    const int ei = element[i], qi = charge[i];
+    double off = 0.0, kl = 0.0, kr = 0.0;
+    for (int k = l; k < width; k += LPR) {
+        const int c = pcol[base + k];
+        if (c == rb) { cf[base + k] = rb; continue; }        // padding
+        const int j = N_left + perm[c];
+        const int ej = element[j];
+        if (CB == 2 && (k_interstitial(ei) || k_interstitial(ej))) { cf[base + k] = rb; continue; }      // no link: stored like padding
+        const bool hi = k_high<CB>(ei, ej, qi, charge[j], ms);
+        cf[base + k] = hi ? (c | (int)0x80000000) : c;
+        off += hi ? high_G : low_G;
+    }
+    const bool cut = CB == 2 && k_interstitial(ei);
+    for (int p = lrp[r] + l; p < lrp[r + 1] && !cut; p += LPR) { const int j = lci[p]; const int ej = element[j]; if (CB == 2 && k_interstitial(ej)) continue; kl += k_high<CB>(ei, ej, qi, charge[j], ms) ? high_G : low_G; }
+    for (int p = rrp[r] + l; p < rrp[r + 1] && !cut; p += LPR) { const int j = N_left + m + rci[p]; const int ej = element[j]; if (CB == 2 && k_interstitial(ej)) continue; kr += k_high<CB>(ei, ej, qi, charge[j], ms) ? high_G : low_G; }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) { off += __shfl_xor(off, o, LPR); kl += __shfl_xor(kl, o, LPR); kr += __shfl_xor(kr, o, LPR); }
+    if (l == 0) {
+        double d = off;
+        d += kl;
+        d += kr;
+        if (CB == 2 && d == 0.0) d = 1.0;
+        diag[rb] = d;
+        rhs[rb] = kl * VL + kr * VR;
+    }
+}
+// s = 1/sqrt(diag); b *= s; yb = y[perm] / s; q = s yb   (entry into the blocked order)
+__global__ void k_kb_scale(int m, const int *__restrict__ perm, const double *__restrict__ diag, double *__restrict__ s, double *__restrict__ b,
+                           const double *__restrict__ y, double *__restrict__ yb, double *__restrict__ q)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const double sv = 1.0 / sqrt(diag[i]);
+    s[i] = sv;
+    b[i] = b[i] * sv;
+    const double ys = y[perm[i]] * 1 / sv;
+    yb[i] = ys;
+    q[i] = sv * ys;
+}
+__global__ void k_kb_unscale(int m, const int *__restrict__ perm, const double *__restrict__ yb, const double *__restrict__ s, double *__restrict__ y)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) y[perm[i]] = yb[i] * s[i];
+}
+__device__ __forceinline__ void kb_load_row(const int *__restrict__ cf, const int4 &bi, int k, int l, bool in, int4 (&cc)[4], bool *lg)
+{
+    int width;
+    const int base = kb_row_base(bi, k, &width);
+    *lg = in && width == 64;
+    if (in) {
+        const int4 *cr = (const int4 *)(cf + base) + l;
+        cc[0] = cr[0]; cc[1] = cr[4];
+        if (width == 64) { cc[2] = cr[8]; cc[3] = cr[12]; }
+    }
+}
+template <int MODE>
+__global__ __launch_bounds__(KB_NT) void k_kb_apply(int m, int R, const int4 *__restrict__ blk, const int *__restrict__ cf, const double *__restrict__ diag,
+                                                    const double *__restrict__ s, const double *__restrict__ q, double high_G, double low_G,
+                                                    const double *__restrict__ pv, double *__restrict__ t, double *__restrict__ part, const KCtrl *ctrl,
+                                                    const double *__restrict__ b, double *__restrict__ r, double *__restrict__ p)
+{
+    extern __shared__ double win[];
+    __shared__ double red[3][KB_NT / 64];
+    __shared__ int sdone;
+    const int4 bi = blk[blockIdx.x];
+    const int wlo = bi.x, wn = bi.y;
+    const int r0 = blockIdx.x * R, nrows = min(R, m - r0);
+    const int g = threadIdx.x >> 2, l = threadIdx.x & 3;
+    // everything the first pass needs is requested before anything is waited for
+    double wv[KB_WREG];
+#pragma unroll
+    for (int j = 0; j < KB_WREG; ++j) { const int idx = threadIdx.x + j * KB_NT; wv[j] = idx < wn ? q[wlo + idx] : 0.0; }
+    int4 cc[4];
+    bool lg;
+    int k = g;
+    kb_load_row(cf, bi, k, l, k < nrows, cc, &lg);
+    if (MODE == 0 && threadIdx.x == 0) sdone = ctrl->done;
+#pragma unroll
+    for (int j = 0; j < KB_WREG; ++j) { const int idx = threadIdx.x + j * KB_NT; if (idx < wn) win[idx] = wv[j]; }
+    __syncthreads();
+    if (MODE == 0 && sdone) return;
+    double acc[3] = {0.0, 0.0, 0.0};
+    for (; k < nrows; k += KB_NT / 4) {
+        const int row = r0 + k;
+        const double qr = win[row - wlo], dg = diag[row], sv = s[row];
+        const double a1 = MODE == 0 ? pv[row] : b[row], a2 = MODE == 0 ? r[row] : 0.0;
+        int c[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { c[4 * j] = cc[j].x; c[4 * j + 1] = cc[j].y; c[4 * j + 2] = cc[j].z; c[4 * j + 3] = cc[j].w; }
+        const bool lgc = lg;
+        double x[16];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = win[(c[u] & 0x7fffffff) - wlo];
+        if (lgc) {
+#pragma unroll
+            for (int u = 8; u < 16; ++u) x[u] = win[(c[u] & 0x7fffffff) - wlo];
+        }
+        kb_load_row(cf, bi, k + KB_NT / 4, l, k + KB_NT / 4 < nrows, cc, &lg);      // next pass
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = (c[u] & 0x7fffffff) == row ? 0.0 : (c[u] < 0 ? high_G : low_G) * x[u];
+        double sum = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+        if (lgc) {
+#pragma unroll
+            for (int u = 8; u < 16; ++u) x[u] = (c[u] & 0x7fffffff) == row ? 0.0 : (c[u] < 0 ? high_G : low_G) * x[u];
+            sum += ((x[8] + x[9]) + (x[10] + x[11])) + ((x[12] + x[13]) + (x[14] + x[15]));
+        }
+        sum += __shfl_xor(sum, 2, 4); sum += __shfl_xor(sum, 1, 4);
+        if (l == 0) {
+            const double tv = sv * (dg * qr - sum);
+            if (MODE == 0) { t[row] = tv; acc[0] += a1 * tv; acc[1] += a2 * tv; acc[2] += tv * tv; }
+            else { const double rv = -a1 + tv; r[row] = rv; p[row] = -rv; acc[0] += rv * rv; }
+        }
+    }
+    block_sum_n<KB_NT, 3>(acc, red);
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = acc[0];
+        if (MODE == 0) { part[KC_NPA + blockIdx.x] = acc[1]; part[2 * KC_NPA + blockIdx.x] = acc[2]; }
+    }
+}
+
+__global__ __launch_bounds__(KC_NT) void k_kc_check0(double *part, KCtrl *ctrl, double tol2)
+{
+    __shared__ double red[KC_NT / 64];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < KC_NPA; i += KC_NT) s += part[i];
+    const double rr = block_sum_all<KC_NT>(s, red);
+    if (threadIdx.x == 0) { part[3 * KC_NPA] = rr; ctrl->rr[0] = rr; ctrl->rr[1] = rr; ctrl->iters = 0; ctrl->done = !(sqrt(rr) > tol2); }
+}
+__global__ __launch_bounds__(KC_NT) void k_kc_step(int m, int it, double *__restrict__ part, double *__restrict__ p, const double *__restrict__ t,
+                                                   double *__restrict__ y, double *__restrict__ r, const double *__restrict__ s, double *__restrict__ q,
+                                                   KCtrl *ctrl, double tol2, int npa)
+{
+    // npa: slots of the p.t / r.t / t.t arrays that can be non-zero (the grid of the product, rounded up to KC_NT)
+    __shared__ double red[4][KC_NT / 64];
     __shared__ int sdone;
     if (threadIdx.x == 0) sdone = ctrl->done;
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += KC_NT) s += part[i];
-    s = block_sum_all<KC_NT>(s, red);
-    *done = sdone != 0;
-    return s;
-}
-__global__ __launch_bounds__(KC_NT) void k_kc_check0(const double *part, int npart, KCtrl *ctrl, double tol2)
-{
-    __shared__ double red[KC_NT / 64];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < npart; i += KC_NT) s += part[i];
-    const double rr = block_sum_all<KC_NT>(s, red);
-    if (threadIdx.x == 0) { ctrl->rr[0] = rr; ctrl->rr[1] = rr; ctrl->iters = 0; ctrl->done = !(sqrt(rr) > tol2); }
-}
-// alpha = rr / p.t ; y += alpha p ; r += alpha t ; partial r.r
-__global__ __launch_bounds__(KC_NT) void k_kc_update(int m, int it, const double *__restrict__ part_pt, int npart, const double *__restrict__ p,
-                                                     const double *__restrict__ t, double *__restrict__ y, double *__restrict__ r,
-                                                     double *__restrict__ part_rr, const KCtrl *ctrl)
-{
-    __shared__ double red[KC_NT / 64];
-    bool done;
-    const double pAp = kc_reduce(part_pt, npart, red, ctrl, &done);
-    if (done) return;
-    const double alpha = ctrl->rr[it & 1] / pAp;
+    int i = blockIdx.x * KC_NT + threadIdx.x;
+    double pi = 0.0, ti = 0.0, yi = 0.0, ri = 0.0, si = 0.0;
+    if (i < m) { pi = p[i]; ti = t[i]; yi = y[i]; ri = r[i]; si = s[i]; }       // in flight while the partial sums are reduced
+    const double *prr = part + 3 * KC_NPA + (it & 1) * KC_NP;
+    double *prr_next = part + 3 * KC_NPA + ((it + 1) & 1) * KC_NP;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int j = threadIdx.x; j < npa; j += KC_NT) { v[0] += part[j]; v[1] += part[KC_NPA + j]; v[2] += part[2 * KC_NPA + j]; }
+#pragma unroll
+    for (int k = 0; k < KC_NP / KC_NT; ++k) v[3] += prr[threadIdx.x + k * KC_NT];
+    block_sum_n<KC_NT, 4>(v, red);
+    if (sdone) return;
+    const double rr = v[3];
+    if (it > 0 && !(rr > tol2)) {            // the test the reference makes after update `it`: every workgroup takes the same decision
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ctrl->rr[0] = rr; ctrl->iters = it; ctrl->done = 1; }
+        return;
+    }
+    const double alpha = rr / v[0];
+    const double rr_new = rr + alpha * (2.0 * v[1] + alpha * v[2]);
+    const double beta = rr_new / rr;
     double acc = 0.0;
-    for (int i = blockIdx.x * KC_NT + threadIdx.x; i < m; i += gridDim.x * KC_NT) {
-        y[i] += alpha * p[i];
-        const double rn = r[i] + alpha * t[i];
+    while (i < m) {
+        y[i] = yi + alpha * pi;
+        const double rn = ri + alpha * ti;
         r[i] = rn;
         acc += rn * rn;
-    }
-    const double tot = block_sum_all<KC_NT>(acc, red);
-    if (threadIdx.x == 0) part_rr[blockIdx.x] = tot;
-}
-// beta = rr' / rr ; p = beta p - r ; q = s p ; stop test on rr'
-__global__ __launch_bounds__(KC_NT) void k_kc_direction(int m, int it, const double *__restrict__ part_rr, int npart, const double *__restrict__ r,
-                                                        double *__restrict__ p, const double *__restrict__ s, double *__restrict__ q, KCtrl *ctrl, double tol2)
-{
-    __shared__ double red[KC_NT / 64];
-    bool done;
-    const double rr_new = kc_reduce(part_rr, npart, red, ctrl, &done);
-    if (done) return;
-    const double beta = rr_new / ctrl->rr[it & 1];
-    for (int i = blockIdx.x * KC_NT + threadIdx.x; i < m; i += gridDim.x * KC_NT) {
-        const double pn = p[i] * beta - r[i];
+        const double pn = pi * beta - rn;
         p[i] = pn;
-        q[i] = s[i] * pn;
+        q[i] = si * pn;
+        i += gridDim.x * KC_NT;
+        if (i < m) { pi = p[i]; ti = t[i]; yi = y[i]; ri = r[i]; si = s[i]; }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        ctrl->rr[(it + 1) & 1] = rr_new;
-        ctrl->iters = it + 1;
-        if (!(rr_new > tol2)) ctrl->done = 1;
+    const double tot = block_sum_all<KC_NT>(acc, red[0]);
+    if (threadIdx.x == 0) {
+        prr_next[blockIdx.x] = tot;
+        if (blockIdx.x == 0) { ctrl->rr[0] = rr_new; ctrl->iters = it + 1; }
     }
 }
 __global__ void k_kc_q(int m, const double *__restrict__ s, const double *__restrict__ p, double *__restrict__ q)
@@ -199,36 +391,126 @@ static inline int kc_grid(long long work, int per_block, int cap)
     return (int)b;
 }
 
+// Builds the blocked form of a K pattern (host side, once per initialize_sparsity; nullptr when the system is too large for it, a row has
+// more than 64 off-diagonal entries or a window does not fit the LDS: the solve then uses the CSR positions).  x: device pointer to the x
+// coordinate of the pattern's rows.
+#define KB_MAXROWS 262144
+void kblocked_free(KBlocked *kb);
+KBlocked *kblocked_build(const int *rp_d, const int *ci_d, int m, int nnz, const double *x_d, hipStream_t st)
+{
+    if (!eng().k_blocked || m < 1 || m > KB_MAXROWS || nnz < 1) return nullptr;
+    std::vector<int> rp(m + 1), ci(nnz);
+    std::vector<double> x(m);
+    if (hipMemcpyAsync(rp.data(), rp_d, (size_t)(m + 1) * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return nullptr;
+    if (hipMemcpyAsync(ci.data(), ci_d, (size_t)nnz * 4, hipMemcpyDeviceToHost, st) != hipSuccess) return nullptr;
+    if (hipMemcpyAsync(x.data(), x_d, (size_t)m * 8, hipMemcpyDeviceToHost, st) != hipSuccess) return nullptr;
+    if (hipStreamSynchronize(st) != hipSuccess) return nullptr;
+    std::vector<int> perm(m);
+    for (int i = 0; i < m; ++i) perm[i] = i;
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) { return x[a] < x[b]; });
+    int R = (m + 255) / 256;
+    R = (R + 63) / 64 * 64;
+    const int nb = (m + R - 1) / R;
+    auto offdiag = [&](int r) { int n = 0; for (int p = rp[r]; p < rp[r + 1]; ++p) n += ci[p] != r; return n; };
+    std::vector<int4> blk(nb);
+    long long total = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int lo = b * R, hi = std::min(m, lo + R);
+        for (int i = lo; i < hi; ++i) if (offdiag(perm[i]) > 64) return nullptr;
+        auto mid = std::stable_partition(perm.begin() + lo, perm.begin() + hi, [&](int r) { return offdiag(r) > 32; });
+        const int nl = (int)(mid - (perm.begin() + lo));
+        blk[b].z = (int)total; blk[b].w = nl;
+        total += (long long)nl * 64 + (long long)(hi - lo - nl) * 32;
+    }
+    std::vector<int> inv(m);
+    for (int i = 0; i < m; ++i) inv[perm[i]] = i;
+    std::vector<int> pcol((size_t)total);
+    int maxwin = 0;
+    long long winsum = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int lo = b * R, hi = std::min(m, lo + R);
+        int cmin = lo, cmax = hi - 1;
+        for (int i = lo; i < hi; ++i) {
+            const int k = i - lo, nl = blk[b].w, width = k < nl ? 64 : 32;
+            int *dst = pcol.data() + blk[b].z + (k < nl ? (size_t)k * 64 : (size_t)nl * 64 + (size_t)(k - nl) * 32);
+            const int r = perm[i];
+            int n = 0;
+            for (int p = rp[r]; p < rp[r + 1]; ++p) if (ci[p] != r) dst[n++] = inv[ci[p]];
+            std::sort(dst, dst + n);
+            if (n) { cmin = std::min(cmin, dst[0]); cmax = std::max(cmax, dst[n - 1]); }
+            for (; n < width; ++n) dst[n] = i;
+        }
+        blk[b].x = cmin; blk[b].y = cmax - cmin + 1;
+        maxwin = std::max(maxwin, blk[b].y); winsum += blk[b].y;
+    }
+    if (maxwin > KB_MAXWIN) return nullptr;
+    KBlocked *kb = new KBlocked{m, R, nb, (int)total, maxwin, winsum, nullptr, nullptr, nullptr};
+    bool ok = hipMalloc((void **)&kb->perm, (size_t)m * 4) == hipSuccess && hipMalloc((void **)&kb->pcol, (size_t)total * 4) == hipSuccess &&
+              hipMalloc((void **)&kb->blk, (size_t)nb * sizeof(int4)) == hipSuccess;
+    ok = ok && hipMemcpy(kb->perm, perm.data(), (size_t)m * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(kb->pcol, pcol.data(), (size_t)total * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(kb->blk, blk.data(), (size_t)nb * sizeof(int4), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { kblocked_free(kb); (void)hipGetLastError(); return nullptr; }
+    return kb;
+}
+void kblocked_free(KBlocked *kb)
+{
+    if (!kb) return;
+    if (kb->perm) (void)hipFree(kb->perm);
+    if (kb->pcol) (void)hipFree(kb->pcol);
+    if (kb->blk) (void)hipFree(kb->blk);
+    delete kb;
+}
+
 // Assemble K for the current elements / charges and solve K y = rhs in place in y (warm start = y on entry).
+// kb: the blocked form of the pattern (or nullptr): the whole solve then runs in the blocked order, y is gathered on entry and scattered on exit.
 int kcg_assemble_and_solve(int cb, int m, int N_left, const int *element, const int *charge, MetalSet ms, double high_G, double low_G,
                            const int *rp, const int *ci, int nnz, const int *lrp, const int *lci, const int *rrp, const int *rci,
-                           double VL, double VR, double *y, int *iters_out, double *rr_out)
+                           double VL, double VR, double *y_site, int *iters_out, double *rr_out, const KBlocked *kb)
 {
     Engine &e = eng(); hipStream_t st = e.stream;
     if (m <= 0) { if (iters_out) *iters_out = 0; if (rr_out) *rr_out = 0; return 0; }
-    int *cf = (int *)scratch(S_K_DATA, (size_t)nnz * 4);
-    double *rhs = (double *)scratch(S_K_RHS, (size_t)m * 8 * 2);
+    if (kb && kb->m != m) return dkmc_fail(6, "K-CG: the blocked form belongs to another pattern", __FILE__, __LINE__);
+    int *cf = (int *)scratch(S_K_DATA, kb ? (size_t)kb->total * 4 : (size_t)nnz * 4);
+    double *rhs = (double *)scratch(S_K_RHS, (size_t)m * 8 * 3);
     double *s = (double *)scratch(S_CG_S, (size_t)m * 8), *r = (double *)scratch(S_CG_R, (size_t)m * 8);
     double *p = (double *)scratch(S_CG_P, (size_t)m * 8), *t = (double *)scratch(S_CG_T, (size_t)m * 8);
     double *q = (double *)scratch(S_XT_Q, (size_t)m * 8);
-    double *part = (double *)scratch(S_CG_PART, (size_t)3 * 8192 * 8);
+    double *part = (double *)scratch(S_CG_PART, (size_t)KC_PART_DOUBLES * 8);
     KCtrl *ctrl = (KCtrl *)scratch(S_CG_CTRL, sizeof(KCtrl));
     if (!cf || !rhs || !s || !r || !p || !t || !q || !part || !ctrl) return e.err_code;
-    double *diag = rhs + m, *part_pt = part, *part_rr = part + 4096;
+    double *diag = rhs + m, *y = kb ? rhs + 2 * (size_t)m : y_site;
     const double tol2 = e.cg_tol * e.cg_tol;
-    const int ab = (m + 15) / 16;
-    if (cb == 2) hipLaunchKernelGGL((k_kc_assemble<2>), dim3(ab), dim3(KC_NT), 0, st, m, N_left, element, charge, ms, high_G, low_G, rp, ci, lrp, lci, rrp, rci, VL, VR, cf, diag, rhs);
-    else if (cb) hipLaunchKernelGGL((k_kc_assemble<1>), dim3(ab), dim3(KC_NT), 0, st, m, N_left, element, charge, ms, high_G, low_G, rp, ci, lrp, lci, rrp, rci, VL, VR, cf, diag, rhs);
-    else hipLaunchKernelGGL((k_kc_assemble<0>), dim3(ab), dim3(KC_NT), 0, st, m, N_left, element, charge, ms, high_G, low_G, rp, ci, lrp, lci, rrp, rci, VL, VR, cf, diag, rhs);
-    const int vb = (m + 255) / 256;
-    hipLaunchKernelGGL(k_kc_scale, dim3(vb), dim3(256), 0, st, m, (const double *)diag, s, rhs, y, q);
-    const int ga = kc_grid(m, KC_NT / 8, 2048);          // apply: 32 rows per block and pass
-    const int gv = kc_grid(m, KC_NT * 4, 512);
+    const int ab = (m + 15) / 16, vb = (m + 255) / 256;
+    const size_t lds = kb ? (size_t)kb->maxwin * 8 : 0;
+    if (kb) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIPCHK(hipFuncSetAttribute((const void *)k_kb_apply<0>, hipFuncAttributeMaxDynamicSharedMemorySize, KB_MAXWIN * 8));
+            HIPCHK(hipFuncSetAttribute((const void *)k_kb_apply<1>, hipFuncAttributeMaxDynamicSharedMemorySize, KB_MAXWIN * 8));
+            attr_set = true;
+        }
+        if (cb == 2) hipLaunchKernelGGL((k_kb_assemble<2>), dim3(ab), dim3(KC_NT), 0, st, m, N_left, kb->R, (const int4 *)kb->blk, (const int *)kb->perm, (const int *)kb->pcol, element, charge, ms, high_G, low_G, lrp, lci, rrp, rci, VL, VR, cf, diag, rhs);
+        else if (cb) hipLaunchKernelGGL((k_kb_assemble<1>), dim3(ab), dim3(KC_NT), 0, st, m, N_left, kb->R, (const int4 *)kb->blk, (const int *)kb->perm, (const int *)kb->pcol, element, charge, ms, high_G, low_G, lrp, lci, rrp, rci, VL, VR, cf, diag, rhs);
+        else hipLaunchKernelGGL((k_kb_assemble<0>), dim3(ab), dim3(KC_NT), 0, st, m, N_left, kb->R, (const int4 *)kb->blk, (const int *)kb->perm, (const int *)kb->pcol, element, charge, ms, high_G, low_G, lrp, lci, rrp, rci, VL, VR, cf, diag, rhs);
+        hipLaunchKernelGGL(k_kb_scale, dim3(vb), dim3(256), 0, st, m, (const int *)kb->perm, (const double *)diag, s, rhs, (const double *)y_site, y, q);
+    } else {
+        if (cb == 2) hipLaunchKernelGGL((k_kc_assemble<2>), dim3(ab), dim3(KC_NT), 0, st, m, N_left, element, charge, ms, high_G, low_G, rp, ci, lrp, lci, rrp, rci, VL, VR, cf, diag, rhs);
+        else if (cb) hipLaunchKernelGGL((k_kc_assemble<1>), dim3(ab), dim3(KC_NT), 0, st, m, N_left, element, charge, ms, high_G, low_G, rp, ci, lrp, lci, rrp, rci, VL, VR, cf, diag, rhs);
+        else hipLaunchKernelGGL((k_kc_assemble<0>), dim3(ab), dim3(KC_NT), 0, st, m, N_left, element, charge, ms, high_G, low_G, rp, ci, lrp, lci, rrp, rci, VL, VR, cf, diag, rhs);
+        hipLaunchKernelGGL(k_kc_scale, dim3(vb), dim3(256), 0, st, m, (const double *)diag, s, rhs, y, q);
+    }
+    const int ga = kb ? kb->nb : kc_grid(m, KC_NT / 8, KC_NPA);         // product: one block of the blocked form, or 32 rows, per workgroup and pass
+    const int gv = kc_grid(m, KC_NT, KC_NP);
+    const int npa = (ga + KC_NT - 1) / KC_NT * KC_NT;
     HIPCHK(hipMemsetAsync(ctrl, 0, sizeof(KCtrl), st));
-    hipLaunchKernelGGL((k_kc_apply<1>), dim3(ga), dim3(KC_NT), 0, st, m, rp, (const int *)cf, (const double *)diag, (const double *)s, (const double *)q, high_G, low_G,
-                       (const double *)nullptr, t, part_rr, (const KCtrl *)ctrl, (const double *)rhs, r, p);
+    HIPCHK(hipMemsetAsync(part, 0, (size_t)KC_PART_DOUBLES * 8, st));       // the slots beyond either grid stay zero
+#define KC_APPLY(MODE, ...) do { if (kb) hipLaunchKernelGGL((k_kb_apply<MODE>), dim3(ga), dim3(KB_NT), lds, st, m, kb->R, (const int4 *)kb->blk, __VA_ARGS__); \
+                                 else hipLaunchKernelGGL((k_kc_apply<MODE>), dim3(ga), dim3(KC_NT), 0, st, m, rp, __VA_ARGS__); } while (0)
+    KC_APPLY(1, (const int *)cf, (const double *)diag, (const double *)s, (const double *)q, high_G, low_G,
+             (const double *)nullptr, t, part, (const KCtrl *)ctrl, (const double *)rhs, r, p);
     hipLaunchKernelGGL(k_kc_q, dim3(vb), dim3(256), 0, st, m, (const double *)s, (const double *)p, q);
-    hipLaunchKernelGGL(k_kc_check0, dim3(1), dim3(KC_NT), 0, st, (const double *)part_rr, ga, ctrl, tol2);
+    hipLaunchKernelGGL(k_kc_check0, dim3(1), dim3(KC_NT), 0, st, part, ctrl, tol2);
     KCHK();
     static hipEvent_t evk[2]; static bool evk_ready = false;
     const bool prof = e.profiling != 0;
@@ -244,10 +526,9 @@ int kcg_assemble_and_solve(int cb, int m, int N_left, const int *element, const 
         if (h.done) break;
         if (it >= 200000) { dkmc_fail(4, "CG: no convergence after 200000 iterations", __FILE__, __LINE__); break; }
         for (int b = 0; b < batch; ++b, ++it) {
-            hipLaunchKernelGGL((k_kc_apply<0>), dim3(ga), dim3(KC_NT), 0, st, m, rp, (const int *)cf, (const double *)diag, (const double *)s, (const double *)q, high_G, low_G,
-                               (const double *)p, t, part_pt, (const KCtrl *)ctrl, (const double *)nullptr, (double *)nullptr, (double *)nullptr);
-            hipLaunchKernelGGL(k_kc_update, dim3(gv), dim3(KC_NT), 0, st, m, it, (const double *)part_pt, ga, (const double *)p, (const double *)t, y, r, part_rr, (const KCtrl *)ctrl);
-            hipLaunchKernelGGL(k_kc_direction, dim3(gv), dim3(KC_NT), 0, st, m, it, (const double *)part_rr, gv, (const double *)r, p, (const double *)s, q, ctrl, tol2);
+            KC_APPLY(0, (const int *)cf, (const double *)diag, (const double *)s, (const double *)q, high_G, low_G,
+                     (const double *)p, t, part, (const KCtrl *)ctrl, (const double *)nullptr, r, (double *)nullptr);
+            hipLaunchKernelGGL(k_kc_step, dim3(gv), dim3(KC_NT), 0, st, m, it, part, p, (const double *)t, y, r, (const double *)s, q, ctrl, tol2, npa);
         }
         KCHK();
         if (batch < 64) batch *= 2;
@@ -259,9 +540,12 @@ int kcg_assemble_and_solve(int cb, int m, int N_left, const int *element, const 
         HIPCHK(hipEventElapsedTime(&ms, evk[0], evk[1]));
         e.stats.kcg_ms = ms; e.stats.kcg_iters_timed = h.iters;
     } else { e.stats.kcg_ms = 0.0; e.stats.kcg_iters_timed = 0; }
-    hipLaunchKernelGGL(k_kc_unscale, dim3(vb), dim3(256), 0, st, m, y, (const double *)s);
+    if (kb) hipLaunchKernelGGL(k_kb_unscale, dim3(vb), dim3(256), 0, st, m, (const int *)kb->perm, (const double *)y, (const double *)s, y_site);
+    else hipLaunchKernelGGL(k_kc_unscale, dim3(vb), dim3(256), 0, st, m, y, (const double *)s);
     KCHK();
+    e.stats.kcg_blocked = kb ? 1 : 0;
+    e.stats.kcg_bytes = kb ? 4LL * kb->total + 16LL * kb->nb + 8LL * kb->winsum + 14LL * 8 * m : 4LL * nnz + 4LL * (m + 1) + 15LL * 8 * m;
     if (iters_out) *iters_out = h.iters;
-    if (rr_out) *rr_out = h.rr[h.iters & 1];
+    if (rr_out) *rr_out = h.rr[0];
     return e.err_code;
 }

@@ -5,7 +5,9 @@
 
 int kcg_assemble_and_solve(int cb, int m, int N_left, const int *element, const int *charge, MetalSet ms, double high_G, double low_G,
                            const int *rp, const int *ci, int nnz, const int *lrp, const int *lci, const int *rrp, const int *rci,
-                           double VL, double VR, double *y, int *iters_out, double *rr_out);
+                           double VL, double VR, double *y, int *iters_out, double *rr_out, const KBlocked *kb);
+KBlocked *kblocked_build(const int *rp_d, const int *ci_d, int m, int nnz, const double *x_d, hipStream_t st);
+void kblocked_free(KBlocked *kb);
 void tcache_invalidate(const void *key);
 void xstate_reset(const void *key);
 
@@ -86,12 +88,20 @@ __global__ void k_kpat_fill(int m, int N_left, int nn, const int *__restrict__ n
 
 // shape of every K pattern built by initialize_sparsity, keyed by its row-pointer array: a solve with other contact sizes
 // than the pattern was built for would index out of bounds
-struct KPatInfo { const int *rp; int m, N_left; };
+struct KPatInfo { const int *rp; int m, N_left; KBlocked *kb; };      // kb: the pattern's blocked form for the K solve (kcg.hip), or nullptr
 static KPatInfo g_kpat[64]; static int g_kpat_next = 0;          // ring: the 64 most recently built patterns
-static void kpat_register(const int *rp, int m, int N_left)
+static void kpat_forget(KPatInfo &k) { kblocked_free(k.kb); k = KPatInfo{nullptr, 0, 0, nullptr}; }
+static void kpat_register(const int *rp, int m, int N_left, KBlocked *kb)
 {
-    for (auto &k : g_kpat) if (k.rp == rp) { k.m = m; k.N_left = N_left; return; }
-    g_kpat[g_kpat_next++ % 64] = KPatInfo{rp, m, N_left};
+    for (auto &k : g_kpat) if (k.rp == rp) kpat_forget(k);
+    KPatInfo &slot = g_kpat[g_kpat_next++ % 64];
+    kpat_forget(slot);
+    slot = KPatInfo{rp, m, N_left, kb};
+}
+static const KBlocked *kpat_blocked(const int *rp)
+{
+    for (const auto &k : g_kpat) if (k.rp == rp) return k.kb;
+    return nullptr;
 }
 static bool kpat_matches(const int *rp, int m, int N_left)
 {
@@ -112,7 +122,7 @@ extern "C" int dkmc_free_sparsity(dkmc_gpubuf *buf)
                     &buf->contact_right_row_ptr, &buf->contact_right_col_indices };
     for (auto pp : ps) {
         if (!*pp) continue;
-        for (auto &k : g_kpat) if (k.rp == *pp) k = KPatInfo{nullptr, 0, 0};
+        for (auto &k : g_kpat) if (k.rp == *pp) kpat_forget(k);
         (void)hipFree(*pp); *pp = nullptr;
     }
     buf->Device_nnz = buf->contact_left_nnz = buf->contact_right_nnz = 0;
@@ -132,7 +142,7 @@ extern "C" int dkmc_initialize_sparsity(dkmc_gpubuf *buf, int pbc, double nn_dis
     int **rps[3] = { &buf->Device_row_ptr_d, &buf->contact_left_row_ptr, &buf->contact_right_row_ptr };
     int **cis[3] = { &buf->Device_col_indices_d, &buf->contact_left_col_indices, &buf->contact_right_col_indices };
     for (int b = 0; b < 3; ++b) {
-        if (*rps[b]) (void)hipFree(*rps[b]);
+        if (*rps[b]) { for (auto &k : g_kpat) if (k.rp == *rps[b]) kpat_forget(k); (void)hipFree(*rps[b]); }
         if (*cis[b]) { (void)hipFree(*cis[b]); *cis[b] = nullptr; }
         HIPCHK(hipMalloc((void **)rps[b], (size_t)(m + 1) * sizeof(int)));
     }
@@ -152,7 +162,7 @@ extern "C" int dkmc_initialize_sparsity(dkmc_gpubuf *buf, int pbc, double nn_dis
                        buf->Device_col_indices_d, buf->contact_left_col_indices, buf->contact_right_col_indices);
     KCHK();
     HIPCHK(hipStreamSynchronize(st));
-    kpat_register(buf->Device_row_ptr_d, m, N_left);
+    kpat_register(buf->Device_row_ptr_d, m, N_left, kblocked_build(buf->Device_row_ptr_d, buf->Device_col_indices_d, m, h_tot[0], buf->site_x + N_left, st));
     return 0;
 }
 
@@ -179,7 +189,7 @@ static int solve_K(dkmc_gpubuf *buf, int N, int N_left, int N_right, double VL, 
     (void)e; (void)st;
     return kcg_assemble_and_solve(cb, m, N_left, buf->site_element, buf->site_charge, ms, high_G, low_G, buf->Device_row_ptr_d, buf->Device_col_indices_d,
                                   buf->Device_nnz, buf->contact_left_row_ptr, buf->contact_left_col_indices, buf->contact_right_row_ptr,
-                                  buf->contact_right_col_indices, VL, VR, field + N_left, iters, rr);
+                                  buf->contact_right_col_indices, VL, VR, field + N_left, iters, rr, kpat_blocked(buf->Device_row_ptr_d));
 }
 
 // background_potential_gpu_sparse (potential_solver_gpu.cu:696-781)

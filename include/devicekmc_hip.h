@@ -93,12 +93,13 @@ typedef struct dkmc_stats {
     /* profiling on: HIP-event time of the whole iteration loop of the last CG solve on K (and the iterations it covers), and
      * of the last pair-sum kernel */
     double kcg_ms;
-    int kcg_iters_timed, kcg_pad;
+    int kcg_iters_timed, kcg_blocked;      /* kcg_blocked: 1 if the last K solve ran on the blocked form of the pattern (dkmc_set_k_blocked) */
     double pair_ms;
     long long pair_evaluated;              /* (site, charged site) pairs inside the screening cut-off of the last pair sum (profiling on) */
     long long pair_tested;                 /* pairs whose distance was tested (all N x N_charged without the cell list; the 3 x 3 columns with it) */
     long long xt_records;                  /* records of column partial sums one matrix-vector product writes (= runs; runs / 4 on one GPU, where the four waves of a workgroup share one) */
     long long tcache_bytes;                /* bytes of tunnelling-coefficient cache THIS rank holds (sharded solve on the tiled X: what its tiles read) */
+    long long kcg_bytes;                   /* bytes one iteration of the last K solve moves: column/class words + the q windows (or one read of q per row) + 14 (15) vector touches */
     int xb_width, xb_fallback;             /* block-CG width of the last current solve (1 = single-vector loop); 1 if the block loop lost definiteness and the single-vector loop finished the solve */
 } dkmc_stats;
 
@@ -143,6 +144,12 @@ void dkmc_reset_pair_sum_cache(void);
  * with the single-vector loop to the stop tolerance, NOT iterate by iterate.  85 071 sites: 666 -> 208 / 133 / 95 sweeps at s = 4 / 8 / 16. */
 void dkmc_set_x_block(int s);
 int dkmc_get_x_block(void);
+/* 1 (default): initialize_sparsity also builds the blocked form of the K pattern (csrc/kcg.hip) for systems of up to 262 144 device rows:
+ * the CG on K (background potential, CB edge: solve_sparse_CG_Jacobi on K, iterative_solvers_gpu.cu:309-480) then runs in an internal
+ * x-sorted row order, one block of rows per CU with its window of the direction vector in LDS; site order outside the solve is untouched.
+ * 0: the solve uses the CSR positions of the pattern (the only form above that size).  Read when a pattern is built. */
+void dkmc_set_k_blocked(int on);
+int dkmc_get_k_blocked(void);
 /* 0 (default): warm-start the current solve from gpubuf.atom_virtual_potentials exactly as the
  * reference does (the buffer holds G0*m of the previous step, current_solver_gpu.cu:1015-1016);
  * 1: warm-start from a private unscaled copy of the previous solution. */

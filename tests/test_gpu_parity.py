@@ -1186,6 +1186,46 @@ def test_pair_sum_site_grouping_follows_the_structure(cell_2p5, hip):
     assert np.abs(gpu_sum(gb2) - want).max() <= 1e-12 * np.abs(want).max()
 
 
+@pytest.mark.parametrize("which", ["2.5nm", "7.5nm"])
+def test_K_blocked_form_matches_csr_positions(cell_2p5, dev_7p5, hip, which):
+    """The CG on K in its internal blocked order (rows sorted by x, one block per CU, q window in LDS: csrc/kcg.hip, the default up to
+    262 144 rows) against the same solve on the CSR positions of the pattern (dkmc_set_k_blocked(0)): background potential and CB edge in
+    SITE order agree to 1e-8 of the bias at a converged tolerance (1e-12; cond(K) x residual: 7e-9 V measured at 85 k sites, where either
+    solve is within 1e-7 of the oracle's), contacts re-imposed exactly, and the unscaled residual of the
+    oracle's K is met by both (2.5 nm).  Nothing outside the solve sees the internal order."""
+    from devicekmc_amd import params as pm
+    host, L = hip
+    structure, p = (cell_2p5, pm.KMCParameters()) if which == "2.5nm" else (dev_7p5, params_7p5())
+    p.cg_tol = 1e-12
+    res = {}
+    try:
+        for on in (0, 1):
+            L.dkmc_set_k_blocked(on)
+            dev, sim, gb, _ = _fresh_device(structure, p, hip)          # (initialize_sparsity reads the switch)
+            cb = dev.site_CB_edge.copy()
+            used_cb = host.get_stats()["kcg_blocked"]
+            dev.updateCharge(gb); dev.updatePotential(gb, p, Vd, 0)
+            st = host.get_stats()
+            assert st["kcg_blocked"] == on and used_cb == on
+            res[on] = (get(gb, "site_potential_boundary").copy(), cb, st["cg_iters_K"])
+        n = p.num_atoms_first_layer
+        assert np.abs(res[1][0] - res[0][0]).max() <= 1e-8 * Vd, (res[0][2], res[1][2])
+        assert np.abs(res[1][1] - res[0][1]).max() <= 1e-8 * p.q * Vd
+        assert (res[1][0][:n] == -Vd / 2).all() and (res[1][0][-n:] == Vd / 2).all()
+        assert abs(res[1][2] - res[0][2]) <= 0.05 * res[0][2] + 2           # same Krylov sequence up to rounding
+        if which == "2.5nm":
+            import scipy.sparse as sp
+            from oracle import oracle as oc
+            o = oc.OracleKMC(structure.element, structure.x, structure.y, structure.z, p)
+            o.set_laplace_potential(Vd); o.update_charge(); o.update_potential(Vd)
+            rp, ci, data, rhs = o._last_K
+            K = sp.csr_matrix((data, ci, rp))
+            for on in (0, 1):
+                assert np.abs(K @ res[on][0][n:dev.N - n] - rhs).max() <= 1e-9, on
+    finally:
+        L.dkmc_set_k_blocked(1); L.dkmc_set_cg_tolerance(1e-6)
+
+
 def test_soak_60_supersteps_against_the_oracle(cell_2p5, hip):
     """60 coupled supersteps of the 2.5 nm device with global heating on, HIP path against the CPU oracle step by step (the long-trajectory
     check that used to live in tools/soak_vs_oracle.py): the same executed events (slot, i, j, type), charges and elements bit for bit,

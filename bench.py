@@ -600,6 +600,7 @@ def main():
     ap.add_argument("--no-cpp-host", action="store_true", help="N = 1: skip the cross-check line through the C++ host driver")
     ap.add_argument("--no-pmc", action="store_true", help="N = 1: do not measure roofline.traffic (two rocprofv3 --pmc child runs)")
     ap.add_argument("--no-log-tolerance", action="store_true", help="N = 1: skip the at_log_tolerance block")
+    ap.add_argument("--peer-exchange", action="store_true", help="N > 1, sharded: exchange the block loop's slots by peer writes over hipIpc-mapped buffers instead of the transport's all-gather (also DKMC_PEER_EXCHANGE=1)")
     ap.add_argument("--k-blocked", type=int, default=1, help="dkmc_set_k_blocked: 1 = library default (K-CG on the blocked form up to 262 144 rows), 0 = CSR positions")
     ap.add_argument("--x-block", type=int, default=16, help="dkmc_set_x_block: 16 = library default (block-CG), 1 = the reference's single-vector CG on X")
     ap.add_argument("--cg-tol", type=float, default=None, help="override the CG tolerance (default: the reference's 1e-6)")
@@ -832,8 +833,13 @@ def main():
                 transport = parallel.attach_solver_comm("host", group=dist.new_group(backend="gloo"))
                 transport_note = "in-library RCCL communicator failed to attach (%s); exchanges go through pinned host memory + gloo" % (why or "on a peer rank")
             sim = Sim(name, devname, x_format=1)
+            # opt-in: the one-shot peer-write exchange for the block loop's sweeps (hipIpc-mapped buffers, push + signal + bounded wait;
+            # validated with two processes on ONE GPU only, hence not the default beside RCCL).  All ranks decide together.
+            peer_on = False
+            if args.peer_exchange or os.environ.get("DKMC_PEER_EXCHANGE") == "1":
+                peer_on = parallel.attach_peer_exchange(16 * (int(sim.dev.N_atom) + 2) + 2)
         else:
-            transport = "none"
+            transport = "none"; peer_on = False
             sim = Sim(name, devname, kmc_seed=parallel.replica_kmc_seed(1, rank))
         big = sim.s.N > 150000
         warm = args.warmup if not big else min(args.warmup, 1)
@@ -867,8 +873,9 @@ def main():
                 "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": name, "sites": res["sites"], "nn": res["nn"], "atoms": res["atoms"], "Vd": VD,
                            "phases": "charge+potential+rates+current+heat",
-                           "parallelism": ("one simulation; X generated/stored/streamed in %d per-rank shares, 1 all-reduce of |S| doubles per CG iteration"
+                           "parallelism": ("one simulation; X generated/stored/streamed in %d per-rank shares, one exchange of 16 |S| + 2 doubles per block-CG sweep, slots added in rank order"
                                            if sharded else "replicas x%d") % world,
+                           "exchange": ("peer-write over hipIpc-mapped buffers (opt-in)" if peer_on else "all-gather of the transport") if sharded else None,
                            "transport": transport, "transport_note": transport_note, "x_format": "tiled", "current_warm_start": 0, "cg_tol": sim.p.cg_tol,
                            "comm_ranks": min(i[0] for i in infos), "comm_rank_ids": sorted(i[1] for i in infos),
                            "comm_transport_code": sorted(set(i[2] for i in infos)), "process_group_world": world, "process_group_backend": backend},
@@ -877,6 +884,7 @@ def main():
                              "subblocks_rank0": int(st["xt_local_subblocks"]), "rank0_share": round(share, 4),
                              "exchange_us": round(sim.prof["comm_ms"] / max(sim.prof["comm_n"], 1) * 1e3, 2),
                              "exchanged_doubles": int(st["comm_count_per_rank"]),
+                             "peer_exchange": parallel.peer_exchange_info() if peer_on else None,
                              "replicated_phases": "charge, K-CG, event loop, neighbour part of X (all < 5 % of a step at this size); pair sum: site slabs + all-gather"},
                 "replicas": replicas, "single_gpu_reference": None,
             }

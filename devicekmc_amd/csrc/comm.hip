@@ -72,6 +72,7 @@ static int rccl_open()
     return 0;
 }
 
+static void peer_release();
 #define RCCLCHK(x) do { int r__ = (x); if (r__ != 0) return dkmc_fail(42, g_comm.error_string(r__), __FILE__, __LINE__); } while (0)
 
 extern "C" int dkmc_comm_unique_id(char *id128)
@@ -88,6 +89,7 @@ extern "C" int dkmc_comm_destroy(void)
     Comm &c = g_comm;
     if (c.transport == DKMC_COMM_RCCL && c.nccl) { (void)hipStreamSynchronize(eng().stream); c.comm_destroy(c.nccl); c.nccl = nullptr; }
     if (c.stage) { (void)hipHostFree(c.stage); c.stage = nullptr; c.stage_bytes = 0; }
+    peer_release();
     c.transport = DKMC_COMM_NONE; c.nranks = 1; c.rank = 0; c.cb = nullptr; c.cb_user = nullptr;
     eng().x_iter_hint = 0;         // rank-local history must not shape the launch plan of a sharded solve
     return 0;
@@ -127,6 +129,157 @@ extern "C" int dkmc_comm_allgather_host(double *buf, size_t count)
     Comm &c = g_comm;
     if (c.transport != DKMC_COMM_HOST) return dkmc_fail(44, "comm: host transport not attached", __FILE__, __LINE__);
     if (int rc = c.cb(buf, count * sizeof(double), c.rank, c.nranks, c.cb_user)) return dkmc_fail(45, "comm: all-gather callback failed", __FILE__, __LINE__);
+    return 0;
+}
+
+#include <algorithm>
+
+// ---- one-shot peer-write exchange of the sharded block-CG ----------------------------------------------------------
+// Beside either transport: every rank owns an exchange buffer of 2 x nranks slots and a row of sequence words, both exported with
+// hipIpcGetMemHandle and mapped by every peer once (dkmc_comm_peer_prepare -> handles exchanged by the host through the process group ->
+// dkmc_comm_peer_attach).  One exchange = three small launches on the engine's stream, no collective call and no host synchronisation:
+//   k_peer_push    copies this rank's slot into the same slot of every peer's buffer (direct stores over xGMI / within the device),
+//   k_peer_signal  after a system-scope fence, stores the exchange's sequence number into word `me` of every rank's sequence row,
+//   k_peer_wait    one lane per rank polls this rank's own row until every word has reached the sequence number (bounded: after
+//                  PEER_TIMEOUT_S it gives up, marks the solve aborted and the caller returns an error instead of hanging the GPU).
+// The slots are then added IN RANK ORDER by the caller's kernel (k_xtb_rows<., 1>): identical bits on every rank by construction.
+// Two slot sets alternate (parity of the exchange): a peer may push exchange n + 1 while this rank still reads the slots of n; it cannot
+// push n + 2 before this rank has pushed n + 1, i.e. finished reading n.
+// Tested with two processes sharing ONE GPU (tests/test_dist_sharded.py); across GPUs the mapping is the one RCCL uses, but polling a
+// word in coarse-grained device memory written by a peer GPU has not been run here -- which is why the RCCL all-gather stays the
+// default transport of the exchange and this one is opt-in (DKMC_PEER_EXCHANGE=1 / parallel.attach_peer_exchange).
+#define PEER_MAXR 16
+#define PEER_TIMEOUT_S 10.0
+struct Peer {
+    bool ready = false;
+    size_t slot = 0;                                   // doubles per slot
+    double *buf = nullptr;                             // local: 2 * nranks * slot doubles
+    unsigned long long *flags = nullptr;               // local: PEER_MAXR words (sequence number of the last complete push of rank r)
+    void *mapped[2 * PEER_MAXR] = {};                  // what hipIpcOpenMemHandle returned (closed on destroy)
+    double **rbuf_d = nullptr; unsigned long long **rflags_d = nullptr;      // device tables of the nranks buffers / sequence rows
+    unsigned long long seq = 0;
+    long long exchanges = 0; double ms = 0.0; int timed = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+};
+static Peer g_peer;
+
+static void peer_release()
+{
+    Peer &p = g_peer;
+    if (p.ready || p.buf) (void)hipStreamSynchronize(eng().stream);
+    for (auto &m : p.mapped) if (m) { (void)hipIpcCloseMemHandle(m); m = nullptr; }
+    if (p.buf) (void)hipFree(p.buf);
+    if (p.flags) (void)hipFree(p.flags);
+    if (p.rbuf_d) (void)hipFree(p.rbuf_d);
+    if (p.rflags_d) (void)hipFree(p.rflags_d);
+    for (auto &ev : p.ev) if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+    p = Peer{};
+}
+
+// allocates this rank's exchange buffer and sequence row; handles128 receives the two IPC handles (64 bytes each)
+extern "C" int dkmc_comm_peer_prepare(size_t slot_doubles, char *handles128)
+{
+    Comm &c = g_comm; Peer &p = g_peer;
+    if (c.transport == DKMC_COMM_NONE || c.nranks > PEER_MAXR || slot_doubles == 0 || !handles128)
+        return dkmc_fail(47, "comm: peer exchange needs an attached communicator of at most 16 ranks", __FILE__, __LINE__);
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+    peer_release();
+    p.slot = slot_doubles;
+    HIPCHK(hipMalloc((void **)&p.buf, (size_t)2 * c.nranks * slot_doubles * 8));
+    HIPCHK(hipMalloc((void **)&p.flags, PEER_MAXR * sizeof(unsigned long long)));
+    HIPCHK(hipMemset(p.flags, 0, PEER_MAXR * sizeof(unsigned long long)));
+    hipIpcMemHandle_t h[2];
+    HIPCHK(hipIpcGetMemHandle(&h[0], p.buf));
+    HIPCHK(hipIpcGetMemHandle(&h[1], p.flags));
+    memcpy(handles128, &h[0], 64); memcpy(handles128 + 64, &h[1], 64);
+    return 0;
+}
+// all_handles: nranks x 128 bytes in rank order (this rank's own entry is ignored).  Every rank must have called prepare with the same slot size.
+extern "C" int dkmc_comm_peer_attach(const char *all_handles)
+{
+    Comm &c = g_comm; Peer &p = g_peer;
+    if (!p.buf || !all_handles) return dkmc_fail(47, "comm: peer exchange not prepared", __FILE__, __LINE__);
+    double *rb[PEER_MAXR] = {}; unsigned long long *rf[PEER_MAXR] = {};
+    for (int r = 0; r < c.nranks; ++r) {
+        if (r == c.rank) { rb[r] = p.buf; rf[r] = p.flags; continue; }
+        hipIpcMemHandle_t h[2];
+        memcpy(&h[0], all_handles + (size_t)r * 128, 64); memcpy(&h[1], all_handles + (size_t)r * 128 + 64, 64);
+        HIPCHK(hipIpcOpenMemHandle(&p.mapped[2 * r], h[0], hipIpcMemLazyEnablePeerAccess));
+        HIPCHK(hipIpcOpenMemHandle(&p.mapped[2 * r + 1], h[1], hipIpcMemLazyEnablePeerAccess));
+        rb[r] = (double *)p.mapped[2 * r]; rf[r] = (unsigned long long *)p.mapped[2 * r + 1];
+    }
+    HIPCHK(hipMalloc((void **)&p.rbuf_d, sizeof(rb))); HIPCHK(hipMalloc((void **)&p.rflags_d, sizeof(rf)));
+    HIPCHK(hipMemcpy(p.rbuf_d, rb, sizeof(rb), hipMemcpyHostToDevice)); HIPCHK(hipMemcpy(p.rflags_d, rf, sizeof(rf), hipMemcpyHostToDevice));
+    HIPCHK(hipEventCreate(&p.ev[0])); HIPCHK(hipEventCreate(&p.ev[1]));
+    p.seq = 0; p.ready = true;
+    return 0;
+}
+extern "C" int dkmc_comm_peer_detach(void) { peer_release(); return 0; }
+// ready; doubles per slot; exchanges since attach; mean duration of the timed ones [us] (profiling on: HIP events round push .. wait)
+extern "C" int dkmc_comm_peer_info(int *ready, long long *slot_doubles, long long *exchanges, double *mean_us)
+{
+    const Peer &p = g_peer;
+    if (ready) *ready = p.ready ? 1 : 0;
+    if (slot_doubles) *slot_doubles = (long long)p.slot;
+    if (exchanges) *exchanges = p.exchanges;
+    if (mean_us) *mean_us = p.timed ? p.ms * 1e3 / p.timed : 0.0;
+    return 0;
+}
+
+__global__ void k_peer_push(int me, double *const *rbuf, size_t off, size_t count)
+{
+    const int r = blockIdx.y;
+    if (r == me) return;
+    const double *src = rbuf[me] + off;
+    double *dst = rbuf[r] + off;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    __threadfence_system();
+}
+__global__ void k_peer_signal(int nr, int me, unsigned long long *const *rflags, unsigned long long seq)
+{
+    __threadfence_system();
+    const int r = threadIdx.x;
+    if (r < nr) __hip_atomic_store(&rflags[r][me], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_peer_wait(int nr, const unsigned long long *flags, unsigned long long seq, long long limit_ticks, int *ctrl_done, int *ctrl_aborted, int *ctrl_timeout, int stamp)
+{
+    const int r = threadIdx.x;
+    bool ok = true;
+    if (r < nr) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(&flags[r], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            if (wall_clock64() - t0 > limit_ticks) { ok = false; break; }
+            __builtin_amdgcn_s_sleep(32);
+        }
+    }
+    if (!ok) { *ctrl_timeout = 1; *ctrl_aborted = 1; *ctrl_done = stamp; }      // every kernel of the loop is gated by `done`
+    __threadfence_system();
+}
+
+int comm_peer_ready(size_t count) { return g_peer.ready && count <= g_peer.slot; }
+// base of the nranks slots of this exchange's parity; slot r starts at r * count (count = the caller's doubles per rank <= the slot size)
+double *comm_peer_slots(int parity) { return g_peer.buf + (size_t)(parity & 1) * g_comm.nranks * g_peer.slot; }
+// this rank's slot of `parity` has been written by kernels already queued on the engine's stream; on return (asynchronously) all slots are complete
+int comm_peer_exchange(int parity, size_t count, int *ctrl_done, int *ctrl_aborted, int *ctrl_timeout, int stamp)
+{
+    Comm &c = g_comm; Peer &p = g_peer; Engine &e = eng(); hipStream_t st = e.stream;
+    if (!comm_peer_ready(count)) return dkmc_fail(47, "comm: peer exchange not attached or slot too small", __FILE__, __LINE__);
+    const size_t off = (size_t)(parity & 1) * c.nranks * p.slot + (size_t)c.rank * count;
+    // (slot r of a parity set starts at r * count: the layout the all-gather produces)
+    const bool timed = e.profiling != 0 && (p.exchanges % 16) == 0;
+    if (timed && p.exchanges >= 16) {          // the pair recorded 16 exchanges ago has long completed
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.ev[0], p.ev[1]) == hipSuccess) { p.ms += ms; ++p.timed; } else (void)hipGetLastError();
+    }
+    if (timed) HIPCHK(hipEventRecord(p.ev[0], st));
+    ++p.seq; ++p.exchanges;
+    const int bx = (int)std::min<size_t>((count + 255) / 256, 64);
+    hipLaunchKernelGGL(k_peer_push, dim3(bx, c.nranks), dim3(256), 0, st, c.rank, (double *const *)p.rbuf_d, off, count);
+    hipLaunchKernelGGL(k_peer_signal, dim3(1), dim3(64), 0, st, c.nranks, c.rank, (unsigned long long *const *)p.rflags_d, p.seq);
+    hipLaunchKernelGGL(k_peer_wait, dim3(1), dim3(64), 0, st, c.nranks, (const unsigned long long *)p.flags, p.seq, (long long)(PEER_TIMEOUT_S * 1e8),
+                       ctrl_done, ctrl_aborted, ctrl_timeout, stamp);
+    if (timed) HIPCHK(hipEventRecord(p.ev[1], st));
+    KCHK();
     return 0;
 }
 

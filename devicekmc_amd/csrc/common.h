@@ -165,6 +165,9 @@ int comm_allgather_f64(double *buf, size_t count);     // in place on the engine
 int comm_allreduce_sum_f64(double *buf, size_t count); // in place; the sum over the ranks (grouping of the additions is the transport's)
 int comm_agree(int local_rc, const char *what);         // agreement point: non-zero on EVERY rank if any rank passed a non-zero local_rc (comm.hip)
 int comm_agree_count();
+int comm_peer_ready(size_t count);                      // the one-shot peer-write exchange is attached and its slots hold `count` doubles (comm.hip)
+double *comm_peer_slots(int parity);
+int comm_peer_exchange(int parity, size_t count, int *ctrl_done, int *ctrl_aborted, int *ctrl_timeout, int stamp);
 int comm_bcast0_f64(double *buf, size_t count);        // in place; every rank ends with rank 0's bits
 
 // shared primitives (scan.hip)

@@ -930,9 +930,11 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
     const int nr = sharded ? comm_nranks() : 1, me = sharded ? comm_rank() : 0;
     double *xbuf = nullptr;
     const size_t xcount = (size_t)A.ns * so + 2;
+    // exchange: the one-shot peer-write exchange when it is attached (comm.hip: push + signal + wait, no collective call), else one all-gather
+    const bool peer = sharded && comm_peer_ready(xcount);
+    int xpar = 0;
     if (sharded) {
-        xbuf = (double *)scratch(S_CG_XCHG, xcount * nr * 8);
-        if (!xbuf) return e.err_code;
+        if (!peer) { xbuf = (double *)scratch(S_CG_XCHG, xcount * nr * 8); if (!xbuf) return e.err_code; }
         hipLaunchKernelGGL(k_xtb_set_sharded, dim3(1), dim3(1), 0, st, A.ctrl);
     }
     int local_fail = 0;
@@ -973,13 +975,17 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
     // collectives must not leave the peers in the all-reduce: it still joins, with the abort word set, and every rank leaves together.
     auto rows = [&](bool init, int itn, hipEvent_t e2, hipEvent_t e3) -> int {
         if (sharded) {
+            if (peer) { xbuf = comm_peer_slots(xpar); }
             hipLaunchKernelGGL(k_xtb_fold_local, dim3(std::max(A.nK, 1)), dim3(XT_NT), 0, st, A.ns, A.nK, A.nW, so, A.wrange, A.nitem_w, (const double *)rowpartB,
                                (const double *)colpartB, xbuf + me * xcount, (const XCtrl *)A.ctrl, 1, A.w_lo, A.w_hi);
             if (hipGetLastError() != hipSuccess || local_fail) {
                 if (!local_fail) local_fail = dkmc_fail(92, "block-CG: launch failed between two collectives", __FILE__, __LINE__);
                 hipLaunchKernelGGL(k_xtb_abort_word, dim3(1), dim3(1), 0, st, A.ctrl, xbuf + me * xcount, (size_t)A.ns * so + 1);
             }
-            if (int rcx = comm_allgather_f64(xbuf, xcount)) return rcx;
+            if (peer) {
+                if (int rcx = comm_peer_exchange(xpar, xcount, &A.ctrl->done, &A.ctrl->aborted, &A.ctrl->xchg_timeout, itn + 2)) return rcx;
+                xpar ^= 1;
+            } else if (int rcx = comm_allgather_f64(xbuf, xcount)) return rcx;
             if (init) hipLaunchKernelGGL((k_xtb_rows<1, 1>), dim3(ng), dim3(XT_NT), 0, st, XB_ROWS_ARGS(itn));
             else hipExtLaunchKernelGGL((k_xtb_rows<0, 1>), dim3(ng), dim3(XT_NT), 0, st, e2, e3, 0, XB_ROWS_ARGS(itn));
         } else {
@@ -1028,6 +1034,7 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
     }
 #undef XB_ROWS_ARGS
     if (local_fail) return local_fail;                                         // the peers were told (abort word)
+    if (h.xchg_timeout) return dkmc_fail(48, "block-CG: the peer-write exchange timed out waiting for a peer's slot", __FILE__, __LINE__);
     if (h.aborted) return dkmc_fail(46, "a peer rank aborted the sharded current solve", __FILE__, __LINE__);
     if (e.err_code) return e.err_code;
     HIPCHK(hipMemcpyAsync(A.y, y0, (size_t)m * 8, hipMemcpyDeviceToDevice, st));

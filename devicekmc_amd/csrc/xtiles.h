@@ -15,7 +15,7 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 
 struct __attribute__((aligned(16))) XTile { int k, w; unsigned mask; int soff; };   // cell (k, w); present sub-blocks; first sub-block slot
 struct __attribute__((aligned(32))) XItem { int t0, t1, w, c, k0; unsigned mask0; int soff0, pad; };   // tiles [t0, t1) of strip w; c = position of the run in its strip; descriptor of tile t0; pad = record of its column sums, colpart[pad * 256]: the run's own (c = 0; pad = its index in the item list) or, on one GPU, one record per aligned group of four runs -- the four waves of a workgroup (c = 1; pad = index / 4; every strip's run count padded to a multiple of four with empty runs)
-struct XCtrl { double rr[2]; int done_local, sharded; int done; int iters; int abort_local, aborted; int pad[2]; };
+struct XCtrl { double rr[2]; int done_local, sharded; int done; int iters; int abort_local, aborted; int pad[2]; int xchg_timeout, pad2; };
 // `done` (non-zero) gates every kernel of the loop; see k_xt_step for its iteration stamp.  Single GPU: set by the step kernel.  Sharded solve: the direction kernel only sets
 // done_local; rank 0's done_local travels in the all-reduced buffer (slot ns) and k_xt_rows_apply turns it into `done` on every
 // rank in the same iteration -- all control flow derives from data every rank received from the same collective, so the ranks

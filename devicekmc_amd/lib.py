@@ -105,6 +105,10 @@ SYMBOLS = {
     "dkmc_debug_inject_fault": (None, [_I, _I]),
     "dkmc_comm_unique_id": (_I, [C.c_char_p]),
     "dkmc_comm_init_rccl": (_I, [_I, _I, C.c_char_p]),
+    "dkmc_comm_peer_prepare": (_I, [C.c_size_t, C.c_char_p]),
+    "dkmc_comm_peer_attach": (_I, [C.c_char_p]),
+    "dkmc_comm_peer_detach": (_I, []),
+    "dkmc_comm_peer_info": (_I, [C.POINTER(C.c_int), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_double)]),
     "dkmc_comm_init_host": (_I, [_I, _I, ALLGATHER_FN, vp]),
     "dkmc_comm_allgather_host": (_I, [vp, C.c_size_t]),
     "dkmc_comm_info": (_I, [C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),

@@ -122,6 +122,46 @@ def attach_solver_comm(transport=None, group=None):
     return transport
 
 
+def attach_peer_exchange(slot_doubles, group=None):
+    """One-shot peer-write exchange of the sharded block-CG beside the attached communicator (csrc/comm.hip): every rank exports its
+    exchange buffer (hipIpc), the handles travel through the process group, every rank maps every peer's buffer.  slot_doubles: capacity of
+    a slot, >= 16 |S| + 2 of the solves to come (a solve whose slot does not fit falls back to the communicator's all-gather on every rank
+    alike).  All ranks must sit on one node.  Returns True on every rank, or False on every rank if any rank could not map a peer."""
+    import ctypes
+    from . import lib
+    L = lib.load()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    mine = ctypes.create_string_buffer(128)
+    ok = L.dkmc_comm_peer_prepare(int(slot_doubles), mine) == 0
+    on_gpu = dist.is_initialized() and dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    t = torch.frombuffer(bytearray(mine.raw), dtype=torch.uint8).to(dev)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(parts, t, group=group)
+    else:
+        parts = [t]
+    allh = b"".join(bytes(x.cpu().numpy().tobytes()) for x in parts)
+    ok = ok and L.dkmc_comm_peer_attach(ctypes.create_string_buffer(allh, len(allh))) == 0
+    flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device=dev)
+    if world > 1:
+        dist.all_reduce(flag, group=group)
+    if int(flag.item()) != 0:
+        L.dkmc_clear_error()
+        L.dkmc_comm_peer_detach()
+        return False
+    return True
+
+
+def peer_exchange_info():
+    import ctypes
+    from . import lib
+    r, s, n, us = ctypes.c_int(0), ctypes.c_longlong(0), ctypes.c_longlong(0), ctypes.c_double(0.0)
+    lib.load().dkmc_comm_peer_info(ctypes.byref(r), ctypes.byref(s), ctypes.byref(n), ctypes.byref(us))
+    return {"ready": bool(r.value), "slot_doubles": s.value, "exchanges": n.value, "mean_us": us.value}
+
+
 def detach_solver_comm():
     global _solver_cb
     from . import lib

@@ -335,6 +335,15 @@ int dkmc_comm_init_host(int nranks, int rank, dkmc_allgather_fn fn, void *user);
 int dkmc_comm_allgather_host(double *host_buf, size_t count_per_rank);  /* the callback transport's host half (no GPU needed) */
 int dkmc_comm_info(int *nranks, int *rank, int *transport);
 int dkmc_comm_destroy(void);
+/* One-shot peer-write exchange of the sharded block-CG (csrc/comm.hip): beside an attached communicator, every rank
+ * exports an exchange buffer of 2 x nranks slots of slot_doubles doubles and a row of sequence words (hipIpc); prepare returns this rank's
+ * two handles (128 bytes), the host all-gathers them through its process group and hands all of them (nranks x 128 bytes, rank order) to
+ * attach.  A sweep's exchange is then push + signal + bounded wait on the engine's stream and the slots are added in rank order; a solve
+ * whose slots do not fit uses the communicator's all-gather.  Tested with two processes on one GPU; opt-in.  The reference has no counterpart. */
+int dkmc_comm_peer_prepare(size_t slot_doubles, char *handles128);
+int dkmc_comm_peer_attach(const char *all_handles);
+int dkmc_comm_peer_detach(void);
+int dkmc_comm_peer_info(int *ready, long long *slot_doubles, long long *exchanges, double *mean_us);
 
 #ifdef __cplusplus
 }

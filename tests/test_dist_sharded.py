@@ -183,6 +183,80 @@ def test_sharded_error_path_returns_on_every_rank():
     assert s0[3][1] == s1[3][1] and s0[3][1] != 0.0
 
 
+def _peer_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    from devicekmc_amd import host, lib, parallel, params, structure
+    from devicekmc_amd.lib import DeviceKMCError
+    parallel.init("gloo")
+    torch.cuda.set_device(0)
+    L = lib.load()
+    assert parallel.attach_solver_comm() == "host"
+    got_ag = _supersteps(2, fmt=1, big=True)                    # exchange of the block loop = the communicator's all-gather
+    ok = parallel.attach_peer_exchange(16 * 9000 + 2)           # |S| = 8 352 at 85 k sites
+    L.dkmc_set_profiling(1)
+    got_peer = _supersteps(2, fmt=1, big=True) if ok else None  # exchange = push + signal + wait over hipIpc-mapped buffers
+    L.dkmc_set_profiling(0)
+    info = parallel.peer_exchange_info()
+    # a rank-local failure on the host side of a block iteration, with the peer exchange carrying the abort word; then a clean step
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    s = structure.load_structure(os.path.join(g, "device_2.5nm.npz"))
+    p = params.KMCParameters(); p.solve_heating_global = True
+    dev = host.Device(s, p); sim = host.KMCProcess(dev, p.freq)
+    gb = dev.make_gpubuf("cuda:0")
+    dev.setLaplacePotential(gb, p, Vd); gb.sync_HostToGPU(dev)
+    seen = []
+    for phase, it in ((3, 5), (0, 0)):
+        dev.updateCharge(gb); dev.updatePotential(gb, p, Vd, 0)
+        sim.executeKMCStep(gb, dev)
+        if rank == 1 and phase:
+            L.dkmc_debug_inject_fault(phase, it)
+        try:
+            dev.updatePower(gb, p, Vd)
+            seen.append((0, dev.imacro))
+        except DeviceKMCError as exc:
+            seen.append((1, str(exc)))
+            L.dkmc_clear_error()
+        parallel.barrier()
+    info2 = parallel.peer_exchange_info()
+    parallel.detach_solver_comm()
+    q.put((rank, ok, got_ag, got_peer, info, info2, seen))
+    parallel.finalize()
+
+
+def test_peer_write_exchange_two_ranks_one_gpu():
+    """The one-shot peer-write exchange of the sharded block-CG (csrc/comm.hip): two processes sharing cuda:0 map each
+    other's exchange buffers over hipIpc; a sweep's exchange is push + signal + bounded wait on the stream, and every rank adds the slots in
+    rank order.  Same slots, same order as with the communicator's all-gather: the two supersteps at 85 k sites give the SAME BITS as over
+    the all-gather, on both ranks; the abort word of a failing rank still ends the loop on both ranks; the next clean step agrees."""
+    import __graft_entry__ as g
+    g.build()
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_peer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    out = sorted((q.get(timeout=600) for _ in range(world)), key=lambda t: t[0])
+    for p in procs: p.join(120); assert p.exitcode == 0
+    (_, ok0, ag0, pe0, info0, info0b, seen0), (_, ok1, ag1, pe1, info1, info1b, seen1) = out
+    assert ok0 and ok1
+    print("peer exchange (two processes, one GPU):", info0, info1, "sweeps", pe0[1])
+    for ag, pe in ((ag0, pe0), (ag1, pe1), (ag0, pe1)):
+        assert pe[0] == ag[0] and pe[1] == ag[1]                      # dt, I_macro, T_bg and sweep counts of every step: exact
+        for n in ag[2]:
+            assert np.array_equal(pe[2][n], ag[2][n]), n
+    assert pe0[3]["xb_width"] == 16 and pe0[3]["comm_ranks"] == 2
+    for info in (info0, info1):
+        assert info["ready"] and info["slot_doubles"] == 16 * 9000 + 2
+        assert info["exchanges"] >= sum(pe0[1]) > 0                   # one exchange per sweep (+ the first product of each solve)
+        assert 0.0 < info["mean_us"] < 5e4, info
+    # the fault path: both ranks return an error, the clean step after it runs on both and agrees; the small device used the exchange too
+    assert [k for k, _ in seen0] == [1, 0] and [k for k, _ in seen1] == [1, 0], (seen0, seen1)
+    assert "peer rank" in seen0[0][1] and "injected fault (block-CG iteration" in seen1[0][1]
+    assert seen0[1][1] == seen1[1][1] != 0.0
+    assert info0b["exchanges"] > info0["exchanges"]
+
+
 def _solo_worker(rank, q, nsteps):
     import torch
     torch.cuda.set_device(0)

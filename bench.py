@@ -778,6 +778,8 @@ def main():
                 if sp.cold:
                     r["cold_step"] = {"ms": round(sp.cold[0] * 1e3, 1), "cg_sweeps_X": sp.cold[1]}
                 if nocur:
+                    for kx in ("cg_iters_X", "X_nnz", "tunnelling_set"):          # no current solve in these steps
+                        r["per_step"].pop(kx, None)
                     r["what"] = ("a crossbar-SIZED stack with the current solve off, as every shipped crossbar parameter set runs "
                                  "(structures/crossbars/*/parameters.txt: solve_current = 0): charge + potential (K-CG + pair sum) + event loop")
                     r["us_per_executed_event"] = round(r["split_ms"]["rates"] * 1e3 / max(r["per_step"]["events"], 1), 1)

@@ -948,7 +948,8 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
     double prof_long_ms = 0.0, prof_short_ms = 0.0; int prof_long_n = 0, prof_short_n = 0;
     // neighbour part beside the tile kernel (see XbSide): only in a sharded solve, where a rank's tile pass is 1 / N of the sweep and the
     // (replicated) neighbour part would otherwise be a serial 0.3 ms behind it.  On ONE GPU the overlap was measured and does not pay: the two
-    // kernels share the memory system, the tile pass slows by what the neighbour part takes (9.4e5 sites: 3.95 + 0 against 3.65 + 0.32 ms).
+    // kernels share the memory system, the tile pass slows by what the neighbour part takes (9.4e5 sites: 3.95 + 0 against 3.65 + 0.32 ms; 85 k sites,
+    // where both are latency-bound: 15.0 against 13.5 ms per superstep -- the two event hand-overs per sweep cost more than the overlap gains).
     const bool side = sharded && m > 20000 && ntb > 0 && xtb_side_init() == 0;
     auto product = [&](hipEvent_t e0, hipEvent_t e1) {
         int sl = 0;

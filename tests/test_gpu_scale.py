@@ -28,13 +28,15 @@ Vd = 5.0
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _fresh(k):
+def _fresh(k, solve_current=True):
     sys.path.insert(0, ROOT)
     from bench import make_workload
     from devicekmc_amd import host, lib
     L = lib.load()
     L.dkmc_set_x_format(1); L.dkmc_set_current_warm_start(0)
     s, p = make_workload("tile:%d" % k)
+    if not solve_current:
+        p.solve_current = False; p.solve_heating_global = False
     dev = host.Device(s, p, gpu_neighbors="cuda:0")
     sim = host.KMCProcess(dev, p.freq)
     gb = dev.make_gpubuf("cuda:0")
@@ -122,3 +124,66 @@ def test_tile10_full_superstep_properties():
     dt_b = _superstep(dev2, sim2, gb2, p2, 0)
     assert (dt_b, dev2.imacro, dev2.T_bg) == trace0
 
+
+
+@pytest.mark.skipif(os.environ.get("DKMC_SLOW_TESTS") != "1", reason="5 min of CPU oracle at 3.8e6 sites (event table, K assembly): DKMC_SLOW_TESTS=1; "
+                    "the run of round 4 is profiles/r04_test_tile20_current_off.log")
+def test_tile20_current_off_first_superstep():
+    """A crossbar-SIZED stack with the current solve off, as every shipped crossbar parameter set runs (structures/crossbars/*/
+    parameters.txt: solve_current = 0; configs[4] is 3.8e6 sites): the 2.5 nm cell tiled 20 x 20, 3 759 600 sites.  A superstep is then
+    charge + potential (K-CG on 3.6e6 rows, on the CSR positions: above the size of the blocked form; pair sum over 3.4e4 charged sites) +
+    the event loop.  Against the oracle at full size: charges identical; the background potential meets the reference's stop test in the
+    TRUE scaled residual of the oracle's K (assembled from the same state; the oracle's own CG at this size would take minutes and prove
+    the same); the pair-sum potential on sampled sites equals the reference's all-pairs sum (gpu_solvers.h:259-265, no cut-off) to 1e-12;
+    and the oracle FED the GPU's potentials builds the same event table and executes the same (slot, i, j, type) sequence, same KMC time."""
+    import math
+    import ctypes as C
+    import scipy.sparse as sp
+    import torch
+    from oracle import oracle as oc
+    s, p, dev, sim, gb, host = _fresh(20, solve_current=False)
+    assert s.N == 3759600
+    o = oc.OracleKMC(s.element, s.x, s.y, s.z, p, neigh=dev.neigh_idx)
+    o.CB_edge[:] = gb.site_CB_edge.cpu().numpy()
+    dev.updateCharge(gb); o.update_charge()
+    assert np.array_equal(gb.site_charge.cpu().numpy(), o.charge)
+    dev.updatePotential(gb, p, Vd, 0)
+    torch.cuda.synchronize()
+    st = host.get_stats()
+    assert st["kcg_blocked"] == 0 and st["cg_rr_K"] <= p.cg_tol ** 2
+    pb, pc = gb.site_potential_boundary.cpu().numpy(), gb.site_potential_charge.cpu().numpy()
+    # ---- K phi = rhs in the oracle's K (okmc_k_assemble: potential_solver_gpu.cu:397-593 restated) ----
+    if o._K is None:
+        o.initialize_sparsity()
+    nl, m, ((rp, ci), (lrp, lci), (rrp, rci)) = o._K
+    data = np.zeros(len(ci)); rhs = np.zeros(m)
+    _p = oc._p
+    oc.lib().okmc_k_assemble(o.N, nl, nl, _p(o.element), _p(o.charge), _p(o.metals), len(o.metals), C.c_double(p.high_G), C.c_double(p.low_G), 0,
+                             _p(rp), _p(ci), _p(lrp), _p(lci), _p(rrp), _p(rci), C.c_double(-Vd / 2), C.c_double(Vd / 2), _p(data), _p(rhs))
+    K = sp.csr_matrix((data, ci, rp), shape=(m, m))
+    assert int(gb.c.Device_nnz) == len(ci) and m == s.N - 2 * nl
+    sres = (K @ pb[nl:nl + m] - rhs) / np.sqrt(K.diagonal())
+    assert np.linalg.norm(sres) <= 10 * p.cg_tol, np.linalg.norm(sres)
+    assert (pb[:nl] == -Vd / 2).all() and (pb[-nl:] == Vd / 2).all()
+    # ---- pair sum on sampled sites against the all-pairs sum of the reference ----
+    q = o.charge; cs = np.flatnonzero(q != 0)
+    assert len(cs) > 3e4
+    rng = np.random.default_rng(11)
+    erfc = np.vectorize(math.erfc)
+    worst, scale = 0.0, np.abs(pc).max()
+    for i in rng.choice(s.N, 48, replace=False):
+        d = np.sqrt((s.x[cs] - s.x[i]) ** 2 + (s.y[cs] - s.y[i]) ** 2 + (s.z[cs] - s.z[i]) ** 2)
+        keep = cs != i
+        r = 1e-10 * d[keep]
+        v = (q[cs][keep] * erfc(r / (p.sigma * math.sqrt(2.0))) * p.k * 1.60217663e-19 / r).sum()
+        worst = max(worst, abs(v - pc[i]))
+    assert worst <= 1e-12 * scale, (worst, scale)
+    # ---- events: the oracle fed these potentials ----
+    o.pot_boundary[:] = pb; o.pot_charge[:] = pc
+    _, dt = sim.executeKMCStep(gb, dev, want_log=True)
+    odt = o.execute_kmc_step()
+    assert len(sim.last_event_log) > 30
+    assert np.array_equal(sim.last_event_log, o.last_events["log"])
+    assert abs(dt - odt) <= 1e-12 * odt
+    gb.sync_GPUToHost(dev)
+    assert np.array_equal(dev.site_element, o.element) and np.array_equal(dev.site_charge, o.charge)

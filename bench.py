@@ -817,6 +817,8 @@ def main():
             # every rank advances the same simulation (same seeds); X is sharded.  RCCL over xGMI when the process group is nccl.  Should
             # the in-library communicator fail to come up on ANY rank (no multi-GPU node was available to try it on), all ranks fall back
             # together to the host-callback transport over a gloo group: slower exchanges, same results -- and the line says so.
+            # (Symmetric failures only: ncclCommInitRank is a collective, a single rank that throws before entering it leaves the others
+            # inside it -- the watchdog then ends the run with exit code 3.)
             import torch.distributed as dist
             ok, why = 1.0, ""
             try:

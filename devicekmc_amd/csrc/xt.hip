@@ -798,6 +798,55 @@ __global__ __launch_bounds__(XT_NT) void k_xt_step(int m, int it, const double *
     }
 }
 __global__ void k_xt_set_sharded(XCtrl *ctrl) { ctrl->sharded = 1; }
+// test aid (tests/test_gpu_parity.py; no counterpart in the reference): the stamped stop word of k_xt_step, deterministically.  Runs ONE launch of
+// iteration `it` over m elements (p = t = r = 1, y = 0, partial sums such that alpha = 1 and r'.r' > tol^2) with ctrl->done preset to
+// `done_word`, and counts the elements of y the launch updated.  0 and it + 2 (the value workgroup 0 of the SAME launch publishes when the
+// iteration converges) must update every element -- whichever workgroups see the word; it + 1 and below (a stop published by an
+// earlier iteration) must update none.
+__global__ void k_xt_dbg_fill(int m, double *p, double *t, double *y, double *r, double *sc, int *nsrank)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) { p[i] = 1.0; t[i] = 1.0; y[i] = 0.0; r[i] = 1.0; sc[i] = 1.0; nsrank[i] = -1; }
+}
+__global__ void k_xt_dbg_count(int m, const double *y, int *n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m && y[i] != 0.0) atomicAdd(n, 1);
+}
+extern "C" int dkmc_debug_step_stop_word(int m, int it, int done_word, int *updated, int *done_after)
+{
+    Engine &e = eng(); hipStream_t st = e.stream;
+    if (m < 1 || it < 0 || !updated) return dkmc_fail(13, "debug_step_stop_word: bad arguments", __FILE__, __LINE__);
+    double *buf = nullptr; int *ibuf = nullptr;
+    const size_t nd = (size_t)6 * m + 3 * XT_PSTRIDE + 2 * 512 + 8;
+    HIPCHK(hipMalloc((void **)&buf, nd * 8));
+    HIPCHK(hipMalloc((void **)&ibuf, ((size_t)m + 4) * 4 + sizeof(XCtrl)));
+    HIPCHK(hipMemsetAsync(buf, 0, nd * 8, st));
+    HIPCHK(hipMemsetAsync(ibuf, 0, ((size_t)m + 4) * 4 + sizeof(XCtrl), st));
+    double *p = buf, *t = p + m, *y = t + m, *r = y + m, *sc = r + m, *q = sc + m, *part3 = q + m, *prr = part3 + 3 * XT_PSTRIDE, *qS = prr + 2 * 512;
+    int *nsrank = ibuf, *cnt = ibuf + m;
+    XCtrl *ctrl = reinterpret_cast<XCtrl *>(ibuf + m + 4);
+    const int gv = xt_grid((m + XT_NT - 1) / XT_NT, 4, 512);
+    hipLaunchKernelGGL(k_xt_dbg_fill, dim3((m + 255) / 256), dim3(256), 0, st, m, p, t, y, r, sc, nsrank);
+    // p.t = m, r.t = -m / 2, t.t = m, r.r = m: alpha = 1, r'.r' = m: no convergence at any tolerance below m
+    const double h_part[3] = {(double)m, -0.5 * (double)m, (double)m}, h_rr = (double)m;
+    for (int k = 0; k < 3; ++k) HIPCHK(hipMemcpyAsync(part3 + k * XT_PSTRIDE, &h_part[k], 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(prr + 512 * (it & 1), &h_rr, 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(&ctrl->done, &done_word, 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_xt_step, dim3(gv), dim3(XT_NT), 0, st, m, it, (const double *)part3, 1, (const double *)(prr + 512 * (it & 1)), 1,
+                       prr + 512 * ((it + 1) & 1), p, (const double *)t, y, r, (const double *)sc, q, (const int *)nsrank, qS, ctrl, 1e-30);
+    hipLaunchKernelGGL(k_xt_dbg_count, dim3((m + 255) / 256), dim3(256), 0, st, m, (const double *)y, cnt);
+    int h_cnt = 0, h_done = 0;
+    HIPCHK(hipMemcpyAsync(&h_cnt, cnt, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&h_done, &ctrl->done, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    (void)hipFree(buf); (void)hipFree(ibuf);
+    KCHK();
+    *updated = h_cnt;
+    if (done_after) *done_after = h_done;
+    return e.err_code;
+}
+
 // a rank whose host side failed between two collectives: its contribution to the next all-reduce says so (whatever else it holds)
 __global__ void k_xt_abort_word(XCtrl *ctrl, double *xbuf, int ns) { ctrl->abort_local = 1; xbuf[ns + 1] = 1.0; }
 // test aid: make this rank fail once, in the assembly (phase 1) or on the host side of CG iteration `iteration` (phase 2)

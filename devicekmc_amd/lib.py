@@ -103,6 +103,7 @@ SYMBOLS = {
     "dkmc_xtb_check_product": (_I, [_I, c_dbl_p, c_dbl_p]),
     "dkmc_xtb_time_apply": (_I, [_I, _I, _I, c_dbl_p]),
     "dkmc_debug_inject_fault": (None, [_I, _I]),
+    "dkmc_debug_step_stop_word": (_I, [_I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dkmc_comm_unique_id": (_I, [C.c_char_p]),
     "dkmc_comm_init_rccl": (_I, [_I, _I, C.c_char_p]),
     "dkmc_comm_peer_prepare": (_I, [C.c_size_t, C.c_char_p]),

@@ -314,6 +314,9 @@ int dkmc_xtb_time_apply(int width, int variant, int reps, double *us);
  * returns non-zero (the failing rank its own code, the others 46) instead of blocking in a collective: the ranks agree on the
  * outcome of the local set-up before the first collective, and inside the loop an abort word travels with every all-reduce. */
 void dkmc_debug_inject_fault(int phase, int iteration);
+/* test aid: one launch of the CG step kernel of iteration `it` over m elements with the stop word preset to done_word; *updated = elements of y it
+ * changed (0 / it + 2: all; 1 ... it + 1: none), *done_after = the stop word afterwards (csrc/xt.hip: k_xt_step's iteration-stamped stop word) */
+int dkmc_debug_step_stop_word(int m, int it, int done_word, int *updated, int *done_after);
 
 /* ---- multi-GPU: one simulation advanced in lockstep by N processes, one GPU each (no reference counterpart) ----
  * While a communicator is attached, update_power_gpu_sparse generates, stores and streams the tunnelling block of X in per-rank

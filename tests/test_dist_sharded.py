@@ -257,31 +257,6 @@ def test_peer_write_exchange_two_ranks_one_gpu():
     assert info0b["exchanges"] > info0["exchanges"]
 
 
-def _solo_worker(rank, q, nsteps):
-    import torch
-    torch.cuda.set_device(0)
-    q.put((rank, _supersteps(nsteps, fmt=1, big=True)))
-
-
-def test_two_concurrent_single_gpu_solves_bit_identical():
-    """Two independent processes run the same single-GPU simulation (85 071 sites, tiled X) on ONE device at the same time.  Workgroups
-    of the two processes interleave on the CUs, so workgroups of one launch start far apart in time -- the situation in which a stop
-    flag written and read inside the same launch (k_xt_step) let late workgroups skip the last update of y.  Every observable of both
-    runs must be bit-identical to each other (the stop word carries the iteration it takes effect at)."""
-    import __graft_entry__ as g
-    g.build()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_solo_worker, args=(r, q, 4)) for r in range(2)]
-    for p in procs: p.start()
-    out = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
-    for p in procs: p.join(120); assert p.exitcode == 0
-    (_, a), (_, b) = out
-    assert a[0] == b[0] and a[1] == b[1], (a[0], b[0], a[1], b[1])
-    for n in a[2]:
-        assert np.array_equal(a[2][n], b[2][n]), n
-
-
 def test_emulated_shares_cover_the_tunnelling_block():
     """Shares of 2 ... 64 ranks built on one GPU as a sharded assembly builds them (dkmc_xt_check_shares): every stored sub-block and
     every work item in exactly one share; the ranks' partial row sums add up to the one-GPU tile pass."""

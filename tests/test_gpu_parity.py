@@ -1186,6 +1186,23 @@ def test_pair_sum_site_grouping_follows_the_structure(cell_2p5, hip):
     assert np.abs(gpu_sum(gb2) - want).max() <= 1e-12 * np.abs(want).max()
 
 
+@pytest.mark.parametrize("m", [1000, 85071, 700001])
+def test_step_kernel_stop_word_is_stamped_with_the_iteration(hip, m):
+    """The CG step kernel both reads and (workgroup 0) writes the stop word.  With a plain 0 / 1 flag a workgroup scheduled after workgroup 0
+    had published convergence skipped y += alpha p on the converging iteration: a partially updated, run-dependent solution (round 2).  The
+    word is stamped instead: d > 0 stops the kernels of iterations >= d - 1, and the value the converging iteration publishes is it + 2.
+    Deterministically (dkmc_debug_step_stop_word: one launch of iteration `it` with the word preset): 0 and it + 2 update EVERY element --
+    whichever workgroups see the word; it + 1 and anything below stop the launch as a whole (an earlier iteration converged)."""
+    host, L = hip
+    from devicekmc_amd.lib import check
+    for it in (0, 7):
+        for word, expect in ((0, m), (it + 2, m), (it + 3, m), (it + 1, 0), (1, 0)):
+            n, after = C.c_int(-1), C.c_int(-1)
+            check(L.dkmc_debug_step_stop_word(m, it, word, C.byref(n), C.byref(after)))
+            assert n.value == expect, (m, it, word, n.value)
+            assert after.value == word                       # r'.r' of the harness stays above the tolerance: the launch publishes nothing
+
+
 @pytest.mark.parametrize("which", ["2.5nm", "7.5nm"])
 def test_K_blocked_form_matches_csr_positions(cell_2p5, dev_7p5, hip, which):
     """The CG on K in its internal blocked order (rows sorted by x, one block per CU, q window in LDS: csrc/kcg.hip, the default up to

@@ -98,7 +98,7 @@ __device__ __forceinline__ double block_sum_all(double v, double *red)
 
 // blocked form of a K pattern (kcg.hip: kblocked_build, once per pattern; device arrays)
 struct KBlocked {
-    int m, R, nb, total, maxwin;
+    int m, R, nb, total, maxwin, maxints;      // maxints: ints of the largest block's padded rows
     long long winsum;   // columns in all windows together
     int *perm;          // [m] row of the blocked order -> row of the pattern
     int *pcol;          // [total] columns in the blocked order, rows padded to 64 / 32 entries with the row itself, diagonal left out

@@ -414,6 +414,7 @@ KBlocked *kblocked_build(const int *rp_d, const int *ci_d, int m, int nnz, const
     auto offdiag = [&](int r) { int n = 0; for (int p = rp[r]; p < rp[r + 1]; ++p) n += ci[p] != r; return n; };
     std::vector<int4> blk(nb);
     long long total = 0;
+    int maxints = 0;
     for (int b = 0; b < nb; ++b) {
         const int lo = b * R, hi = std::min(m, lo + R);
         for (int i = lo; i < hi; ++i) if (offdiag(perm[i]) > 64) return nullptr;
@@ -421,6 +422,7 @@ KBlocked *kblocked_build(const int *rp_d, const int *ci_d, int m, int nnz, const
         const int nl = (int)(mid - (perm.begin() + lo));
         blk[b].z = (int)total; blk[b].w = nl;
         total += (long long)nl * 64 + (long long)(hi - lo - nl) * 32;
+        maxints = std::max(maxints, nl * 64 + (hi - lo - nl) * 32);
     }
     std::vector<int> inv(m);
     for (int i = 0; i < m; ++i) inv[perm[i]] = i;
@@ -444,7 +446,7 @@ KBlocked *kblocked_build(const int *rp_d, const int *ci_d, int m, int nnz, const
         maxwin = std::max(maxwin, blk[b].y); winsum += blk[b].y;
     }
     if (maxwin > KB_MAXWIN) return nullptr;
-    KBlocked *kb = new KBlocked{m, R, nb, (int)total, maxwin, winsum, nullptr, nullptr, nullptr};
+    KBlocked *kb = new KBlocked{m, R, nb, (int)total, maxwin, maxints, winsum, nullptr, nullptr, nullptr};
     bool ok = hipMalloc((void **)&kb->perm, (size_t)m * 4) == hipSuccess && hipMalloc((void **)&kb->pcol, (size_t)total * 4) == hipSuccess &&
               hipMalloc((void **)&kb->blk, (size_t)nb * sizeof(int4)) == hipSuccess;
     ok = ok && hipMemcpy(kb->perm, perm.data(), (size_t)m * 4, hipMemcpyHostToDevice) == hipSuccess &&
@@ -500,6 +502,10 @@ int kcg_assemble_and_solve(int cb, int m, int N_left, const int *element, const 
         else hipLaunchKernelGGL((k_kc_assemble<0>), dim3(ab), dim3(KC_NT), 0, st, m, N_left, element, charge, ms, high_G, low_G, rp, ci, lrp, lci, rrp, rci, VL, VR, cf, diag, rhs);
         hipLaunchKernelGGL(k_kc_scale, dim3(vb), dim3(256), 0, st, m, (const double *)diag, s, rhs, y, q);
     }
+    static hipEvent_t evk[2]; static bool evk_ready = false;
+    const bool prof = e.profiling != 0;
+    if (prof && !evk_ready) { HIPCHK(hipEventCreate(&evk[0])); HIPCHK(hipEventCreate(&evk[1])); evk_ready = true; }
+    KCtrl h{};
     const int ga = kb ? kb->nb : kc_grid(m, KC_NT / 8, KC_NPA);         // product: one block of the blocked form, or 32 rows, per workgroup and pass
     const int gv = kc_grid(m, KC_NT, KC_NP);
     const int npa = (ga + KC_NT - 1) / KC_NT * KC_NT;
@@ -512,14 +518,8 @@ int kcg_assemble_and_solve(int cb, int m, int N_left, const int *element, const 
     hipLaunchKernelGGL(k_kc_q, dim3(vb), dim3(256), 0, st, m, (const double *)s, (const double *)p, q);
     hipLaunchKernelGGL(k_kc_check0, dim3(1), dim3(KC_NT), 0, st, part, ctrl, tol2);
     KCHK();
-    static hipEvent_t evk[2]; static bool evk_ready = false;
-    const bool prof = e.profiling != 0;
-    if (prof) {
-        if (!evk_ready) { HIPCHK(hipEventCreate(&evk[0])); HIPCHK(hipEventCreate(&evk[1])); evk_ready = true; }
-        HIPCHK(hipEventRecord(evk[0], st));
-    }
+    if (prof) HIPCHK(hipEventRecord(evk[0], st));
     int it = 0, batch = 8;
-    KCtrl h{};
     for (;;) {
         HIPCHK(hipMemcpyAsync(&h, ctrl, sizeof(KCtrl), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));

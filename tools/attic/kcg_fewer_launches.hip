@@ -199,3 +199,154 @@ __global__ __launch_bounds__(KB_NT) void k_kb_solve(int m, int R, const int4 *__
         }
     }
 */
+
+
+// ======================================================================================================================================
+// Second variant (round 4, also removed after measurement): ONE launch per iteration on the blocked form.  rocprofv3 kernel durations on
+// MI355X, tol 1e-12: 9 111 rows: k_kb_iter 10.1 us against k_kb_apply 6.5 + k_kc_step 4.2; 82 479 rows: 16.5 us against 8.7 + 6.9 -- the
+// merged launch takes what the two take together (HIP events per iteration: 13.5 vs 15.3 us and 17.1 vs 15.5 us): the iteration is a chain of
+// dependent memory latencies and workgroup-wide reductions, not launch overhead, and forming q' for the whole window in every workgroup adds
+// work.  Fragments: the kernel, then the two host fragments.
+// ONE launch per iteration on the blocked form (k_kb_iter = the step of iteration c followed by the product of iteration c + 1).  A block
+// needs q' = s p' on its whole WINDOW before it can multiply, and p' = beta p - (r + alpha t) is elementwise: so every workgroup forms q' for
+// its window itself, redundantly (17 x its own rows at the crossbar: 4 coalesced reads of 61 KB instead of 1, from L2), straight into LDS --
+// q never exists in memory -- and writes y, r', p' for its own rows only.  p, r, t and the partial sums alternate between two buffers (a
+// neighbour may still read the old ones).  The stop test is the reference's, on the summed r.r of the r this launch STARTS from (formed and
+// summed by its predecessor): launch c tests "after update c" and then changes nothing.  Per iteration: one launch of ~9 us instead of two
+// of 6-9 us.
+__global__ __launch_bounds__(KB_NT) void k_kb_iter(int m, int R, int c, const int4 *__restrict__ blk, const int *__restrict__ cf, const double *__restrict__ diag,
+                                                   const double *__restrict__ s, const double *__restrict__ Pold, const double *__restrict__ Rold,
+                                                   const double *__restrict__ Told, double *__restrict__ Pnew, double *__restrict__ Rnew, double *__restrict__ Tnew,
+                                                   double *__restrict__ y, const double *__restrict__ part_in, double *__restrict__ part_out,
+                                                   const double *__restrict__ prr_in, double *__restrict__ prr_out, KCtrl *ctrl,
+                                                   double high_G, double low_G, double tol2, int npa, int wcap)
+{
+    extern __shared__ double win[];                                            // wcap doubles of q', then p' and r' of the block's own rows
+    double *ps = win + wcap, *rs = ps + R;
+    __shared__ double red[4][KB_NT / 64];
+    __shared__ int sdone;
+    const int4 bi = blk[blockIdx.x];
+    const int wlo = bi.x, wn = bi.y;
+    const int r0 = blockIdx.x * R, nrows = min(R, m - r0);
+    const int g = threadIdx.x >> 2, l = threadIdx.x & 3;
+    if (threadIdx.x == 0) sdone = ctrl->done;
+    // requested before the partial sums are reduced: the first four window elements of this thread
+    double pw[4], rw[4], tw[4], sw[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int idx = threadIdx.x + u * KB_NT;
+        const bool ok = idx < wn;
+        const int w = wlo + (ok ? idx : 0);
+        pw[u] = Pold[w]; rw[u] = Rold[w]; tw[u] = Told[w]; sw[u] = s[w];
+    }
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int j = threadIdx.x; j < npa; j += KB_NT) { v[0] += part_in[j]; v[1] += part_in[KC_NPA + j]; v[2] += part_in[2 * KC_NPA + j]; }
+    for (int j = threadIdx.x; j < KC_NP; j += KB_NT) v[3] += prr_in[j];
+    block_sum_n<KB_NT, 4>(v, red);
+    if (sdone) return;
+    const double rr = v[3];
+    if (c > 0 && !(rr > tol2)) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ctrl->rr[0] = rr; ctrl->iters = c; ctrl->done = 1; }
+        return;
+    }
+    const double alpha = rr / v[0];
+    const double rr_new = rr + alpha * (2.0 * v[1] + alpha * v[2]);
+    const double beta = rr_new / rr;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int base = 0; base < wn; base += 4 * KB_NT) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = base + threadIdx.x + u * KB_NT;
+            if (idx < wn) {
+                const int w = wlo + idx;
+                const double rn = rw[u] + alpha * tw[u];
+                const double pn = pw[u] * beta - rn;
+                win[idx] = sw[u] * pn;
+                const int kk = w - r0;
+                if (kk >= 0 && kk < nrows) {
+                    y[w] += alpha * pw[u];
+                    Rnew[w] = rn; Pnew[w] = pn;
+                    ps[kk] = pn; rs[kk] = rn;
+                    acc[3] += rn * rn;
+                }
+            }
+        }
+        if (base + 4 * KB_NT < wn) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + 4 * KB_NT + threadIdx.x + u * KB_NT;
+                const int w = wlo + (idx < wn ? idx : 0);
+                pw[u] = Pold[w]; rw[u] = Rold[w]; tw[u] = Told[w]; sw[u] = s[w];
+            }
+        }
+    }
+    int4 cc[4];
+    bool lg;
+    int k = g;
+    kb_load_row(cf, bi, k, l, k < nrows, cc, &lg);                             // (in flight across the barrier)
+    __syncthreads();
+    for (; k < nrows; k += KB_NT / 4) {
+        const int row = r0 + k;
+        const double qr = win[row - wlo], dg = diag[row], sv = s[row];
+        int cidx[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { cidx[4 * j] = cc[j].x; cidx[4 * j + 1] = cc[j].y; cidx[4 * j + 2] = cc[j].z; cidx[4 * j + 3] = cc[j].w; }
+        const bool lgc = lg;
+        double x[16];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = win[(cidx[u] & 0x7fffffff) - wlo];
+        if (lgc) {
+#pragma unroll
+            for (int u = 8; u < 16; ++u) x[u] = win[(cidx[u] & 0x7fffffff) - wlo];
+        }
+        kb_load_row(cf, bi, k + KB_NT / 4, l, k + KB_NT / 4 < nrows, cc, &lg);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = (cidx[u] & 0x7fffffff) == row ? 0.0 : (cidx[u] < 0 ? high_G : low_G) * x[u];
+        double sum = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+        if (lgc) {
+#pragma unroll
+            for (int u = 8; u < 16; ++u) x[u] = (cidx[u] & 0x7fffffff) == row ? 0.0 : (cidx[u] < 0 ? high_G : low_G) * x[u];
+            sum += ((x[8] + x[9]) + (x[10] + x[11])) + ((x[12] + x[13]) + (x[14] + x[15]));
+        }
+        sum += __shfl_xor(sum, 2, 4); sum += __shfl_xor(sum, 1, 4);
+        if (l == 0) {
+            const double tv = sv * (dg * qr - sum);
+            Tnew[row] = tv;
+            acc[0] += ps[k] * tv; acc[1] += rs[k] * tv; acc[2] += tv * tv;
+        }
+    }
+    block_sum_n<KB_NT, 4>(acc, red);
+    if (threadIdx.x == 0) {
+        part_out[blockIdx.x] = acc[0]; part_out[KC_NPA + blockIdx.x] = acc[1]; part_out[2 * KC_NPA + blockIdx.x] = acc[2];
+        prr_out[blockIdx.x] = acc[3];
+        if (blockIdx.x == 0) { ctrl->rr[0] = rr_new; ctrl->iters = c + 1; }
+    }
+}
+
+
+/* ---- host fragments ----
+    // blocked form: ONE launch per iteration (k_kb_iter) after a first product; else product + step
+    const bool one_launch = kb && e.k_blocked >= 2;
+    double *set1 = nullptr, *part1 = part + 3 * KC_NPA + 2 * KC_NP, *prr = part + 3 * KC_NPA;
+    size_t lds_i = 0;
+    if (one_launch) {
+        set1 = (double *)scratch(S_K_PING, (size_t)3 * m * 8);
+        if (!set1) return e.err_code;
+        lds_i = ((size_t)kb->maxwin + 2 * (size_t)kb->R) * 8;
+        static bool attr_i = false;
+        if (!attr_i) { HIPCHK(hipFuncSetAttribute((const void *)k_kb_iter, hipFuncAttributeMaxDynamicSharedMemorySize, (KB_MAXWIN + 2 * 1024) * 8)); attr_i = true; }
+        KC_APPLY(0, (const int *)cf, (const double *)diag, (const double *)s, (const double *)q, high_G, low_G,
+                 (const double *)p, t, part, (const KCtrl *)ctrl, (const double *)nullptr, r, (double *)nullptr);
+    }
+
+...
+            if (one_launch) {
+                const int o = it & 1;
+                double *P0 = o ? set1 : p, *R0 = o ? set1 + m : r, *T0 = o ? set1 + 2 * (size_t)m : t;
+                double *P1 = o ? p : set1, *R1 = o ? r : set1 + m, *T1 = o ? t : set1 + 2 * (size_t)m;
+                hipLaunchKernelGGL(k_kb_iter, dim3(ga), dim3(KB_NT), lds_i, st, m, kb->R, it, (const int4 *)kb->blk, (const int *)cf, (const double *)diag, (const double *)s,
+                                   (const double *)P0, (const double *)R0, (const double *)T0, P1, R1, T1, y, (const double *)(o ? part1 : part), o ? part : part1,
+                                   (const double *)(prr + o * KC_NP), prr + (o ^ 1) * KC_NP, ctrl, high_G, low_G, tol2, npa, kb->maxwin);
+                continue;
+            }
+*/

@@ -783,7 +783,11 @@ def main():
                     r["what"] = ("a crossbar-SIZED stack with the current solve off, as every shipped crossbar parameter set runs "
                                  "(structures/crossbars/*/parameters.txt: solve_current = 0): charge + potential (K-CG + pair sum) + event loop")
                     r["us_per_executed_event"] = round(r["split_ms"]["rates"] * 1e3 / max(r["per_step"]["events"], 1), 1)
-                r.update(rooflines(sp))
+                rf = rooflines(sp)
+                if nocur:                                # the library's X statistics are those of an earlier simulation of this process
+                    rf.pop("roofline", None)
+                    if "cold_step" in r: r["cold_step"].pop("cg_sweeps_X", None)
+                r.update(rf)
                 points[spn] = r
                 sp.close()
             except Exception as exc:                 # a failed scale point must not void the main measurement

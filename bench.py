@@ -340,7 +340,15 @@ def strong_scaling_model_block(sim, roof, res):
         tn = step_ms - iters * (sweep_us - sw) * 1e-3
         rows[n] = {"apply_us": round(apply_us / n, 1), "replicated_us_per_sweep": round(other_us, 1), "exchange_us_assumed": round(xchg, 1),
                    "exchange_bytes_per_rank": payload, "modelled_ms_per_step": round(tn, 1), "modelled_speedup": round(step_ms / tn, 2)}
+    # the one measurement of the exchange that exists: two processes sharing ONE GPU, peer-write exchange over hipIpc-mapped buffers
+    # (profiles/r04_bench_2rank_rehearsal_one_gpu_tile5_peer_exchange.json: 59 us per exchange of a 2.97 MB slot, HIP events around
+    # push ... wait, the peer's skew included) -- same-device copies and a time-sliced GPU, NOT an xGMI number
+    same_dev = {"us_per_exchange": 58.9, "slot_bytes": 371602 * 8.0, "ranks": 2,
+                "scaled_to_this_payload_us": round(58.9 * payload / (371602 * 8.0), 1),
+                "source": "profiles/r04_bench_2rank_rehearsal_one_gpu_tile5_peer_exchange.json",
+                "note": "two processes on ONE GPU (same-device copies, time-sliced): a functional cost, not an xGMI number; the model above keeps its ASSUMED link rate"}
     return {"what": "coarse: apply kernel / N + replicated rest of a sweep + an ASSUMED all-gather (payload / 100 GB/s per link + 20 us); nothing here was run on more than one GPU",
+            "exchange_measured_same_device": same_dev,
             "cg_sweeps_X_per_step": iters, "single_gpu_ms_per_step": step_ms, "by_n_gpus": rows,
             "note": "the replicated part of a sweep (neighbour part, row kernel, panel updates) caps the speed-up near apply / rest + 1; sharding those rows is the next step"}
 

@@ -664,7 +664,8 @@ def main():
                        "phases": "charge+potential+rates+current+heat", "parallelism": "single GPU", "x_format": "tiled" if args.x_format else "csr",
                        "current_warm_start": args.warm_start, "cg_tol": sim.p.cg_tol, "x_block": sim.x_block,
                        "cg_on_X": ("block-CG of width %d, tile x panel product on the matrix cores (csrc/xtb.hip)" % sim.x_block) if sim.x_block > 1
-                                  else "single-vector CG in the reference's iterate order (csrc/xt.hip)"},
+                                  else "single-vector CG in the reference's iterate order (csrc/xt.hip)",
+                       "x_aux_columns": ("smooth (lowest Laplacian modes of the bounding box / s)" if sim.host.get_stats()["xb_aux"] else "fixed-seed hash") if sim.x_block > 1 else None},
             "split_ms": res["split_ms"], "per_step": res["per_step"],
             "steady": {"steps": n, "ms_each": [round(t * 1e3, 1) for t, _ in sim.step_log], "cg_sweeps_X_each": [i for _, i in sim.step_log]},
             "cold_step": ({"ms": round(sim.cold[0] * 1e3, 1), "cg_sweeps_X": sim.cold[1],

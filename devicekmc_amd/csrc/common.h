@@ -115,6 +115,7 @@ struct Engine {
     long long tcache_budget = -1;  // bytes the tunnelling-coefficient cache may take; -1 = a third of the free device memory, 8-128 GiB (dkmc_set_tcache_budget)
     double pair_cut = 6.5;         // screening cut-off of the pair sum in units of sigma sqrt 2 (dkmc_set_pair_cutoff; 0 = all pairs like the reference)
     int k_blocked = 1;             // build the blocked form of K patterns (dkmc_set_k_blocked; kcg.hip)
+    int x_aux = 2;                 // auxiliary columns of the block-CG (dkmc_set_x_aux; xtb.hip): 0 hash set, 1 smooth set, 2 smooth at tolerances >= 1e-8
     int x_block = 16;              // block-CG width of the current solve on the tiled X (dkmc_set_x_block; xtb.hip): 16 by default, 1 = the reference's single-vector loop (its iterate sequence)
     int x_format = 1;              // 1: tiled X (xt.hip, default); 0: CSR X as the reference stores it (current.hip + cg.hip)
     int x_iter_hint = 0;           // iteration count of the previous CG solve of X (sizes the first launch batch)
@@ -153,7 +154,7 @@ enum {
     S_XT_DPOS, S_XT_SNODE_D, S_XT_SNODE_I, S_XT_CMASK, S_XT_ISTILE, S_XT_NSUBC, S_XT_TOFF, S_XT_SOFF, S_XT_TILES, S_XT_NITEMW, S_XT_WRANGE,
     S_XT_ITEMS, S_XT_SPLIT, S_XT_TVAL, S_XT_ROWPART, S_XT_COLPART, S_XT_CNT, S_XT_Q,
     S_XT_T_NITEMW, S_XT_T_ITEMS, S_XT_T_SPLIT, S_XT_T_COLPART, S_XT_T_MISC,
-    S_XTB_PANELS, S_XTB_QS, S_XTB_ROWPART, S_XTB_COLPART, S_XTB_GRAM, S_XTB_SMALL,
+    S_XTB_PANELS, S_XTB_QS, S_XTB_ROWPART, S_XTB_COLPART, S_XTB_GRAM, S_XTB_SMALL, S_XTB_XI,
     S_NSLOTS
 };
 

@@ -48,6 +48,8 @@ void dkmc_set_tcache_budget(long long bytes) { eng().tcache_budget = bytes; }
 void dkmc_set_pair_cutoff(double x_cut) { eng().pair_cut = x_cut > 0.0 ? x_cut : 0.0; }
 void dkmc_set_x_block(int s) { eng().x_block = s < 1 ? 1 : (s > 16 ? 16 : s); }
 int dkmc_get_x_block(void) { return eng().x_block; }
+void dkmc_set_x_aux(int mode) { eng().x_aux = mode < 0 ? 0 : (mode > 3 ? 2 : mode); }
+int dkmc_get_x_aux(void) { return eng().x_aux; }
 void dkmc_set_k_blocked(int on) { eng().k_blocked = on ? 1 : 0; }
 int dkmc_get_k_blocked(void) { return eng().k_blocked; }
 void dkmc_set_cb_edge_domain(int atoms_only) { eng().cb_edge_domain = atoms_only ? 1 : 0; }

@@ -1238,7 +1238,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         B.m = m; B.ns = ns; B.ns_pad = ns_pad; B.nK = nK; B.nW = nW; B.s = e.x_block;
         B.items = (const XItem *)items + X.item_lo; B.item_n = X.item_n; B.tiles = tiles; B.sub_base = (int)X.sub_base; B.tval = tval;
         B.wrange = wrange; B.nitem_w = nitem_w; B.nrecords = X.nitems >> X.rec_shift;
-        B.srow = srow; B.sS = sS; B.nsrank = nsrank; B.rp = rp; B.ci = col; B.val = val; B.sc = sc; B.b = rhs; B.y = y;
+        B.srow = srow; B.sS = sS; B.nsrank = nsrank; B.rp = rp; B.ci = col; B.val = val; B.sc = sc; B.ax = buf->atom_x; B.ay = buf->atom_y; B.az = buf->atom_z; B.b = rhs; B.y = y;
         B.ctrl = ctrl; B.tol2 = tol2; B.nt_loads = nt_loads; B.sharded = sharded; B.w_lo = X.w_lo; B.w_hi = X.w_hi;
         int bi = 0; double brr = 0.0;
         rc = xtb_cg(B, &bi, &brr);

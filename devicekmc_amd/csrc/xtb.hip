@@ -55,10 +55,69 @@ __device__ __forceinline__ double xtb_aux(int row, int col)
     h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
     return (double)(h >> 11) * (1.0 / 4503599627370496.0) - 1.0;
 }
-// column v of the scaled right-hand side panel at a row: the physical one, an auxiliary one, or padding
-__device__ __forceinline__ double xtb_rhs(const double *__restrict__ b, int row, int v, int s)
+// column v of the scaled right-hand side panel at a row: the physical one, an auxiliary one, or padding.
+// Auxiliary columns are a free choice (only their block Krylov space matters).  aux != nullptr: the SMOOTH set -- column v is
+// cos(kx pi xi) cos(ky pi eta) cos(kz pi zeta) / s_row, (xi, eta, zeta) the atom's position scaled to the unit box and (kx, ky, kz) the v-th
+// lowest mode of the Laplacian of the device's bounding box (k_xtb_modes: adapts to the aspect ratio -- along x for a narrow stack, lateral
+// for a wide one).  The neighbour part of X is a graph Laplacian: its low modes are smooth, and right-hand sides rich in them deflate that end
+// of the spectrum from the first sweeps (oracle's X, tools/blockcg_proto.py, x modes: 6.4e3 rows 48 -> 31 sweeps, 5.8e4 rows 95 -> 76).
+// Smooth systems also CONVERGE sooner than the physical column; close to a converged tolerance (1e-10 and below) their residual columns
+// vanish and the s x s systems lose rank, so below 1e-8 the hash set stays (dkmc_set_x_aux).
+struct XbAux { double lo[3], hi[3]; int k[16][3]; unsigned long long mm[6]; };
+__device__ __forceinline__ double xtb_rhs(const double *__restrict__ b, int row, int v, int s, const XbAux *__restrict__ aux = nullptr,
+                                          const double *__restrict__ ax = nullptr, const double *__restrict__ ay = nullptr, const double *__restrict__ az = nullptr,
+                                          const double *__restrict__ sc = nullptr)
 {
-    return v == 0 ? b[row] : (v < s ? xtb_aux(row, v) : 0.0);
+    if (v == 0) return b[row];
+    if (v >= s) return 0.0;
+    if (!aux) return xtb_aux(row, v);
+    // rows 0 / 1: the ground-side and the source-side driver node, at the two ends of x, in the middle of the cross-section
+    double u[3];
+    if (row < 2) { u[0] = row == 0 ? 1.0 : 0.0; u[1] = 0.5; u[2] = 0.5; }
+    else {
+        const double c[3] = {ax[row - 2], ay[row - 2], az[row - 2]};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) u[d] = aux->hi[d] > aux->lo[d] ? (c[d] - aux->lo[d]) / (aux->hi[d] - aux->lo[d]) : 0.0;
+    }
+    return cospi((double)aux->k[v][0] * u[0]) * cospi((double)aux->k[v][1] * u[1]) * cospi((double)aux->k[v][2] * u[2]) / sc[row];
+}
+// bounding box of the atoms (order-preserving integer image of c + 2^20 > 0: the result does not depend on the order of the atomics)
+__global__ void k_xtb_box(int na, const double *__restrict__ ax, const double *__restrict__ ay, const double *__restrict__ az, XbAux *aux)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= na) return;
+    const double c[3] = {ax[i], ay[i], az[i]};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const unsigned long long u = (unsigned long long)__double_as_longlong(c[d] + 1048576.0);
+        atomicMin(&aux->mm[2 * d], u); atomicMax(&aux->mm[2 * d + 1], u);
+    }
+}
+// the s - 1 lowest non-constant modes of the box: (kx / Lx)^2 + (ky / Ly)^2 + (kz / Lz)^2 ascending, ties by (kx, ky, kz) descending in
+// kx (the transport direction first); x_only: (v, 0, 0).  One thread.
+__global__ void k_xtb_modes(XbAux *aux, int x_only)
+{
+    double L[3];
+    for (int d = 0; d < 3; ++d) {
+        aux->lo[d] = __longlong_as_double((long long)aux->mm[2 * d]) - 1048576.0;
+        aux->hi[d] = __longlong_as_double((long long)aux->mm[2 * d + 1]) - 1048576.0;
+        L[d] = aux->hi[d] - aux->lo[d];
+        if (!(L[d] > 1e-6)) L[d] = 1e-6;
+    }
+    aux->k[0][0] = aux->k[0][1] = aux->k[0][2] = 0;
+    double last = 0.0; int lastcode = 1 << 30;
+    for (int v = 1; v < 16; ++v) {
+        if (x_only) { aux->k[v][0] = v; aux->k[v][1] = 0; aux->k[v][2] = 0; continue; }
+        double best = 1e300; int bc = -1;
+        for (int code = 8 * 8 * 8 - 1; code >= 1; --code) {                  // code = kx * 64 + ky * 8 + kz, descending
+            const int kx = code >> 6, ky = (code >> 3) & 7, kz = code & 7;
+            const double ev = (kx / L[0]) * (kx / L[0]) + (ky / L[1]) * (ky / L[1]) + (kz / L[2]) * (kz / L[2]);
+            const bool after = ev > last || (ev == last && code < lastcode);   // strictly after the previous pick in (ev ascending, code descending)
+            if (after && (ev < best)) { best = ev; bc = code; }
+        }
+        aux->k[v][0] = bc >> 6; aux->k[v][1] = (bc >> 3) & 7; aux->k[v][2] = bc & 7;
+        last = best; lastcode = bc;
+    }
 }
 // position of (S rank r, vector v) in the compact panel QS: rows pairwise interleaved, [r / 2][v][r % 2] -- two consecutive rows of one
 // vector are one 16-byte read (two k-steps of the row product).  (The LDS copy of a strip's window adds a swizzle: k_xtb_apply.)
@@ -471,7 +530,8 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_rows(int ns, int nK, int nW, int 
                                                     const int *__restrict__ srow, const double *__restrict__ sS, const int *__restrict__ nsrank,
                                                     const double *__restrict__ sc, const double *__restrict__ drvpart, double *__restrict__ T,
                                                     const double *__restrict__ P, double *__restrict__ R, const double *__restrict__ b,
-                                                    double *__restrict__ gpart, XCtrl *ctrl, const double *__restrict__ xbuf, int it, int nr)
+                                                    double *__restrict__ gpart, XCtrl *ctrl, const double *__restrict__ xbuf, int it, int nr,
+                                                    const XbAux *__restrict__ aux, const double *__restrict__ ax, const double *__restrict__ ay, const double *__restrict__ az)
 {
     const size_t xslot = (size_t)ns * so + 2;
     __shared__ double lg[4][XB_NG / 2][4][64];                                 // the four waves' Gram accumulators, three matrices at a time (24 KiB)
@@ -522,12 +582,12 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_rows(int ns, int nK, int nW, int 
         if (sA < ns) {
             const int row = srow[sA]; const size_t o = (size_t)row * XB_SP + v;
             tA = sS[sA] * (T[o] + tA); T[o] = tA;
-            if (INIT) { rA = tA - xtb_rhs(b, row, v, s); R[o] = rA; } else { pA = P[o]; rA = R[o]; }
+            if (INIT) { rA = tA - xtb_rhs(b, row, v, s, aux, ax, ay, az, sc); R[o] = rA; } else { pA = P[o]; rA = R[o]; }
         } else tA = 0.0;
         if (sB < ns) {
             const int row = srow[sB]; const size_t o = (size_t)row * XB_SP + v;
             tB = sS[sB] * (T[o] + tB); T[o] = tB;
-            if (INIT) { rB = tB - xtb_rhs(b, row, v, s); R[o] = rB; } else { pB = P[o]; rB = R[o]; }
+            if (INIT) { rB = tB - xtb_rhs(b, row, v, s, aux, ax, ay, az, sc); R[o] = rB; } else { pB = P[o]; rB = R[o]; }
         } else tB = 0.0;
         if (!INIT) {
             G[0] = XB_MFMA(pA, tA, G[0]); G[1] = XB_MFMA(pA, rA, G[1]); G[2] = XB_MFMA(tA, rA, G[2]); G[3] = XB_MFMA(tA, tA, G[3]); G[5] = XB_MFMA(pA, pA, G[5]);
@@ -564,7 +624,7 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_rows(int ns, int nK, int nW, int 
                     for (int w = 0; w < XB_DSPLIT; ++w) sd += drvpart[(row * XB_DSPLIT + w) * XB_SP + v];
                     t_ = sc[row] * sd; T[o] = t_;
                 }
-                if (INIT) { if (use) { r_ = t_ - xtb_rhs(b, row, v, s); R[o] = r_; } }
+                if (INIT) { if (use) { r_ = t_ - xtb_rhs(b, row, v, s, aux, ax, ay, az, sc); R[o] = r_; } }
                 else if (use) { p_ = pv[u]; r_ = rv[u]; }
                 if (!INIT) { G[0] = XB_MFMA(p_, t_, G[0]); G[1] = XB_MFMA(p_, r_, G[1]); G[2] = XB_MFMA(t_, r_, G[2]); G[3] = XB_MFMA(t_, t_, G[3]); G[5] = XB_MFMA(p_, p_, G[5]); }
                 G[4] = XB_MFMA(r_, r_, G[4]);
@@ -937,6 +997,18 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
         if (!peer) { xbuf = (double *)scratch(S_CG_XCHG, xcount * nr * 8); if (!xbuf) return e.err_code; }
         hipLaunchKernelGGL(k_xtb_set_sharded, dim3(1), dim3(1), 0, st, A.ctrl);
     }
+    // smooth auxiliary columns (see xtb_rhs): dkmc_set_x_aux 0 never, 1 always, 2 (default) at tolerances of 1e-8 and looser, 3 always with x modes only
+    XbAux *aux = nullptr;
+    if (A.ax && A.ay && A.az && m > 2 && (e.x_aux == 1 || e.x_aux == 3 || (e.x_aux == 2 && A.tol2 >= 1e-16))) {
+        aux = (XbAux *)scratch(S_XTB_XI, sizeof(XbAux));
+        if (!aux) return e.err_code;
+        XbAux h0{};
+        for (int d = 0; d < 3; ++d) { h0.mm[2 * d] = ~0ull; h0.mm[2 * d + 1] = 0ull; }
+        HIPCHK(hipMemcpyAsync(aux, &h0, sizeof(XbAux), hipMemcpyHostToDevice, st));       // (pageable source: copied before the call returns)
+        hipLaunchKernelGGL(k_xtb_box, dim3((m - 2 + 255) / 256), dim3(256), 0, st, m - 2, A.ax, A.ay, A.az, aux);
+        hipLaunchKernelGGL(k_xtb_modes, dim3(1), dim3(1), 0, st, aux, e.x_aux == 3 ? 1 : 0);
+    }
+    e.stats.xb_aux = aux ? 1 : 0;
     int local_fail = 0;
     hipLaunchKernelGGL(k_xtb_init, dim3((unsigned)((pan + 255) / 256)), dim3(256), 0, st, m, (const double *)A.y, A.sc, A.nsrank, y0, P, QS);
     const int ntb = (A.item_n + 3) / 4;
@@ -971,7 +1043,7 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
         else hipLaunchKernelGGL(k_xtb_neigh, dim3(nnb), dim3(XT_NT), 0, st, m, A.rp, A.ci, A.val, (const double *)P, A.sc, A.nsrank, (const XCtrl *)A.ctrl, T, drvpart);
     };
 #define XB_ROWS_ARGS(IT_) A.ns, A.nK, A.nW, m, s, so, A.wrange, A.nitem_w, (const double *)rowpartB, (const double *)colpartB, A.srow, A.sS, A.nsrank, A.sc, \
-                     (const double *)drvpart, T, (const double *)P, R, A.b, gpart, A.ctrl, (const double *)xbuf, IT_, nr
+                     (const double *)drvpart, T, (const double *)P, R, A.b, gpart, A.ctrl, (const double *)xbuf, IT_, nr, (const XbAux *)aux, A.ax, A.ay, A.az
     // S rows of T + partial Gram matrices; a sharded solve exchanges the tile sums first.  A host-side failure of this rank between two
     // collectives must not leave the peers in the all-reduce: it still joins, with the abort word set, and every rank leaves together.
     auto rows = [&](bool init, int itn, hipEvent_t e2, hipEvent_t e3) -> int {
@@ -1109,7 +1181,7 @@ extern "C" int dkmc_xtb_check_product(int width, double *max_abs_diff, double *m
 #undef XB_APPLY
     hipLaunchKernelGGL((k_xtb_rows<1, 0>), dim3(ng), dim3(XT_NT), 0, st, ns, X.nK, X.nW, m, s, so, (const int2 *)g_xb.wrange, (const int *)g_xb.nitem_w, (const double *)rowpartB,
                        (const double *)colpartB, (const int *)g_xb.srow, (const double *)sS, (const int *)g_xb.nsrank, (const double *)sc, (const double *)drvpart, T,
-                       (const double *)P, R, (const double *)rhs, gpart, ctrl, (const double *)nullptr, -1, 1);
+                       (const double *)P, R, (const double *)rhs, gpart, ctrl, (const double *)nullptr, -1, 1, (const XbAux *)nullptr, (const double *)nullptr, (const double *)nullptr, (const double *)nullptr);
     KCHK();
     const int gb = (ns + 255) / 256;
     for (int v = 0; v < so; ++v) {

@@ -65,6 +65,7 @@ struct XtbArgs {
     const int *srow; const double *sS; const int *nsrank;
     const xrp_t *rp; const int *ci; const double *val;      // neighbour part Xs (CSR, unscaled, diagonal included)
     const double *sc;                             // Jacobi scaling 1 / sqrt(diag)
+    const double *ax, *ay, *az;                   // position of the atom of row r >= 2 at [r - 2] (smooth auxiliary columns; may be null)
     const double *b;                              // scaled right-hand side
     double *y;                                    // in: scaled start vector y / s; out: scaled solution
     XCtrl *ctrl; double tol2; bool nt_loads;

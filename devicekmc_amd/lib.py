@@ -40,7 +40,7 @@ class dkmc_stats(C.Structure):
                 ("spmv_tiles", C.c_int), ("spmv_pad2", C.c_int), ("spmv_tile_entries", C.c_longlong),
                 ("xt_subblocks", C.c_longlong), ("xt_local_subblocks", C.c_longlong), ("xt_items", C.c_int), ("xt_kc", C.c_int),
                 ("xt_sparse_nnz", C.c_longlong), ("xt_ns", C.c_int), ("xt_split_launch", C.c_int),
-                ("kcg_ms", C.c_double), ("kcg_iters_timed", C.c_int), ("kcg_blocked", C.c_int), ("pair_ms", C.c_double), ("pair_evaluated", C.c_longlong), ("pair_tested", C.c_longlong), ("xt_records", C.c_longlong), ("tcache_bytes", C.c_longlong), ("kcg_bytes", C.c_longlong), ("xb_width", C.c_int), ("xb_fallback", C.c_int)]
+                ("kcg_ms", C.c_double), ("kcg_iters_timed", C.c_int), ("kcg_blocked", C.c_int), ("pair_ms", C.c_double), ("pair_evaluated", C.c_longlong), ("pair_tested", C.c_longlong), ("xt_records", C.c_longlong), ("tcache_bytes", C.c_longlong), ("kcg_bytes", C.c_longlong), ("xb_aux", C.c_int), ("xb_pad", C.c_int), ("xb_width", C.c_int), ("xb_fallback", C.c_int)]
 
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
@@ -60,6 +60,8 @@ SYMBOLS = {
     "dkmc_set_cb_edge_domain": (None, [_I]),
     "dkmc_set_x_block": (None, [_I]),
     "dkmc_get_x_block": (_I, []),
+    "dkmc_set_x_aux": (None, [_I]),
+    "dkmc_get_x_aux": (_I, []),
     "dkmc_set_k_blocked": (None, [_I]),
     "dkmc_get_k_blocked": (_I, []),
     "dkmc_set_pair_cutoff": (None, [_D]),

@@ -100,6 +100,7 @@ typedef struct dkmc_stats {
     long long xt_records;                  /* records of column partial sums one matrix-vector product writes (= runs; runs / 4 on one GPU, where the four waves of a workgroup share one) */
     long long tcache_bytes;                /* bytes of tunnelling-coefficient cache THIS rank holds (sharded solve on the tiled X: what its tiles read) */
     long long kcg_bytes;                   /* bytes one iteration of the last K solve moves: column/class words + the q windows (or one read of q per row) + 14 (15) vector touches */
+    int xb_aux, xb_pad;                    /* 1: the last block solve used the smooth auxiliary columns (dkmc_set_x_aux) */
     int xb_width, xb_fallback;             /* block-CG width of the last current solve (1 = single-vector loop); 1 if the block loop lost definiteness and the single-vector loop finished the solve */
 } dkmc_stats;
 
@@ -144,6 +145,13 @@ void dkmc_reset_pair_sum_cache(void);
  * with the single-vector loop to the stop tolerance, NOT iterate by iterate.  85 071 sites: 666 -> 208 / 133 / 95 sweeps at s = 4 / 8 / 16. */
 void dkmc_set_x_block(int s);
 int dkmc_get_x_block(void);
+/* Auxiliary right-hand sides of the block-CG (a free choice: only their block Krylov space matters; column 0 is always the physical system).
+ * 0: fixed-seed hash of (row, column), uniform in [-1, 1).  1: smooth set, column v = cos(v pi xi) / s with xi the atom's x coordinate scaled to
+ * [0, 1] -- rich in the low modes of the neighbour part of X: 20-35 % fewer sweeps at the default tolerance.  2 (default): the smooth set at
+ * tolerances of 1e-8 and looser, the hash set below (smooth systems converge before the physical column does and the s x s systems then lose
+ * rank close to a converged tolerance).  No counterpart in the reference. */
+void dkmc_set_x_aux(int mode);
+int dkmc_get_x_aux(void);
 /* 1 (default): initialize_sparsity also builds the blocked form of the K pattern (csrc/kcg.hip) for systems of up to 262 144 device rows:
  * the CG on K (background potential, CB edge: solve_sparse_CG_Jacobi on K, iterative_solvers_gpu.cu:309-480) then runs in an internal
  * x-sorted row order, one block of rows per CU with its window of the direction vector in LDS; site order outside the solve is untouched.

@@ -156,3 +156,42 @@ def test_block_cg_small_and_degenerate_systems(cell_2p5, hip):
                 assert abs(dev.imacro - ref[1]) <= (1e-8 if V > 1 else 1e-1) * abs(ref[1]), (V, width, dev.imacro, ref[1])
     finally:
         L.dkmc_set_x_block(16); L.dkmc_set_cg_tolerance(1e-6)
+
+
+@pytest.mark.parametrize("which", ["2.5nm", "7.5nm"])
+def test_smooth_auxiliary_columns(cell_2p5, dev_7p5, hip, which):
+    """The auxiliary right-hand sides of the block-CG are a free choice (dkmc_set_x_aux): the fixed-seed hash set, or the smooth set (the lowest
+    Laplacian modes of the device's bounding box over the Jacobi scaling; default at tolerances >= 1e-8).  Whatever the set, the solution of the
+    physical column meets the reference's stop test in the TRUE scaled residual of the CSR X and I_macro agrees to the tolerance's level; the
+    smooth set needs fewer sweeps on these devices (oracle's X on the CPU: 48 -> 31 and 95 -> 76 with x modes); below 1e-8 the default falls
+    back to the hash set (smooth columns converge before the physical one does and the s x s systems lose rank)."""
+    from devicekmc_amd import params as pm
+    host, L = hip
+    structure, p = (cell_2p5, pm.KMCParameters()) if which == "2.5nm" else (dev_7p5, params_7p5())
+    p.solve_heating_global = False
+    try:
+        L.dkmc_set_x_format(0); L.dkmc_set_x_block(1)
+        dev, sim, gb, _ = _fresh_device(structure, p, hip)
+        dev.updateCharge(gb); dev.updatePotential(gb, p, Vd, 0); dev.updatePower(gb, p, Vd)
+        rp, ci, data = host.get_last_X()
+        L.dkmc_set_x_format(1)
+        res = {}
+        for mode in (0, 1, 3, 2):
+            L.dkmc_set_x_aux(mode)
+            a = _solve(dev, gb, p, hip, 16, 1e-6)
+            st = host.get_stats()
+            assert st["xb_aux"] == (0 if mode == 0 else 1) and a["fallback"] == 0, mode
+            assert _scaled_residual(rp, ci, data, a["m"], p.G0, p.X_loop_G) <= 1e-5, (mode, a["iters"])
+            res[mode] = a
+        for mode in (1, 3, 2):
+            assert abs(res[mode]["im"] / res[0]["im"] - 1) <= 1e-5, mode
+            assert res[mode]["iters"] < 0.95 * res[0]["iters"], (mode, res[mode]["iters"], res[0]["iters"])
+        assert res[2]["iters"] == res[1]["iters"] and np.array_equal(res[2]["m"], res[1]["m"])      # default = the box modes at this tolerance
+        b = _solve(dev, gb, p, hip, 16, 1e-6)                                                         # bitwise reproducible
+        assert np.array_equal(b["m"], res[2]["m"]) and b["iters"] == res[2]["iters"]
+        L.dkmc_set_x_aux(2)
+        c = _solve(dev, gb, p, hip, 16, 1e-10)
+        assert host.get_stats()["xb_aux"] == 0                                                        # converged tolerances keep the hash set
+        assert _scaled_residual(rp, ci, data, c["m"], p.G0, p.X_loop_G) <= 3e-9
+    finally:
+        L.dkmc_set_x_format(1); L.dkmc_set_x_block(16); L.dkmc_set_x_aux(2); L.dkmc_set_cg_tolerance(1e-6)

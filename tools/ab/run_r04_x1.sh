@@ -7,8 +7,8 @@ import bench
 from devicekmc_amd import lib
 L = lib.load()
 out = {}
-for name, steps in (("2.5nm", 6), ("7.5nm", 6), ("tile:2", 4), ("tile:5", 3), ("tile:10", 2)):
-    for mode in (0, 3, 2):
+for name, steps in (("2.5nm", 10), ("7.5nm", 10), ("tile:2", 6), ("tile:5", 3)):
+    for mode in (0, 2):
         L.dkmc_set_x_aux(mode)
         sim = bench.Sim(name, "cuda:0", x_format=1)
         el, n = sim.run(steps, 1, budget_s=120.0)

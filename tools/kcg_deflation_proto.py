@@ -1,5 +1,6 @@
 """CPU experiment (round 4): deflated CG on the oracle's K with the lowest Laplacian modes of the bounding box (over the Jacobi
 scaling) as the coarse space -- the K-side counterpart of the smooth auxiliary columns of the block-CG on X (csrc/xtb.hip).
+(The GPU version was built and removed in round 4: on the warm-started production solves the gain was 742 -> 543 iterations at 2.7 x the cost per iteration.)
 usage: python tools/kcg_deflation_proto.py [crossbar|7.5nm|tile:K] [tol]"""
 import os, sys, time
 import numpy as np, scipy.sparse as sp

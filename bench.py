@@ -18,14 +18,16 @@ Workloads (config.workload):
 Contract: python bench.py --gpus N --steps K --warmup W ; prints ONE JSON line on rank 0.  `--gpus N` with N > 1 and no rank environment
 starts the N ranks itself (devicekmc_amd/launch.py); a world that is not --gpus is refused.
 
-N = 1: `value` = steady-state steps/s of tile:10 at the library's defaults: CG tolerance 1e-6 (the snapshot's) and the block-CG of width 16
-on the tiled X (csrc/xtb.hip).  W >= 1 puts the cold step (coefficient cache, buffer sizing, zero start vector) into the warm-up; it is
+N = 1: `value` = steady-state steps/s of tile:10 at the library's defaults: CG tolerance 1e-6 (the snapshot's), the block-CG of width 16
+on the tiled X (csrc/xtb.hip), current solve started from the previous step's solution (dkmc_set_current_warm_start(1), the default since
+round 5: tests/test_gpu_warm_start.py).  W >= 1 puts the cold step (coefficient cache, buffer sizing, zero start vector) into the warm-up; it is
 reported as `cold_step`.  The same line carries
   * `roofline`: the dominant kernel (k_xtb_apply: tile x panel product on the matrix cores) -- HIP-event time of sampled launches,
     algorithmic bytes AND fp64 flops per launch, HBM `traffic` from two rocprofv3 --pmc child runs;
-  * `reference_order_cg`: the same workload with dkmc_set_x_block(1), the reference's single-vector CG (its iterate sequence): cold + one
+  * `reference_order_cg`: the same workload with dkmc_set_x_block(1), the reference's single-vector CG (its iterate sequence) from the reference's start vector: cold + one
     steady step, sweeps per step, its own kernel roofline, and the strong-scaling model of the sharded solve built on it;
-  * `alt_warm_start`: the optional unscaled warm start of the current solve (never `value`);
+  * `reference_start_vector`: the same simulation with dkmc_set_current_warm_start(0), the reference code's start vector (the buffer it
+    scaled by G0 in place, i.e. practically zero): what the default's warm start from the previous solution saves;
   * `cpu_baseline`: the oracle's CG iteration timed at this size x the REFERENCE algorithm's iteration count (a lower bound on a CPU step);
   * `device_7p5nm`: the reference's own 85 071-site device: steps/s, split, kernel roofline, oracle superstep on the host cores, the run
     under KMCParameters.log_revision() checked against the reference's CUDA log (`at_log_tolerance`), the C++ host cross-check;
@@ -85,7 +87,7 @@ def make_workload(name):
 class Sim:
     """One simulation resident on the GPU: the reference's host objects (Device / KMCProcess / GPUBuffers mirror) + one superstep."""
 
-    def __init__(self, name, devname, kmc_seed=None, x_format=1, warm_start=0, log_revision=False, cg_tol=None, x_block=None, Vd=None, solve_current=None):
+    def __init__(self, name, devname, kmc_seed=None, x_format=1, warm_start=None, log_revision=False, cg_tol=None, x_block=None, Vd=None, solve_current=None):
         from devicekmc_amd import host, lib
         self.host, self.L = host, lib.load()
         self.name = name
@@ -106,7 +108,8 @@ class Sim:
         self.dev = host.Device(self.s, self.p, gpu_neighbors=devname)   # HIP cell-list neighbour index (setup, outside the timed region)
         self.kmc = host.KMCProcess(self.dev, self.p.freq)
         self.gb = self.dev.make_gpubuf(devname)
-        self.L.dkmc_set_current_warm_start(warm_start)
+        self.warm_start = 1 if warm_start is None else int(warm_start)        # 1 = the library default (start from the previous solution)
+        self.L.dkmc_set_current_warm_start(self.warm_start)
         self.L.dkmc_set_x_format(x_format)
         self.L.dkmc_set_x_block(self.x_block)
         self.dev.setLaplacePotential(self.gb, self.p, self.Vd)
@@ -133,6 +136,7 @@ class Sim:
         if timed: sync()
         t1 = time.perf_counter()
         self.L.dkmc_set_x_block(self.x_block)
+        self.L.dkmc_set_current_warm_start(self.warm_start)
         dev.updatePotential(gb, p, self.Vd, self.k)
         if timed: sync()
         t2 = time.perf_counter()
@@ -597,14 +601,14 @@ def main():
     ap.add_argument("--no-device", action="store_true", help="N = 1: skip the block on the reference's own 85 071-site device")
     ap.add_argument("--no-reference-order", action="store_true", help="N = 1: skip the runs with dkmc_set_x_block(1), the reference's single-vector CG")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--warm-start", type=int, default=0, help="dkmc_set_current_warm_start mode (0 = reference)")
+    ap.add_argument("--warm-start", type=int, default=1, help="dkmc_set_current_warm_start: 1 = library default (previous solution), 0 = the reference code's G0-scaled buffer")
     ap.add_argument("--x-format", type=int, default=1, help="1: tiled X (default); 0: CSR X as the reference stores it")
     ap.add_argument("--mode", choices=["sharded", "replicas"], default="sharded",
                     help="N > 1: ONE simulation, X sharded over the ranks (strong scaling, default) or independent replicas (weak scaling)")
     ap.add_argument("--scale-points", default=None, help="N = 1: comma list of extra workloads measured in the same run (default tile:5,crossbar_10nm_5pitch,tile:20:nocurrent; 'none')")
     ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the replicas block")
     ap.add_argument("--no-single-ref", action="store_true", help="N > 1: skip the single-GPU run of the same simulation (reference point of the speed-up)")
-    ap.add_argument("--no-alt", action="store_true", help="skip the alt_warm_start block")
+    ap.add_argument("--no-alt", action="store_true", help="skip the reference_start_vector block")
     ap.add_argument("--no-cpp-host", action="store_true", help="N = 1: skip the cross-check line through the C++ host driver")
     ap.add_argument("--no-pmc", action="store_true", help="N = 1: do not measure roofline.traffic (two rocprofv3 --pmc child runs)")
     ap.add_argument("--no-log-tolerance", action="store_true", help="N = 1: skip the at_log_tolerance block")
@@ -662,7 +666,8 @@ def main():
             "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "none", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": name, "sites": res["sites"], "nn": res["nn"], "atoms": res["atoms"], "Vd": sim.Vd,
                        "phases": "charge+potential+rates+current+heat", "parallelism": "single GPU", "x_format": "tiled" if args.x_format else "csr",
-                       "current_warm_start": args.warm_start, "cg_tol": sim.p.cg_tol, "x_block": sim.x_block,
+                       "current_warm_start": sim.warm_start, "cg_tol": sim.p.cg_tol, "x_block": sim.x_block,
+                       "start_vector_of_X": "previous step's solution (library default)" if sim.warm_start else "the reference code's G0-scaled buffer",
                        "cg_on_X": ("block-CG of width %d, tile x panel product on the matrix cores (csrc/xtb.hip)" % sim.x_block) if sim.x_block > 1
                                   else "single-vector CG in the reference's iterate order (csrc/xt.hip)",
                        "x_aux_columns": ("smooth (lowest Laplacian modes of the bounding box / s)" if sim.host.get_stats()["xb_aux"] else "fixed-seed hash") if sim.x_block > 1 else None},
@@ -678,17 +683,18 @@ def main():
         out.update(roofs)
         if big and sim.x_block > 1 and "roofline" in out:
             out["strong_scaling_model"] = strong_scaling_model_block(sim, out["roofline"], res)
-        # ---- same simulation, optional unscaled warm start of the current solve (never `value`) ----
-        if args.warm_start == 0 and not args.no_alt:
-            sim.L.dkmc_set_current_warm_start(1)
-            sim.step(False)                                  # this step stores the private copy the next ones start from
+        # ---- same simulation from the reference code's start vector (dkmc_set_current_warm_start(0)): what the default's warm start saves ----
+        if args.warm_start == 1 and not args.no_alt:
+            sim.warm_start = 0
             t0 = time.perf_counter(); it0 = 0; na = 2 if big else min(n, 5)
             for _ in range(na):
                 sim.step(False); it0 += sim.host.get_stats()["cg_iters_X"]
             ta = time.perf_counter() - t0
-            out["alt_warm_start"] = {"current_warm_start": 1, "steps": na, "value": round(na / ta, 5), "ms_per_step": round(ta / na * 1e3, 3), "cg_sweeps_X": it0 / na,
-                                     "note": "warm start from an unscaled private copy of the previous solution instead of the reference's G0-scaled buffer"}
-            sim.L.dkmc_set_current_warm_start(0)
+            out["reference_start_vector"] = {"current_warm_start": 0, "steps": na, "value": round(na / ta, 5), "ms_per_step": round(ta / na * 1e3, 3), "cg_sweeps_X": it0 / na,
+                                             "note": "same block-CG, started from gpubuf.atom_virtual_potentials as the reference code does (the buffer holds G0 x the previous "
+                                                     "solution, current_solver_gpu.cu:1013-1016: practically a zero start)"}
+            out["warm_start_gain"] = {"sweeps": round(it0 / na / max(res["per_step"]["cg_iters_X"], 1), 2), "steps_per_s": round(out["value"] / (na / ta), 2)}
+            sim.warm_start = 1
         sites_main = sim.s.N
         sim.close()
         # ---- roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC counters, measured now (the counter runs stop their
@@ -703,11 +709,11 @@ def main():
         ref_iters = None
         if not args.no_reference_order and X_BLOCK > 1 and args.x_format:
             try:
-                sr = Sim(name, devname, x_format=args.x_format, x_block=1)
+                sr = Sim(name, devname, x_format=args.x_format, x_block=1, warm_start=0)
                 elr, nr_ = sr.run(1 if big else min(n, 5), 1, budget_s=60.0)
                 rr = summary(sr, elr, nr_)
                 ref_iters = rr["per_step"]["cg_iters_X"]
-                blk = {"x_block": 1, "what": "dkmc_set_x_block(1): solve_sparse_CG_Jacobi's iterate sequence and start vector (iterative_solvers_gpu.cu:309-480)",
+                blk = {"x_block": 1, "current_warm_start": 0, "what": "dkmc_set_x_block(1) + dkmc_set_current_warm_start(0): solve_sparse_CG_Jacobi's iterate sequence from the reference code's start vector (iterative_solvers_gpu.cu:309-480)",
                        "steps": nr_, "warmup": 1, "value": round(nr_ / elr, 5), "ms_per_step": rr["ms_per_step"], "split_ms": rr["split_ms"],
                        "cg_sweeps_X": ref_iters, "cold_step": {"ms": round(sr.cold[0] * 1e3, 1), "cg_sweeps_X": sr.cold[1]} if sr.cold else None}
                 blk.update({k: v for k, v in rooflines(sr).items() if k == "roofline"})
@@ -745,21 +751,20 @@ def main():
                        "reference_cuda_log": {"s_per_superstep_median": 4.78, "source": "structures/single_devices/timing_7.5nm/output_noguess.txt (BASELINE.md; unnamed GPU)"}}
                 blk.update(rooflines(d))
                 if not args.no_alt:
-                    d.L.dkmc_set_current_warm_start(1)
-                    d.step(False)
+                    d.warm_start = 0
                     t0 = time.perf_counter(); it0 = 0
                     for _ in range(5):
                         d.step(False); it0 += d.host.get_stats()["cg_iters_X"]
                     ta = time.perf_counter() - t0
-                    blk["alt_warm_start"] = {"current_warm_start": 1, "value": round(5 / ta, 4), "ms_per_step": round(ta / 5 * 1e3, 3), "cg_sweeps_X": it0 / 5}
-                    d.L.dkmc_set_current_warm_start(0)
+                    blk["reference_start_vector"] = {"current_warm_start": 0, "value": round(5 / ta, 4), "ms_per_step": round(ta / 5 * 1e3, 3), "cg_sweeps_X": it0 / 5}
+                    d.warm_start = 1
                 if not args.no_cpp_host:
                     blk["cpp_host_crosscheck"] = cpp_host_crosscheck(d, 10, 2)
                 if not args.no_cpu_baseline:
                     blk["cpu_baseline"] = cpu_superstep_baseline(d.s, d.p, ncpu)
                 d.close()
                 if not args.no_reference_order:
-                    d1 = Sim("7.5nm", devname, x_format=args.x_format, x_block=1)
+                    d1 = Sim("7.5nm", devname, x_format=args.x_format, x_block=1, warm_start=0)
                     el1, n1 = d1.run(10, 2)
                     r1 = summary(d1, el1, n1)
                     blk["reference_order_cg"] = {"x_block": 1, "value": round(n1 / el1, 4), "ms_per_step": r1["ms_per_step"], "cg_sweeps_X": r1["per_step"]["cg_iters_X"]}
@@ -893,7 +898,7 @@ def main():
                            "parallelism": ("one simulation; X generated/stored/streamed in %d per-rank shares, one exchange of 16 |S| + 2 doubles per block-CG sweep, slots added in rank order"
                                            if sharded else "replicas x%d") % world,
                            "exchange": ("peer-write over hipIpc-mapped buffers (opt-in)" if peer_on else "all-gather of the transport") if sharded else None,
-                           "transport": transport, "transport_note": transport_note, "x_format": "tiled", "current_warm_start": 0, "cg_tol": sim.p.cg_tol,
+                           "transport": transport, "transport_note": transport_note, "x_format": "tiled", "current_warm_start": sim.warm_start, "cg_tol": sim.p.cg_tol,
                            "comm_ranks": min(i[0] for i in infos), "comm_rank_ids": sorted(i[1] for i in infos),
                            "comm_transport_code": sorted(set(i[2] for i in infos)), "process_group_world": world, "process_group_backend": backend},
                 "split_ms": res["split_ms"], "per_step": res["per_step"], "cpu_baseline": None,

@@ -26,6 +26,7 @@
 //     that the partitioning and lockstep logic can be exercised by several ranks sharing one GPU, which RCCL refuses.
 #include "common.h"
 #include <dlfcn.h>
+#include <stdlib.h>
 
 struct nccl_id_t { char internal[128]; };          // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128), passed by value
 static const int NCCL_FLOAT64 = 8;                 // ncclDataType_t: ncclDouble
@@ -35,6 +36,9 @@ typedef int (*fn_comm_destroy)(void *);
 typedef int (*fn_all_gather)(const void *, void *, size_t, int, void *, hipStream_t);
 typedef int (*fn_all_reduce)(const void *, void *, size_t, int, int, void *, hipStream_t);
 typedef const char *(*fn_error_string)(int);
+typedef int (*fn_send)(const void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_recv)(void *, size_t, int, int, void *, hipStream_t);
+typedef int (*fn_group)(void);
 
 struct Comm {
     int transport = DKMC_COMM_NONE, nranks = 1, rank = 0;
@@ -46,6 +50,7 @@ struct Comm {
     fn_all_gather all_gather = nullptr;
     fn_all_reduce all_reduce = nullptr;
     fn_error_string error_string = nullptr;
+    fn_send send = nullptr; fn_recv recv = nullptr; fn_group group_start = nullptr, group_end = nullptr;       // point-to-point (all-to-all-v of the slab-distributed block-CG)
     // host callback
     dkmc_allgather_fn cb = nullptr; void *cb_user = nullptr;
     double *stage = nullptr; size_t stage_bytes = 0;
@@ -66,6 +71,8 @@ static int rccl_open()
     c.all_gather = (fn_all_gather)dlsym(h, "ncclAllGather");
     c.all_reduce = (fn_all_reduce)dlsym(h, "ncclAllReduce");
     c.error_string = (fn_error_string)dlsym(h, "ncclGetErrorString");
+    c.send = (fn_send)dlsym(h, "ncclSend"); c.recv = (fn_recv)dlsym(h, "ncclRecv");
+    c.group_start = (fn_group)dlsym(h, "ncclGroupStart"); c.group_end = (fn_group)dlsym(h, "ncclGroupEnd");
     if (!c.get_unique_id || !c.comm_init_rank || !c.comm_destroy || !c.all_gather || !c.all_reduce || !c.error_string)
         return dkmc_fail(41, "comm: librccl lacks a required symbol", __FILE__, __LINE__);
     c.dl = h;
@@ -73,6 +80,7 @@ static int rccl_open()
 }
 
 static void peer_release();
+#define PEER_MAXR_A2A 64
 #define RCCLCHK(x) do { int r__ = (x); if (r__ != 0) return dkmc_fail(42, g_comm.error_string(r__), __FILE__, __LINE__); } while (0)
 
 extern "C" int dkmc_comm_unique_id(char *id128)
@@ -145,13 +153,17 @@ extern "C" int dkmc_comm_allgather_host(double *buf, size_t count)
 // The slots are then added IN RANK ORDER by the caller's kernel (k_xtb_rows<., 1>): identical bits on every rank by construction.
 // Two slot sets alternate (parity of the exchange): a peer may push exchange n + 1 while this rank still reads the slots of n; it cannot
 // push n + 2 before this rank has pushed n + 1, i.e. finished reading n.
-// Tested with two processes sharing ONE GPU (tests/test_dist_sharded.py); across GPUs the mapping is the one RCCL uses, but polling a
-// word in coarse-grained device memory written by a peer GPU has not been run here -- which is why the RCCL all-gather stays the
-// default transport of the exchange and this one is opt-in (DKMC_PEER_EXCHANGE=1 / parallel.attach_peer_exchange).
+// Memory: slots and sequence rows are allocated FINE-GRAINED (hipExtMallocWithFlags, hipDeviceMallocFinegrained): a peer device's
+// stores become visible to this device's loads without a kernel boundary, which the poll in k_peer_wait and the slot reads of
+// k_xtb_rows behind it rely on (coarse-grained hipMalloc memory is only coherent across devices at kernel boundaries: a poll could
+// sit on a stale line, a slot read could hit the L2 copy of exchange n - 2).  Flags are written / read with system-scope release /
+// acquire.  Tested with two processes sharing ONE GPU (tests/test_dist_sharded.py), which is all the development box allows: an attach
+// whose ranks sit on DIFFERENT devices (PCI bus ids travel with the handles) is refused unless DKMC_PEER_CROSS_DEVICE=1 is set AND the
+// fine-grained allocation succeeded -- the caller (parallel.attach_peer_exchange) then stays on the communicator's all-gather.
 #define PEER_MAXR 16
 #define PEER_TIMEOUT_S 10.0
 struct Peer {
-    bool ready = false;
+    bool ready = false, finegrained = false;
     size_t slot = 0;                                   // doubles per slot
     double *buf = nullptr;                             // local: 2 * nranks * slot doubles
     unsigned long long *flags = nullptr;               // local: PEER_MAXR words (sequence number of the last complete push of rank r)
@@ -176,34 +188,69 @@ static void peer_release()
     p = Peer{};
 }
 
-// allocates this rank's exchange buffer and sequence row; handles128 receives the two IPC handles (64 bytes each)
-extern "C" int dkmc_comm_peer_prepare(size_t slot_doubles, char *handles128)
+// allocates this rank's exchange buffer and sequence row; handles192 receives the two IPC handles (64 bytes each) and, in the last 64
+// bytes, this rank's device identity: [0] 'F' / 'C' (fine- / coarse-grained allocation), [1...] the PCI bus id string of its device
+static int peer_alloc(void **ptr, size_t bytes, bool fine)
+{
+    if (fine) { if (hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocFinegrained) == hipSuccess) return 0; (void)hipGetLastError(); *ptr = nullptr; return 1; }
+    HIPCHK(hipMalloc(ptr, bytes));
+    return 0;
+}
+extern "C" int dkmc_comm_peer_prepare(size_t slot_doubles, char *handles192)
 {
     Comm &c = g_comm; Peer &p = g_peer;
-    if (c.transport == DKMC_COMM_NONE || c.nranks > PEER_MAXR || slot_doubles == 0 || !handles128)
+    if (c.transport == DKMC_COMM_NONE || c.nranks > PEER_MAXR || slot_doubles == 0 || !handles192)
         return dkmc_fail(47, "comm: peer exchange needs an attached communicator of at most 16 ranks", __FILE__, __LINE__);
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
     peer_release();
     p.slot = slot_doubles;
-    HIPCHK(hipMalloc((void **)&p.buf, (size_t)2 * c.nranks * slot_doubles * 8));
-    HIPCHK(hipMalloc((void **)&p.flags, PEER_MAXR * sizeof(unsigned long long)));
-    HIPCHK(hipMemset(p.flags, 0, PEER_MAXR * sizeof(unsigned long long)));
+    const size_t bbytes = (size_t)2 * c.nranks * slot_doubles * 8, fbytes = PEER_MAXR * sizeof(unsigned long long);
     hipIpcMemHandle_t h[2];
-    HIPCHK(hipIpcGetMemHandle(&h[0], p.buf));
-    HIPCHK(hipIpcGetMemHandle(&h[1], p.flags));
-    memcpy(handles128, &h[0], 64); memcpy(handles128 + 64, &h[1], 64);
+    // fine-grained first (see the header comment); a runtime that cannot allocate or export such memory gets the coarse-grained
+    // allocation, which is only valid between ranks on ONE device (attach checks)
+    bool fine = getenv("DKMC_PEER_COARSE") == nullptr;
+    for (int attempt = 0; attempt < 2; ++attempt, fine = false) {
+        if (peer_alloc((void **)&p.buf, bbytes, fine) == 0 && peer_alloc((void **)&p.flags, fbytes, fine) == 0 &&
+            hipIpcGetMemHandle(&h[0], p.buf) == hipSuccess && hipIpcGetMemHandle(&h[1], p.flags) == hipSuccess) { p.finegrained = fine; break; }
+        (void)hipGetLastError();
+        if (p.buf) { (void)hipFree(p.buf); p.buf = nullptr; }
+        if (p.flags) { (void)hipFree(p.flags); p.flags = nullptr; }
+        if (!fine) return dkmc_fail(47, "comm: peer exchange: could not allocate / export the exchange buffers", __FILE__, __LINE__);
+    }
+    HIPCHK(hipMemset(p.flags, 0, fbytes));
+    HIPCHK(hipDeviceSynchronize());
+    memcpy(handles192, &h[0], 64); memcpy(handles192 + 64, &h[1], 64);
+    char *id = handles192 + 128; memset(id, 0, 64);
+    id[0] = p.finegrained ? 'F' : 'C';
+    int dev = 0; HIPCHK(hipGetDevice(&dev));
+    if (hipDeviceGetPCIBusId(id + 1, 62, dev) != hipSuccess) { (void)hipGetLastError(); snprintf(id + 1, 62, "device-%d", dev); }
     return 0;
 }
-// all_handles: nranks x 128 bytes in rank order (this rank's own entry is ignored).  Every rank must have called prepare with the same slot size.
+// all_handles: nranks x 192 bytes in rank order (this rank's own handles are ignored).  Every rank must have called prepare with the same slot size.
 extern "C" int dkmc_comm_peer_attach(const char *all_handles)
 {
     Comm &c = g_comm; Peer &p = g_peer;
     if (!p.buf || !all_handles) return dkmc_fail(47, "comm: peer exchange not prepared", __FILE__, __LINE__);
+    // ranks on different devices: only with fine-grained buffers on EVERY rank and the explicit opt-in (never run on this pool: see above)
+    {
+        const char *mine = all_handles + (size_t)c.rank * 192 + 128;
+        bool cross = false, all_fine = true;
+        for (int r = 0; r < c.nranks; ++r) {
+            const char *id = all_handles + (size_t)r * 192 + 128;
+            if (strncmp(id + 1, mine + 1, 62) != 0) cross = true;
+            if (id[0] != 'F') all_fine = false;
+        }
+        if (cross && !(all_fine && getenv("DKMC_PEER_CROSS_DEVICE") && getenv("DKMC_PEER_CROSS_DEVICE")[0] == '1')) {
+            peer_release();
+            return dkmc_fail(49, "comm: peer exchange refused: the ranks sit on different devices (validated on one device only; DKMC_PEER_CROSS_DEVICE=1 with "
+                                 "fine-grained buffers on every rank overrides) -- the communicator's all-gather stays in use", __FILE__, __LINE__);
+        }
+    }
     double *rb[PEER_MAXR] = {}; unsigned long long *rf[PEER_MAXR] = {};
     for (int r = 0; r < c.nranks; ++r) {
         if (r == c.rank) { rb[r] = p.buf; rf[r] = p.flags; continue; }
         hipIpcMemHandle_t h[2];
-        memcpy(&h[0], all_handles + (size_t)r * 128, 64); memcpy(&h[1], all_handles + (size_t)r * 128 + 64, 64);
+        memcpy(&h[0], all_handles + (size_t)r * 192, 64); memcpy(&h[1], all_handles + (size_t)r * 192 + 64, 64);
         HIPCHK(hipIpcOpenMemHandle(&p.mapped[2 * r], h[0], hipIpcMemLazyEnablePeerAccess));
         HIPCHK(hipIpcOpenMemHandle(&p.mapped[2 * r + 1], h[1], hipIpcMemLazyEnablePeerAccess));
         rb[r] = (double *)p.mapped[2 * r]; rf[r] = (unsigned long long *)p.mapped[2 * r + 1];
@@ -215,6 +262,12 @@ extern "C" int dkmc_comm_peer_attach(const char *all_handles)
     return 0;
 }
 extern "C" int dkmc_comm_peer_detach(void) { peer_release(); return 0; }
+// a solve that failed while the exchange was in use (time-out, abort, launch error): the ranks' sequence counters may have drifted apart
+// (a rank that timed out stops at the end of its batch, its peers queue further exchanges), so every later exchange would wait
+// PEER_TIMEOUT_S for a sequence number the peer never reaches.  Drop the attachment: later solves use the communicator's all-gather
+// until the host attaches again (which resets sequence numbers and flags on every rank).
+void comm_peer_drop() { peer_release(); }
+int comm_peer_finegrained() { return g_peer.ready && g_peer.finegrained ? 1 : 0; }
 // ready; doubles per slot; exchanges since attach; mean duration of the timed ones [us] (profiling on: HIP events round push .. wait)
 extern "C" int dkmc_comm_peer_info(int *ready, long long *slot_doubles, long long *exchanges, double *mean_us)
 {
@@ -311,6 +364,61 @@ int comm_allgather_f64(double *buf, size_t count)
         HIPCHK(hipMemcpyAsync(buf, c.stage, bytes, hipMemcpyHostToDevice, st));
         return 0;
     }
+    return 0;
+}
+
+// All-to-all-v of doubles on the engine's stream (slab-distributed block-CG, xtb.hip): rank s sends cnt[s * nranks + d] doubles to rank d.
+// cnt is the FULL table (every rank holds the same one: piece sizes derive from replicated data), so no size exchange is needed.  In a
+// rank's send buffer the pieces lie in destination order, in its receive buffer in source order, both densely packed; a rank's piece for
+// itself is copied on the device.
+//   RCCL: one group of ncclSend / ncclRecv pairs -- on the xGMI mesh every pair of ranks has its own link, so the n - 1 pieces travel in
+//         parallel (this is what RCCL's own all-to-all does); never run here with more than one rank (one-GPU box).
+//   host: every rank's whole send buffer is all-gathered through the callback (padded to the longest) and the pieces are copied out of the
+//         staging area -- rehearsal and tests only (several ranks on one GPU).
+int comm_alltoallv_f64(const double *sendbuf, double *recvbuf, const long long *cnt)
+{
+    Comm &c = g_comm; hipStream_t st = eng().stream;
+    const int nr = c.nranks, me = c.rank;
+    if (c.transport == DKMC_COMM_NONE) return 0;
+    long long soff[PEER_MAXR_A2A + 1], roff[PEER_MAXR_A2A + 1];
+    if (nr > PEER_MAXR_A2A) return dkmc_fail(43, "comm: all-to-all-v supports at most 64 ranks", __FILE__, __LINE__);
+    soff[0] = roff[0] = 0;
+    for (int r = 0; r < nr; ++r) { soff[r + 1] = soff[r] + cnt[(size_t)me * nr + r]; roff[r + 1] = roff[r] + cnt[(size_t)r * nr + me]; }
+    if (c.transport == DKMC_COMM_RCCL) {
+        if (!c.send || !c.recv || !c.group_start || !c.group_end) return dkmc_fail(41, "comm: librccl lacks ncclSend / ncclRecv / ncclGroup*", __FILE__, __LINE__);
+        if (cnt[(size_t)me * nr + me] > 0)
+            HIPCHK(hipMemcpyAsync(recvbuf + roff[me], sendbuf + soff[me], (size_t)cnt[(size_t)me * nr + me] * 8, hipMemcpyDeviceToDevice, st));
+        if (nr > 1) {
+            RCCLCHK(c.group_start());
+            for (int r = 0; r < nr; ++r) {
+                if (r == me) continue;
+                if (cnt[(size_t)me * nr + r] > 0) RCCLCHK(c.send(sendbuf + soff[r], (size_t)cnt[(size_t)me * nr + r], NCCL_FLOAT64, r, c.nccl, st));
+                if (cnt[(size_t)r * nr + me] > 0) RCCLCHK(c.recv(recvbuf + roff[r], (size_t)cnt[(size_t)r * nr + me], NCCL_FLOAT64, r, c.nccl, st));
+            }
+            RCCLCHK(c.group_end());
+        }
+        return 0;
+    }
+    // host transport
+    long long maxsend = 1;
+    for (int s = 0; s < nr; ++s) { long long t = 0; for (int d = 0; d < nr; ++d) t += cnt[(size_t)s * nr + d]; if (t > maxsend) maxsend = t; }
+    const size_t bytes = (size_t)nr * maxsend * sizeof(double);
+    if (c.stage_bytes < bytes) {
+        if (c.stage) (void)hipHostFree(c.stage);
+        c.stage = nullptr; c.stage_bytes = 0;
+        HIPCHK(hipHostMalloc((void **)&c.stage, bytes, hipHostMallocDefault));
+        c.stage_bytes = bytes;
+    }
+    if (soff[nr] > 0) HIPCHK(hipMemcpyAsync(c.stage + (size_t)me * maxsend, sendbuf, (size_t)soff[nr] * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (int rc = c.cb(c.stage, (size_t)maxsend * sizeof(double), c.rank, c.nranks, c.cb_user)) return dkmc_fail(45, "comm: all-gather callback failed", __FILE__, __LINE__);
+    for (int s = 0; s < nr; ++s) {
+        const long long n = cnt[(size_t)s * nr + me];
+        if (n <= 0) continue;
+        long long o = 0; for (int d = 0; d < me; ++d) o += cnt[(size_t)s * nr + d];
+        HIPCHK(hipMemcpyAsync(recvbuf + roff[s], c.stage + (size_t)s * maxsend + o, (size_t)n * 8, hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));          // the staging buffer is reused by the next call
     return 0;
 }
 

@@ -6,6 +6,7 @@
 #include <string.h>
 #include <math.h>
 #include "../../include/devicekmc_hip.h"
+#include "../../include/devicekmc_hip_debug.h"
 
 // ELEMENT / EVENTTYPE (utils.h:37-60)
 enum { DEFECT = 0, OXYGEN_DEFECT = 1, VACANCY = 2, O_EL = 3, Hf_EL = 4, Ni_EL = 5, Ti_EL = 6, Pt_EL = 7, N_EL = 8, NULL_ELEMENT = 9 };
@@ -109,13 +110,14 @@ struct Engine {
     hipStream_t stream = nullptr;
     int device = 0;
     double cg_tol = 1e-6;
-    int current_warm_start = 0;
+    int current_warm_start = 1;    // start vector of the current solve (dkmc_set_current_warm_start): 1 previous solution (private unscaled copy), 0 the reference code's G0-scaled buffer
     int profiling = 0;
     int cb_edge_domain = 0;        // 0: CB-edge system over every site (snapshot source); 1: over atoms only (dkmc_set_cb_edge_domain)
     long long tcache_budget = -1;  // bytes the tunnelling-coefficient cache may take; -1 = a third of the free device memory, 8-128 GiB (dkmc_set_tcache_budget)
     double pair_cut = 6.5;         // screening cut-off of the pair sum in units of sigma sqrt 2 (dkmc_set_pair_cutoff; 0 = all pairs like the reference)
     int k_blocked = 1;             // build the blocked form of K patterns (dkmc_set_k_blocked; kcg.hip)
     int x_aux = 2;                 // auxiliary columns of the block-CG (dkmc_set_x_aux; xtb.hip): 0 hash set, 1 smooth set, 2 smooth at tolerances >= 1e-8
+    int x_slab = 1;                // > 1 rank: distribute the STATE of the block-CG by row slabs (xtb_slab.inc; dkmc_set_x_slab); 0: all-gather variant (tile stream sharded only)
     int x_block = 16;              // block-CG width of the current solve on the tiled X (dkmc_set_x_block; xtb.hip): 16 by default, 1 = the reference's single-vector loop (its iterate sequence)
     int x_format = 1;              // 1: tiled X (xt.hip, default); 0: CSR X as the reference stores it (current.hip + cg.hip)
     int x_iter_hint = 0;           // iteration count of the previous CG solve of X (sizes the first launch batch)
@@ -155,6 +157,8 @@ enum {
     S_XT_ITEMS, S_XT_SPLIT, S_XT_TVAL, S_XT_ROWPART, S_XT_COLPART, S_XT_CNT, S_XT_Q,
     S_XT_T_NITEMW, S_XT_T_ITEMS, S_XT_T_SPLIT, S_XT_T_COLPART, S_XT_T_MISC,
     S_XTB_PANELS, S_XTB_QS, S_XTB_ROWPART, S_XTB_COLPART, S_XTB_GRAM, S_XTB_SMALL, S_XTB_XI,
+    S_XTB_SLAB_BOX, S_XTB_SLAB_TAB, S_XTB_SLAB_OWNER, S_XTB_SLAB_LISTS, S_XTB_SLAB_SDST, S_XTB_SLAB_FLAG, S_XTB_SLAB_RLISTS, S_XTB_SLAB_GX, S_XTB_SLAB_S1, S_XTB_SLAB_S3, S_XTB_SLAB_R3,
+    S_XTB_EMU_Y, S_XTB_EMU_CTRL,
     S_NSLOTS
 };
 
@@ -163,11 +167,13 @@ int comm_attached();
 int comm_nranks();
 int comm_rank();
 int comm_allgather_f64(double *buf, size_t count);     // in place on the engine's stream; rank r owns buf[r*count, (r+1)*count)
+int comm_alltoallv_f64(const double *sendbuf, double *recvbuf, const long long *cnt);   // rank s sends cnt[s * nranks + d] doubles to rank d (full table on every rank; pieces packed in destination / source order)
 int comm_allreduce_sum_f64(double *buf, size_t count); // in place; the sum over the ranks (grouping of the additions is the transport's)
 int comm_agree(int local_rc, const char *what);         // agreement point: non-zero on EVERY rank if any rank passed a non-zero local_rc (comm.hip)
 int comm_agree_count();
 int comm_peer_ready(size_t count);                      // the one-shot peer-write exchange is attached and its slots hold `count` doubles (comm.hip)
 double *comm_peer_slots(int parity);
+void comm_peer_drop();                                  // after a failed solve: the peers' sequence counters may have drifted (comm.hip)
 int comm_peer_exchange(int parity, size_t count, int *ctrl_done, int *ctrl_aborted, int *ctrl_timeout, int stamp);
 int comm_bcast0_f64(double *buf, size_t count);        // in place; every rank ends with rank 0's bits
 

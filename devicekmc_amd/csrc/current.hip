@@ -113,6 +113,7 @@ struct TCacheState {
     int col_lo = 0, ncols = 0;          // columns of the main part (one GPU / CSR X: all nM)
     // part A of a sharded solve on the tiled X (TCacheView): the nL left-contact columns for the vacancies of this rank's windows
     int sharded = 0, nL = 0, capA = 0;
+    int nL_split = 0;                   // left-contact metals in front of the first vacancy of S, whether part A is held or not (nL = 0: not held)
     int *slotA_of_site = nullptr, *ctrA = nullptr; double *slotA_cb = nullptr, *valsA = nullptr; int2 *queueA = nullptr;
     size_t bytes() const { return ((size_t)cap * ncols + (size_t)capA * nL) * 8; }
 };
@@ -221,12 +222,13 @@ static int tc_reset(const XParams &P, int N, const int *aflag, const double *acb
     if (hipMemGetInfo(&mem_free, &mem_total) != hipSuccess) mem_free = 0;
     size_t budget = std::min((size_t)128 << 30, std::max((size_t)8 << 30, mem_free / 3));
     if (e.tcache_budget >= 0) budget = (size_t)e.tcache_budget;        // dkmc_set_tcache_budget (tests: force the uncached path)
+    const int nL_split = nL;
     if (capA * nL * 8 > budget / 2) { capA = 0; nL = 0; }              // part A does not fit: its pairs are integrated directly
     const size_t left = budget - capA * nL * 8;
     if (ncols > 0 && cap * ncols * 8 > left) cap = left / ((size_t)ncols * 8);
     if (ncols > 0 && cap < (size_t)n_vacancies + 16) { g_tc.valid = 0; return 0; }         // does not fit: run uncached
     if (ncols == 0) cap = 16;
-    g_tc.cap = (int)cap; g_tc.col_lo = col_lo; g_tc.ncols = ncols; g_tc.nL = nL; g_tc.capA = (int)capA;
+    g_tc.cap = (int)cap; g_tc.col_lo = col_lo; g_tc.ncols = ncols; g_tc.nL = nL; g_tc.nL_split = nL_split; g_tc.capA = (int)capA;
     HIPCHK(hipMalloc((void **)&g_tc.slot_of_site, (size_t)N * 4));
     HIPCHK(hipMalloc((void **)&g_tc.slot_cb, cap * 8));
     HIPCHK(hipMalloc((void **)&g_tc.vals, std::max<size_t>(cap * ncols, 1) * 8));
@@ -262,8 +264,8 @@ static int tc_update(const XParams &P, int N, int ns, const SEntry *S, const int
         HIPCHK(hipMemsetAsync(g_tc.ctr + 1, 0, 3 * sizeof(int), st));
         hipLaunchKernelGGL(k_tc_validate, dim3((P.Na + 255) / 256), dim3(256), 0, st, P.Na, aflag, acb, (const int *)g_tc.mrank_atom,
                            (const double *)g_tc.metal_cb, flags);
-        if (share) hipLaunchKernelGGL(k_tc_check_cols, dim3((ns + 255) / 256), dim3(256), 0, st, ns, S, (const int *)g_tc.mrank_atom, g_tc.nL, share[0], std::min(share[1], ns),
-                                      g_tc.col_lo, g_tc.ncols, flags);
+        if (share) hipLaunchKernelGGL(k_tc_check_cols, dim3((ns + 255) / 256), dim3(256), 0, st, ns, S, (const int *)g_tc.mrank_atom, g_tc.nL_split, share[0], std::min(share[1], ns),
+                                      g_tc.col_lo, g_tc.ncols, flags);      // (the TRUE left-contact count: with part A not held nL is 0 and every left-contact metal would read as a missing right-contact column)
         if (g_tc.ncols > 0)
             hipLaunchKernelGGL(k_tc_assign, dim3((ns + 255) / 256), dim3(256), 0, st, ns, S, atom_site, g_tc.cap, g_tc.slot_of_site, g_tc.slot_cb,
                                g_tc.ctr, g_tc.queue, 0, ns);
@@ -548,6 +550,32 @@ static int update_power_body(dkmc_gpubuf *buf, int n_src, int n_gnd, int nlc, do
     KCHK();
     HIPCHK(hipStreamSynchronize(st));
     return e.err_code;
+}
+
+// ---- the private start vector of dkmc_set_current_warm_start(1), for snapshot / restart (io.py: the sidecar keeps it) -------------------
+// get: *n_out = entries held for this buffer (0: none yet); copies min(n, capacity) doubles when h_out is non-null.
+// set: replaces the vector (n = 0 drops it); the next update_power with the same system size starts from it.
+extern "C" int dkmc_get_current_warm_vector(const dkmc_gpubuf *buf, double *h_out, int capacity, int *n_out)
+{
+    Engine &e = eng();
+    XBufState *st = buf ? xstate_find(buf->site_x) : nullptr;
+    const int n = (st && st->warm) ? st->warm_n : 0;
+    if (n_out) *n_out = n;
+    if (h_out && n > 0) {
+        HIPCHK(hipStreamSynchronize(e.stream));
+        HIPCHK(hipMemcpy(h_out, st->warm, (size_t)(n < capacity ? n : capacity) * 8, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+extern "C" int dkmc_set_current_warm_vector(const dkmc_gpubuf *buf, const double *h_in, int n)
+{
+    Engine &e = eng();
+    if (!buf || n < 0 || (n > 0 && !h_in)) return dkmc_fail(14, "set_current_warm_vector: bad arguments", __FILE__, __LINE__);
+    xstate_select(buf->site_x);
+    HIPCHK(hipStreamSynchronize(e.stream));
+    if (g_warm_n != n) { if (g_warm) (void)hipFree(g_warm); g_warm = nullptr; g_warm_n = 0; if (n > 0) { HIPCHK(hipMalloc((void **)&g_warm, (size_t)n * 8)); g_warm_n = n; } }
+    if (n > 0) HIPCHK(hipMemcpy(g_warm, h_in, (size_t)n * 8, hipMemcpyHostToDevice));
+    return 0;
 }
 
 extern "C" int dkmc_get_last_X(int *rows_out, long long *nnz_out, int *h_rp, int *h_col, double *h_data)

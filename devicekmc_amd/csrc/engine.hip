@@ -41,11 +41,14 @@ void dkmc_clear_error(void) { eng().err[0] = 0; eng().err_code = 0; }
 const dkmc_stats *dkmc_get_stats(void) { return &eng().stats; }
 void dkmc_set_cg_tolerance(double tol) { eng().cg_tol = tol; }
 void dkmc_set_current_warm_start(int mode) { eng().current_warm_start = mode; }
+int dkmc_get_current_warm_start(void) { return eng().current_warm_start; }
 void dkmc_set_profiling(int on) { eng().profiling = on; }
 void dkmc_set_x_format(int tiled) { eng().x_format = tiled ? 1 : 0; }
 int dkmc_get_x_format(void) { return eng().x_format; }
 void dkmc_set_tcache_budget(long long bytes) { eng().tcache_budget = bytes; }
 void dkmc_set_pair_cutoff(double x_cut) { eng().pair_cut = x_cut > 0.0 ? x_cut : 0.0; }
+void dkmc_set_x_slab(int on) { eng().x_slab = on ? 1 : 0; }
+int dkmc_get_x_slab(void) { return eng().x_slab; }
 void dkmc_set_x_block(int s) { eng().x_block = s < 1 ? 1 : (s > 16 ? 16 : s); }
 int dkmc_get_x_block(void) { return eng().x_block; }
 void dkmc_set_x_aux(int mode) { eng().x_aux = mode < 0 ? 0 : (mode > 3 ? 2 : mode); }

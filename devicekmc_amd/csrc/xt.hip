@@ -941,7 +941,6 @@ int xt_tile_sums_mv(const double *vS, double *out) { return xt_tile_sums<0>(vS, 
 
 // Builds the work items for an nranks-way split and reports rank `me`'s share.  Slots: where the item arrays go (the resident ones of
 // an assembly, or temporary ones of dkmc_xt_time_share).
-struct XShare { int nitems, maxchunk, item_lo, item_n, tile_lo, tile_n, w_lo, w_hi; long long sub_base, sub_n; XItem *items; int *nitem_w; int rec_shift; };
 static int xt_build_items(int nK, int nW, int kc, int ntiles, long long nsub_total, const int *toff, const XTile *tiles, int nranks, int me,
                           int slot_nitemw, int slot_items, int slot_split, XShare *out, int rec_shift = 0)
 {
@@ -1049,6 +1048,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         hipLaunchKernelGGL(k_xt_node_srank, dim3(nbr), dim3(256), 0, st, Nsub, srank, nsrank);
         KCHK();
         g_xb.rp = rp; g_xb.dpos = dpos; g_xb.ci = col; g_xb.val = val; g_xb.nsrank = nsrank;
+        g_xb.ax = buf->atom_x; g_xb.ay = buf->atom_y; g_xb.az = buf->atom_z;
 
         // ---- S in solver order ----
         sd = (double *)scratch(S_XT_SNODE_D, (size_t)ns_pad * 4 * 8);
@@ -1517,6 +1517,73 @@ extern "C" int dkmc_xt_check_shares(int nranks, double *max_abs_diff, double *ma
     if (max_abs) *max_abs = ma;
     if (subblocks_sum) *subblocks_sum = sb_sum;
     if (items_sum) *items_sum = it_sum;
+    return e.err_code;
+}
+
+
+// ---- test / measurement aid: the slab-distributed block-CG (xtb_slab.inc) with nranks VIRTUAL ranks on ONE GPU -----------------------------------
+// On the X left resident by the last single-GPU solve: (1) the block-CG of width `width` as one GPU runs it, from a zero start, to `tol`;
+// (2) the same system by the slab-distributed loop with nranks virtual ranks -- shares of the tiles built as a sharded assembly builds them, rows
+// owned by lateral slabs, every exchange a device copy.  The emulation itself fails (error 13) if the virtual ranks leave the loop at
+// different sweeps or end with different bits.  Out: largest deviation of the two solutions relative to the largest entry, both sweep counts,
+// the mean kernel times of virtual rank time_rank over sweeps 2 ... 25 (time_rank < 0: none), the doubles a rank receives per sweep in the three
+// exchanges (largest over the ranks).  Scratch vectors of the last solve are overwritten; delivered results are not.
+int xtb_cg_slab_emulate(const XtbArgs &A, int nr, const XShare *shares, int time_rank, int *iters_out, double *rr_out, double *times_us, long long *xdoubles);
+extern "C" int dkmc_xtb_emulate_slabs(int nranks, int width, double tol, int time_rank, double *rel_diff, int *iters_slab, int *iters_ref,
+                                      double *times_us /* [8] */, long long *xdoubles /* [3] */, int *rows_min_max /* [2] */)
+{
+    Engine &e = eng(); hipStream_t st = e.stream; const XTState &X = g_xt;
+    if (!X.valid || comm_attached() || X.tile_n != X.ntiles || X.ns <= 0 || !g_xb.ay) return dkmc_fail(13, "xtb_emulate_slabs: needs the X of a single-GPU solve", __FILE__, __LINE__);
+    if (nranks < 1 || nranks > 32) return dkmc_fail(13, "xtb_emulate_slabs: 1 ... 32 ranks", __FILE__, __LINE__);
+    const int m = X.Nsub, ns = X.ns, s = std::max(2, std::min(width, 16));
+    double *sc = (double *)e.buf[S_CG_S], *sS = (double *)e.buf[S_CG_PS], *rhs = (double *)e.buf[S_X_RHS];
+    double *yb = (double *)scratch(S_XTB_EMU_Y, (size_t)(m + 8) * 8 * 2);
+    XCtrl *ctrl = (XCtrl *)scratch(S_XTB_EMU_CTRL, 256);
+    if (!sc || !sS || !rhs || !yb || !ctrl) return e.err_code ? e.err_code : dkmc_fail(13, "xtb_emulate_slabs: no solver state", __FILE__, __LINE__);
+    sS += X.ns_pad;
+    XtbArgs B{};
+    B.m = m; B.ns = ns; B.ns_pad = X.ns_pad; B.nK = X.nK; B.nW = X.nW; B.s = s;
+    B.items = (const XItem *)g_xb.items + X.item_lo; B.item_n = X.item_n; B.tiles = g_xb.tiles; B.sub_base = (int)X.sub_base; B.tval = g_xb.tval;
+    B.wrange = g_xb.wrange; B.nitem_w = g_xb.nitem_w; B.nrecords = X.nitems >> X.rec_shift;
+    B.srow = g_xb.srow; B.sS = sS; B.nsrank = g_xb.nsrank; B.rp = g_xb.rp; B.ci = g_xb.ci; B.val = g_xb.val; B.sc = sc;
+    B.ax = g_xb.ax; B.ay = g_xb.ay; B.az = g_xb.az; B.b = rhs; B.ctrl = ctrl; B.tol2 = tol * tol;
+    B.nt_loads = (size_t)X.sub_n * XT_SUB * 8 > ((size_t)200 << 20); B.sharded = false; B.w_lo = X.w_lo; B.w_hi = X.w_hi;
+    const int hint = e.x_iter_hint;
+    // (1) one GPU
+    double *yref = yb, *yslab = yb + m + 8;
+    HIPCHK(hipMemsetAsync(yb, 0, (size_t)(m + 8) * 8 * 2, st));
+    B.y = yref;
+    int it_ref = 0, it_slab = 0; double rr = 0.0;
+    int rc = xtb_cg(B, &it_ref, &rr);
+    if (rc && rc != DKMC_XTB_BREAKDOWN) return rc;
+    // (2) nranks virtual ranks: the shares of an nranks-way assembly
+    const int ntiles = X.ntiles;
+    int kc = std::max(1, std::min(XT_MAXKC, ntiles / nranks / 4096));
+    if (ntiles <= 2048 * nranks) kc = std::max(1, std::min(XT_MAXKC, (ntiles + 1024 * nranks - 1) / (1024 * nranks)));
+    std::vector<XShare> sh((size_t)nranks);
+    for (int r = 0; r < nranks; ++r) {
+        rc = xt_build_items(X.nK, X.nW, kc, ntiles, X.nsub_total, (const int *)g_xb.toff, (const XTile *)g_xb.tiles, nranks, r, S_XT_T_NITEMW, S_XT_T_ITEMS, S_XT_T_SPLIT, &sh[r], 2);
+        if (rc) return rc;
+        if ((sh[r].item_lo | sh[r].item_n) & 3) return dkmc_fail(48, "xtb_emulate_slabs: run list not padded to groups of four", __FILE__, __LINE__);
+    }
+    B.y = yslab;
+    rc = xtb_cg_slab_emulate(B, nranks, sh.data(), time_rank, &it_slab, &rr, times_us, xdoubles);
+    e.x_iter_hint = hint;
+    if (rc && rc != DKMC_XTB_BREAKDOWN) return rc;
+    std::vector<double> h0((size_t)m), h1((size_t)m);
+    HIPCHK(hipMemcpyAsync(h0.data(), yref, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(h1.data(), yslab, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    double md = 0.0, ma = 0.0;
+    for (int i = 0; i < m; ++i) { md = std::max(md, fabs(h0[i] - h1[i])); ma = std::max(ma, fabs(h0[i])); }
+    if (rel_diff) *rel_diff = ma > 0.0 ? md / ma : md;
+    if (iters_slab) *iters_slab = it_slab;
+    if (iters_ref) *iters_ref = it_ref;
+    if (rows_min_max) {          // balance of the slabs: rows of the smallest and the largest one (the table the solver built)
+        std::vector<int> tab((size_t)nranks);
+        HIPCHK(hipMemcpy(tab.data(), (int *)e.buf[S_XTB_SLAB_TAB] + 4096 + 32 + 2, (size_t)nranks * 4, hipMemcpyDeviceToHost));
+        rows_min_max[0] = *std::min_element(tab.begin(), tab.end()); rows_min_max[1] = *std::max_element(tab.begin(), tab.end());
+    }
     return e.err_code;
 }
 

@@ -39,6 +39,7 @@
 #include "xtiles.h"
 #include <hip/hip_ext.h>
 #include <algorithm>
+#include <functional>
 #include <vector>
 
 #define XB_SP 16                      // vectors per panel row (padded block width)
@@ -405,9 +406,12 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
 // Workgroups [0, 2 XB_DSPLIT): the two driver rows (thousands of entries each), XB_DSPLIT slices per row, partial sums to drvpart (finished
 // by k_xtb_rows).  The rest: 16 atom rows per workgroup, 16 lanes per row (one per vector).  Non-S rows are finished (scaled) here; S rows
 // leave their sparse sum in T for k_xtb_rows.
+// Slab-distributed solve (rowlist != nullptr): the atom rows are the nlist rows of this rank's list; a driver row's partial sums run over the
+// columns this rank OWNS (the drivers' own columns 0 / 1 count for rank 0), the owners' partials are added in rank order by k_xtb_rows_slab.
 __global__ __launch_bounds__(XT_NT) void k_xtb_neigh(int m, const xrp_t *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ val,
                                                      const double *__restrict__ P, const double *__restrict__ sc, const int *__restrict__ nsrank,
-                                                     const XCtrl *ctrl, double *__restrict__ T, double *__restrict__ drvpart)
+                                                     const XCtrl *ctrl, double *__restrict__ T, double *__restrict__ drvpart,
+                                                     const int *__restrict__ rowlist = nullptr, int nlist = 0, const int *__restrict__ owner = nullptr, int me = 0)
 {
     __shared__ double red[16][16];
     if (ctrl->done) return;
@@ -418,6 +422,10 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_neigh(int m, const xrp_t *__restr
         const xrp_t len = p1 - p0, a = p0 + len * part / XB_DSPLIT, b = p0 + len * (part + 1) / XB_DSPLIT;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         xrp_t p = a + g;
+        if (owner) {
+            for (; p < b; p += 16) { const int c0 = ci[p]; if ((c0 < 2 ? 0 : owner[c0]) == me) s0 += val[p] * (sc[c0] * P[(size_t)c0 * XB_SP + v]); }
+            p = b;
+        }
         for (; p + 48 < b; p += 64) {
             const int c0 = ci[p], c1 = ci[p + 16], c2 = ci[p + 32], c3 = ci[p + 48];
             const double a0 = val[p], a1 = val[p + 16], a2 = val[p + 32], a3 = val[p + 48];
@@ -438,7 +446,8 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_neigh(int m, const xrp_t *__restr
     // atom rows (<= nn + 3 entries): the 16 lanes of a row first fetch its entries, one or two per lane, and fold the column's scaling into the
     // value; every entry is then handed round the group (shuffles) and all 16 panel reads of a batch are issued together -- three dependent
     // memory rounds per row instead of two per four entries (26 -> 12 us per sweep at 85 k sites)
-    const int row = 2 + ((int)blockIdx.x - 2 * XB_DSPLIT) * 16 + g;
+    const int li = ((int)blockIdx.x - 2 * XB_DSPLIT) * 16 + g;
+    const int row = rowlist ? (li < nlist ? rowlist[li] : m) : 2 + li;
     const bool ok = row < m;
     const xrp_t p0 = ok ? rp[row] : 0, p1 = ok ? rp[row + 1] : 0;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -495,8 +504,10 @@ __device__ __forceinline__ void xtb_list_sum2(const double *__restrict__ p, size
 // decision and any rank's abort word.  [w_lo, w_hi): windows that can hold this rank's partial sums (every other cell of its arrays is zero)
 __global__ __launch_bounds__(XT_NT) void k_xtb_fold_local(int ns, int nK, int nW, int so, const int2 *__restrict__ wrange, const int *__restrict__ nitem_w,
                                                           const double *__restrict__ rowpartB, const double *__restrict__ colpartB, double *__restrict__ xbuf,
-                                                          const XCtrl *ctrl, int flag_rank0, int w_lo, int w_hi)
+                                                          const XCtrl *ctrl, int flag_rank0, int w_lo, int w_hi, const long long *__restrict__ sdst = nullptr)
 {
+    // sdst (slab-distributed solve): S rank q's so tile sums go to xbuf[sdst[q]] -- the piece for the rank that owns the row (the control words are
+    // written by k_xtb_slab_tail)
     if (ctrl->done) return;
     const int v = threadIdx.x & 15, r4 = threadIdx.x >> 4;
     const int rec_shift = nitem_w[2 * (nW + 2)];
@@ -516,11 +527,11 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_fold_local(int ns, int nK, int nW
             xtb_list_sum2(rpp, rs, (size_t)16 * so, wr.x, wr.y, rA_, rB_);
             tA = cA + rA_; tB = cB + rB_;
             const int sA = XT_R * k + r4, sB = sA + 16;
-            if (sA < ns) xbuf[(size_t)sA * so + v] = tA;
-            if (sB < ns) xbuf[(size_t)sB * so + v] = tB;
+            if (sA < ns) xbuf[(sdst ? (size_t)sdst[sA] : (size_t)sA * so) + v] = tA;
+            if (sB < ns) xbuf[(sdst ? (size_t)sdst[sB] : (size_t)sB * so) + v] = tB;
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (!sdst && blockIdx.x == 0 && threadIdx.x == 0) {
         xbuf[(size_t)ns * so] = (flag_rank0 && ctrl->done_local) ? 1.0 : 0.0;
         xbuf[(size_t)ns * so + 1] = ctrl->abort_local ? 1.0 : 0.0;
     }
@@ -551,7 +562,8 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_rows(int ns, int nK, int nW, int 
             for (int r = 0; r < nr; ++r) ab |= xbuf[r * xslot + (size_t)ns * so + 1] != 0.0;
             if (xbuf[(size_t)ns * so] != 0.0 || ab) {                         // rank 0's stop decision; anybody's abort word
                 sdone = 1;
-                if (blockIdx.x == 0) { ctrl->done = it + 1; if (ab) ctrl->aborted = 1; }     // stops this iteration's step kernel too
+                // stops this iteration's step kernel too; the set-up pass (it = -1) must latch a NON-ZERO stamp as well
+                if (blockIdx.x == 0) { ctrl->done = it + 1 > 0 ? it + 1 : 1; if (ab) ctrl->aborted = 1; }
             }
         }
     }
@@ -766,15 +778,28 @@ __device__ __forceinline__ void xtb_chol_solve(XB_M(X), XB_M(L), XB_M(B), int s)
     }
     XB_WSYNC();
 }
-__global__ __launch_bounds__(64) void k_xtb_small(int it, int s, const double *__restrict__ gfin, double *__restrict__ mats, XCtrl *ctrl, double tol2)
+// nrg > 1 (slab-distributed solve): gfin holds one block of gstride doubles per rank -- that rank's partial Gram matrices and, behind them, its
+// abort word -- all-gathered; every rank adds the blocks IN RANK ORDER: identical matrices, hence identical decisions, on every rank.
+__global__ __launch_bounds__(64) void k_xtb_small(int it, int s, const double *__restrict__ gfin, double *__restrict__ mats, XCtrl *ctrl, double tol2,
+                                                  int nrg = 1, int gstride = 0)
 {
     __shared__ double Gm[XB_NG][16][17], Lp[16][17], Cm[16][17], Vm[16][17], Bm[16][17], Grn[16][17], Gprn[16][17], Gg[16][17], Wm[16][17], Tm[16][17];
     if (ctrl->done) return;
+    if (nrg > 1) {
+        bool ab = false;
+        for (int r = 0; r < nrg; ++r) ab |= gfin[(size_t)r * gstride + XB_NG * 256 + 1] != 0.0;
+        if (ab) { if (threadIdx.x == 0) { ctrl->aborted = 1; ctrl->done = it + 1 > 0 ? it + 1 : 1; } return; }      // uniform: every lane read the same words
+    }
     // Gram matrices: entry e = (register u, lane l) of the row kernel's accumulators is (l / 16 + 4 u, l % 16)
 #pragma unroll
     for (int g = 0; g < XB_NG; ++g)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int l = threadIdx.x; Gm[g][(l >> 4) + 4 * u][l & 15] = gfin[g * 256 + u * 64 + l]; }
+        for (int u = 0; u < 4; ++u) {
+            const int l = threadIdx.x;
+            double a = gfin[g * 256 + u * 64 + l];
+            for (int r = 1; r < nrg; ++r) a += gfin[(size_t)r * gstride + g * 256 + u * 64 + l];
+            Gm[g][(l >> 4) + 4 * u][l & 15] = a;
+        }
     XB_WSYNC();
     const bool init = it < 0;
     double rr_new;
@@ -876,9 +901,11 @@ __global__ __launch_bounds__(64) void k_xtb_small(int it, int s, const double *_
 // ---- panel updates: Y += P c ; R += T c ; P = R M1 + T M3 + P M2 ; Q = S P -------------------------------------------------------------
 // 16 rows per wave and step: the three panels as A operands (row on i, vector on k), the 16 x 16 matrices as B operands, Y and R as
 // accumulator input.  P is formed from the ORIGINAL R, T, P (M3 = c M1), so no result has to change its register map.
+// rowlist (slab-distributed solve): the rows are the m entries of this rank's list (the two driver rows, replicated, + the rows it owns).
 __global__ __launch_bounds__(XT_NT) void k_xtb_step(int m, int it, const double *__restrict__ mats, double *__restrict__ y0, double *__restrict__ R,
                                                     double *__restrict__ P, const double *__restrict__ T, const double *__restrict__ sc,
-                                                    const int *__restrict__ nsrank, double *__restrict__ QS, const XCtrl *ctrl)
+                                                    const int *__restrict__ nsrank, double *__restrict__ QS, const XCtrl *ctrl,
+                                                    const int *__restrict__ rowlist = nullptr)
 {
     __shared__ int sdone;
     if (threadIdx.x == 0) { const int d = ctrl->done; sdone = d != 0 && it + 1 >= d; }
@@ -898,20 +925,23 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_step(int m, int it, const double 
         const int row0 = 16 * g;
         double pa[4], ta[4], ra[4];
         const bool oka = row0 + a < m;
-        const size_t oa = (size_t)(row0 + a) * XB_SP + b;
+        const int rowa = oka ? (rowlist ? rowlist[row0 + a] : row0 + a) : 0;
+        const size_t oa = (size_t)rowa * XB_SP + b;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { pa[kk] = oka ? P[oa + 4 * kk] : 0.0; ta[kk] = oka ? T[oa + 4 * kk] : 0.0; ra[kk] = oka ? R[oa + 4 * kk] : 0.0; }
         dbl4 rN, pN = (dbl4)(0.0);
-        const double yold = (b == 0 && oka) ? y0[row0 + a] : 0.0;
+        const double yold = (b == 0 && oka) ? y0[rowa] : 0.0;
+        int rowu[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int row = row0 + b + 4 * u;
-            rN[u] = row < m ? R[(size_t)row * XB_SP + a] : 0.0;
+            const int li = row0 + b + 4 * u;
+            rowu[u] = li < m ? (rowlist ? rowlist[li] : li) : -1;
+            rN[u] = rowu[u] >= 0 ? R[(size_t)rowu[u] * XB_SP + a] : 0.0;
         }
-        // y0[row0 + a] += sum_i P[row0 + a][i] c[i][0]: lane (a, b) holds i = 4 kk + b; the four b-groups are added in a fixed order
+        // y0[row] += sum_i P[row][i] c[i][0]: lane (a, b) holds i = 4 kk + b; the four b-groups are added in a fixed order
         double yacc = (pa[0] * c0[0] + pa[1] * c0[1]) + (pa[2] * c0[2] + pa[3] * c0[3]);
         yacc += __shfl_xor(yacc, 16, WAVE); yacc += __shfl_xor(yacc, 32, WAVE);
-        if (b == 0 && oka) y0[row0 + a] = yold + yacc;
+        if (b == 0 && oka) y0[rowa] = yold + yacc;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             rN = XB_MFMA(ta[kk], cB[kk], rN);
@@ -919,8 +949,8 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_step(int m, int it, const double 
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int row = row0 + b + 4 * u;
-            if (row < m) {
+            const int row = rowu[u];
+            if (row >= 0) {
                 const size_t o = (size_t)row * XB_SP + a;
                 R[o] = rN[u]; P[o] = pN[u];
                 const int sr = nsrank[row];
@@ -971,7 +1001,22 @@ int g_xtb_fault_iter = -1;
 // ---- host loop ------------------------------------------------------------------------------------------------------------------------
 // Returns 0 with the scaled solution of column 0 in A.y; DKMC_XTB_BREAKDOWN (> 0, no error recorded) when an s x s system lost
 // definiteness: A.y then holds the last good iterate and the caller continues with the single-vector loop from it.
+static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *peer_used);
+#define XS_MAXR 32
+static int xtb_cg_slab(const XtbArgs &A, int nr, int me0, const XShare *emu_shares, int time_rank, int *iters_out, double *rr_out);
 int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
+{
+    bool peer_used = false;
+    // more than one rank: the state of the solve is distributed by row slabs (xtb_slab.inc; dkmc_set_x_slab(0) keeps the all-gather variant
+    // below, which shards the tile stream only)
+    if (A.sharded && eng().x_slab && comm_nranks() > 1 && comm_nranks() <= XS_MAXR && A.ay && A.az)
+        return xtb_cg_slab(A, comm_nranks(), comm_rank(), nullptr, -1, iters_out, rr_out);
+    const int rc = xtb_cg_body(A, iters_out, rr_out, &peer_used);
+    // a sharded solve that failed with the peer-write exchange in use: the ranks' sequence counters may have drifted (comm.hip)
+    if (rc != 0 && rc != DKMC_XTB_BREAKDOWN && peer_used) comm_peer_drop();
+    return rc;
+}
+static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *peer_used)
 {
     Engine &e = eng(); hipStream_t st = e.stream;
     const int m = A.m, s = A.s, so = 4 * ((s + 3) / 4);                       // vector groups of four: the matrix instruction's width
@@ -1000,6 +1045,7 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
     const size_t xcount = (size_t)A.ns * so + 2;
     // exchange: the one-shot peer-write exchange when it is attached (comm.hip: push + signal + wait, no collective call), else one all-gather
     const bool peer = sharded && comm_peer_ready(xcount);
+    *peer_used = peer;
     int xpar = 0;
     if (sharded) {
         if (!peer) { xbuf = (double *)scratch(S_CG_XCHG, xcount * nr * 8); if (!xbuf) return e.err_code; }
@@ -1089,7 +1135,7 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
     for (;;) {
         HIPCHK(hipMemcpyAsync(&h, A.ctrl, sizeof(XCtrl), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        if (prof && launched) {
+        if (prof && launched && ntb > 0) {
             for (int bq = 0; bq < 8 && bq * XT_PROF_STRIDE < launched; ++bq) {
                 if (it - launched + bq * XT_PROF_STRIDE >= h.iters) break;
                 float ms = 0.f;
@@ -1100,7 +1146,7 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
         if (h.done) break;
         if (it >= 200000) { dkmc_fail(4, "block-CG: no convergence after 200000 iterations", __FILE__, __LINE__); break; }
         for (int bq = 0; bq < batch; ++bq, ++it) {
-            const bool pb = prof && bq < 8 * XT_PROF_STRIDE && (bq % XT_PROF_STRIDE == 0);
+            const bool pb = prof && ntb > 0 && bq < 8 * XT_PROF_STRIDE && (bq % XT_PROF_STRIDE == 0);      // (no tile launch: its events would never be recorded)
             const int sl = bq / XT_PROF_STRIDE;
             if (g_xtb_fault_iter >= 0 && sharded && it >= g_xtb_fault_iter) { g_xtb_fault_iter = -1; local_fail = dkmc_fail(91, "injected fault (block-CG iteration)", __FILE__, __LINE__); }
             product(pb ? evs[4 * sl] : nullptr, pb ? evs[4 * sl + 1] : nullptr);
@@ -1127,6 +1173,16 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
         e.stats.spmv_long_launches = prof_long_n; e.stats.spmv_short_launches = prof_short_n;
     }
     return h.pad[0] ? DKMC_XTB_BREAKDOWN : 0;
+}
+
+#include "xtb_slab.inc"
+// emulation entry (xt.hip: dkmc_xtb_emulate_slabs): nr virtual ranks in this process on the resident X of a single-GPU solve
+int xtb_cg_slab_emulate(const XtbArgs &A, int nr, const XShare *shares, int time_rank, int *iters_out, double *rr_out, double *times_us, long long *xdoubles)
+{
+    const int rc = xtb_cg_slab(A, nr, 0, shares, time_rank, iters_out, rr_out);
+    if (times_us) for (int c = 0; c < 8; ++c) times_us[c] = g_slab_times.us[c];
+    if (xdoubles) for (int c = 0; c < 3; ++c) xdoubles[c] = g_slab_xbytes[c];
+    return rc;
 }
 
 // ---- test aid (tests/test_gpu_block_cg.py; no counterpart in the reference) ---------------------------------------------------------------

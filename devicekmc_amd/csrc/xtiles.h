@@ -41,6 +41,7 @@ struct XTBuffers {
     SNodes S; int *srow; XTile *tiles; XItem *items; int2 *wrange; int *nitem_w; double *tval, *rowpart, *colpart;
     xrp_t *rp, *dpos; int *ci; double *val; int *nsrank;
     unsigned *cmask; int *toff;      // census of the last assembly (kept for dkmc_xt_time_share)
+    const double *ax, *ay, *az;      // atom positions of the last assembly (dkmc_xtb_emulate_slabs)
 };
 
 extern XTState g_xt;
@@ -72,4 +73,9 @@ struct XtbArgs {
     bool sharded; int w_lo, w_hi;                 // sharded solve (comm.hip): windows of this rank's tiles
 };
 int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out);
+// one rank's share of the work items of an nranks-way split (xt.hip: xt_build_items)
+struct XShare { int nitems, maxchunk, item_lo, item_n, tile_lo, tile_n, w_lo, w_hi; long long sub_base, sub_n; XItem *items; int *nitem_w; int rec_shift; };
+// the slab-distributed block-CG with nr VIRTUAL ranks in this process (xtb_slab.inc); times_us[8]: mean kernel times of virtual rank time_rank
+// (apply, neighbour part, fold, rows, Gram reduction, s x s algebra, step, pack + unpack); xdoubles[3]: doubles a rank receives per sweep in the three exchanges
+int xtb_cg_slab_emulate(const XtbArgs &A, int nr, const XShare *shares, int time_rank, int *iters_out, double *rr_out, double *times_us, long long *xdoubles);
 __global__ void k_xt_vec_mul(int m, double *__restrict__ y, const double *__restrict__ s);

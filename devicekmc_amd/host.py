@@ -310,22 +310,26 @@ class KMCProcess:
         return {"Z - calculation time - kmc events [s]": time.perf_counter() - t0}, et.value
 
 
-def save_restart(path, device: Device, sim: KMCProcess, gpubuf: GPUBuffers, kmc_time=0.0, kmc_step_count=0, current_warm_start=0):
+def save_restart(path, device: Device, sim: KMCProcess, gpubuf: GPUBuffers, kmc_time=0.0, kmc_step_count=0):
     """Device::writeSnapshot (Device.cpp:236-252) + the state it drops (io.write_restart): after load_restart the run continues with
-    the same event sequence, bit for bit.  That holds for the reference's start vector of the current solve (dkmc_set_current_warm_start(0):
-    gpubuf.atom_virtual_potentials, saved here).  Mode 1 keeps a private unscaled copy inside the library that the C ABI does not export:
-    a run in that mode states it (current_warm_start=1), and load_restart refuses the sidecar rather than continue on another iterate."""
+    the same event sequence, bit for bit.  The start vector of the next current solve is part of that state in both modes of
+    dkmc_set_current_warm_start: gpubuf.atom_virtual_potentials (mode 0 reads it) and the library's private unscaled copy of the last
+    solution (mode 1, the default; dkmc_get_current_warm_vector)."""
     from . import io
-    if current_warm_start not in (0, 1):
-        raise ValueError("current_warm_start must be 0 or 1")
+    L = _lib.load()
     gpubuf.sync_GPUToHost(device)
+    n = C.c_int(0)
+    check(L.dkmc_get_current_warm_vector(C.byref(gpubuf.c), None, 0, C.byref(n)))
+    warm = np.zeros(n.value)
+    if n.value:
+        check(L.dkmc_get_current_warm_vector(C.byref(gpubuf.c), _np_ptr(warm), n.value, C.byref(n)))
     state = dict(site_charge=device.site_charge, site_potential_boundary=device.site_potential_boundary,
                  site_potential_charge=device.site_potential_charge, site_power=device.site_power,
                  site_temperature=device.site_temperature, site_CB_edge=device.site_CB_edge,
-                 atom_virtual_potentials=gpubuf.atom_virtual_potentials.cpu().numpy(),
+                 atom_virtual_potentials=gpubuf.atom_virtual_potentials.cpu().numpy(), current_warm_vector=warm,
                  T_bg=float(device.T_bg), kmc_time=float(kmc_time), kmc_step_count=int(kmc_step_count),
                  rnd_seed_kmc=int(sim.random_generator.seed), kmc_rng_raw_draws=int(sim.random_generator.n_raw),
-                 current_warm_start=int(current_warm_start), N_atom_buffer=int(gpubuf.N_atom_))
+                 current_warm_start=int(L.dkmc_get_current_warm_start()), N_atom_buffer=int(gpubuf.N_atom_))
     io.write_restart(path, device.site_element, device.site_x, device.site_y, device.site_z, state)
 
 
@@ -348,9 +352,11 @@ def load_restart(path, p: KMCParameters, device="cuda:0", gpu_neighbors=None):
         dev.site_CB_edge = np.asarray(state["site_CB_edge"], dtype=np.float64)
         dev.T_bg = float(state["T_bg"])
         gb.sync_HostToGPU(dev)
-        if int(state.get("current_warm_start", 0)) != 0:
-            raise ValueError("restart sidecar was written by a run with dkmc_set_current_warm_start(1): its private start vector is not in "
-                             "the sidecar, a bit-identical continuation is not possible")
+        warm = np.asarray(state["current_warm_vector"], dtype=np.float64) if "current_warm_vector" in state else np.zeros(0)
+        if int(state.get("current_warm_start", 0)) != 0 and "current_warm_vector" not in state:
+            raise ValueError("restart sidecar was written in warm-start mode 1 by a version that did not save the private start vector: "
+                             "a bit-identical continuation is not possible")
+        check(_lib.load().dkmc_set_current_warm_vector(C.byref(gb.c), _np_ptr(warm) if len(warm) else None, len(warm)))
         # the start vector of the next current solve: entries [0, Na + 1) of the saved buffer are read (Na = atoms of the snapshot).  The
         # buffer of the saved run was sized for ITS initial atom count, this one for the snapshot's: the used part must fit both.
         m = np.asarray(state["atom_virtual_potentials"], dtype=np.float64)

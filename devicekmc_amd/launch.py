@@ -31,12 +31,27 @@ def run_ranks(script, argv, nranks, timeout=None) -> int:
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL / cross-process device memory need it on this host driver
     env.pop("RANK", None); env.pop("WORLD_SIZE", None); env.pop("LOCAL_RANK", None)
     cmd = rank_command(script, argv, nranks, free_port())
+    # the rank group runs in its own session: on a time-out the WHOLE group is ended (SIGTERM, then SIGKILL), not just the launcher --
+    # orphaned ranks would keep holding the GPU while the caller reports a failure
+    import signal
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env, start_new_session=True)
     try:
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=None, text=True, env=env, timeout=timeout)
-    except subprocess.TimeoutExpired as exc:
-        sys.stderr.write("launch: the rank group did not finish within %s s\n" % timeout)
-        out = exc.stdout or ""
-        r = subprocess.CompletedProcess(cmd, 3, out if isinstance(out, str) else out.decode(), None)
+        out, _ = proc.communicate(timeout=timeout)
+        r = subprocess.CompletedProcess(cmd, proc.returncode, out, None)
+    except subprocess.TimeoutExpired:
+        sys.stderr.write("launch: the rank group did not finish within %s s -- ending process group %d\n" % (timeout, proc.pid))
+        out = ""
+        for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 10.0)):
+            try:
+                os.killpg(proc.pid, sig)          # start_new_session: the child's pid is its process-group id
+            except ProcessLookupError:
+                break
+            try:
+                out, _ = proc.communicate(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        r = subprocess.CompletedProcess(cmd, 3, out or "", None)
     line = None
     for ln in (r.stdout or "").splitlines():
         s = ln.strip()

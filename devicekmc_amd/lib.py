@@ -46,7 +46,7 @@ class dkmc_stats(C.Structure):
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
 
 
-# every symbol include/devicekmc_hip.h declares: name -> (restype, argtypes)
+# every symbol include/devicekmc_hip.h and include/devicekmc_hip_debug.h declare: name -> (restype, argtypes)
 _I, _D = C.c_int, C.c_double
 SYMBOLS = {
     "dkmc_last_error": (C.c_char_p, []),
@@ -60,6 +60,8 @@ SYMBOLS = {
     "dkmc_set_cb_edge_domain": (None, [_I]),
     "dkmc_set_x_block": (None, [_I]),
     "dkmc_get_x_block": (_I, []),
+    "dkmc_set_x_slab": (None, [_I]),
+    "dkmc_get_x_slab": (_I, []),
     "dkmc_set_x_aux": (None, [_I]),
     "dkmc_get_x_aux": (_I, []),
     "dkmc_set_k_blocked": (None, [_I]),
@@ -68,6 +70,9 @@ SYMBOLS = {
     "dkmc_reset_pair_sum_cache": (None, []),
     "dkmc_set_tcache_budget": (None, [C.c_longlong]),
     "dkmc_set_current_warm_start": (None, [_I]),
+    "dkmc_get_current_warm_start": (_I, []),
+    "dkmc_get_current_warm_vector": (_I, [C.POINTER(dkmc_gpubuf), vp, _I, c_int_p]),
+    "dkmc_set_current_warm_vector": (_I, [C.POINTER(dkmc_gpubuf), vp, _I]),
     "dkmc_set_profiling": (None, [_I]),
     "dkmc_set_x_format": (None, [_I]),
     "dkmc_get_x_format": (_I, []),
@@ -104,6 +109,7 @@ SYMBOLS = {
     "dkmc_xt_check_shares": (_I, [_I, c_dbl_p, c_dbl_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), c_int_p]),
     "dkmc_xtb_check_product": (_I, [_I, c_dbl_p, c_dbl_p]),
     "dkmc_xtb_time_apply": (_I, [_I, _I, _I, c_dbl_p]),
+    "dkmc_xtb_emulate_slabs": (_I, [_I, _I, _D, _I, c_dbl_p, c_int_p, c_int_p, c_dbl_p, C.POINTER(C.c_longlong), c_int_p]),
     "dkmc_debug_inject_fault": (None, [_I, _I]),
     "dkmc_debug_step_stop_word": (_I, [_I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dkmc_comm_unique_id": (_I, [C.c_char_p]),

@@ -126,13 +126,14 @@ def attach_peer_exchange(slot_doubles, group=None):
     """One-shot peer-write exchange of the sharded block-CG beside the attached communicator (csrc/comm.hip): every rank exports its
     exchange buffer (hipIpc), the handles travel through the process group, every rank maps every peer's buffer.  slot_doubles: capacity of
     a slot, >= 16 |S| + 2 of the solves to come (a solve whose slot does not fit falls back to the communicator's all-gather on every rank
-    alike).  All ranks must sit on one node.  Returns True on every rank, or False on every rank if any rank could not map a peer."""
+    alike).  All ranks must sit on one node.  Returns True on every rank, or False on every rank if any rank could not map a peer -- or if
+    the ranks sit on different devices, which the library refuses (validated on one device only; DKMC_PEER_CROSS_DEVICE=1 overrides)."""
     import ctypes
     from . import lib
     L = lib.load()
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    mine = ctypes.create_string_buffer(128)
+    mine = ctypes.create_string_buffer(192)          # two hipIpc handles + the rank's device identity (csrc/comm.hip)
     ok = L.dkmc_comm_peer_prepare(int(slot_doubles), mine) == 0
     on_gpu = dist.is_initialized() and dist.get_backend(group) == "nccl"
     dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")

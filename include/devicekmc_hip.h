@@ -145,6 +145,12 @@ void dkmc_reset_pair_sum_cache(void);
  * with the single-vector loop to the stop tolerance, NOT iterate by iterate.  85 071 sites: 666 -> 208 / 133 / 95 sweeps at s = 4 / 8 / 16. */
 void dkmc_set_x_block(int s);
 int dkmc_get_x_block(void);
+/* More than one rank (dkmc_comm_*): 1 (default) distributes the STATE of the block-CG by spatial row slabs -- a rank owns the rows of one lateral
+ * slab of the device: neighbour part, Gram pass and panel updates run on its rows only; per sweep the tile sums of the S rows go to their owners
+ * (all-to-all-v), 6 x 256 Gram entries are all-gathered and added in rank order, the own rows of Q = S P and the halo rows of P go out
+ * (all-to-all-v) (csrc/xtb_slab.inc).  0: the all-gather variant -- only the tile stream is sharded, everything else replicated. */
+void dkmc_set_x_slab(int on);
+int dkmc_get_x_slab(void);
 /* Auxiliary right-hand sides of the block-CG (a free choice: only their block Krylov space matters; column 0 is always the physical system).
  * 0: fixed-seed hash of (row, column), uniform in [-1, 1).  1: smooth set, column v = cos(v pi xi) / s with xi the atom's x coordinate scaled to
  * [0, 1] -- rich in the low modes of the neighbour part of X: 20-35 % fewer sweeps at the default tolerance.  2 (default): the smooth set at
@@ -158,10 +164,16 @@ int dkmc_get_x_aux(void);
  * 0: the solve uses the CSR positions of the pattern (the only form above that size).  Read when a pattern is built. */
 void dkmc_set_k_blocked(int on);
 int dkmc_get_k_blocked(void);
-/* 0 (default): warm-start the current solve from gpubuf.atom_virtual_potentials exactly as the
- * reference does (the buffer holds G0*m of the previous step, current_solver_gpu.cu:1015-1016);
- * 1: warm-start from a private unscaled copy of the previous solution. */
+/* Start vector of the current solve.  1 (default): the previous step's solution, from a private unscaled copy kept per GPUBuffers -- what
+ * the reference's own comment asks for ("use the previous solution as the initial guess", current_solver_gpu.cu:976-977).  0: whatever
+ * gpubuf.atom_virtual_potentials holds, exactly as the reference code does -- and that buffer was scaled by G0 in place after the previous
+ * solve (current_solver_gpu.cu:1013-1016), so the reference starts from G0*m, i.e. practically from zero: the reference-order switch
+ * (with dkmc_set_x_block(1): the reference's iterate sequence).  Either way the contract is the solution within the stop test; the first
+ * solve of a run starts from the buffer in both modes.  dkmc_get/set_current_warm_vector export and restore the private copy (restart). */
 void dkmc_set_current_warm_start(int mode);
+int dkmc_get_current_warm_start(void);
+int dkmc_get_current_warm_vector(const dkmc_gpubuf *buf, double *h_out, int capacity, int *n_out);
+int dkmc_set_current_warm_vector(const dkmc_gpubuf *buf, const double *h_in, int n);
 /* 1: bracket every SpMV launch of the CG solves with HIP events on the engine's stream and accumulate
  * their durations into dkmc_stats (measurement aid for bench.py; off by default) */
 void dkmc_set_profiling(int on);
@@ -298,33 +310,8 @@ int dkmc_update_temperature_local(dkmc_gpubuf *buf, double step_time, double del
                                   double k_th_interface, double k_th_vacancies, double nn_dist, int num_atoms_contact,
                                   int *n_solves_out, int *steady_out, int *cg_iters_out, double *T_bg_out);
 
-/* measurement aid (bench.py's strong-scaling model): on the tiled X left resident by the last single-GPU update_power, the time per CG
- * iteration of what ONE rank of an nranks-way sharded solve runs -- apply_us: the apply kernel over that rank's share of the tiles
- * (work items sized as an nranks run sizes them) + the neighbour part; side_us[4]: partial row sums, finish, vector step, and -- nranks > 1 or a multi-GB sweep, where apply_us is the tile pass alone -- the
- * neighbour part that a sharded solve runs on a second stream beside the exchange (each timed on its own).  The
- * all-reduce between them cannot be measured on one GPU.  Scratch vectors are overwritten; results of the last solve already
- * delivered (potentials, I_macro, power) are not. */
-int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_us, double *side_us /* [4] */, int *items_out, long long *subblocks_out);
-/* Test aid: emulates on ONE GPU the tile pass of an nranks-way sharded matrix-vector product over the X of the last single-GPU solve
- * (every rank's work items built as a sharded assembly builds them, partial arrays zeroed per rank, partial row sums restricted to
- * the rank's windows) and compares the sum of the ranks' results with the one-GPU pass.  subblocks_sum / items_sum: totals over the
- * shares (must equal the stored sub-blocks / items_total: every tile in exactly one share). */
-int dkmc_xt_check_shares(int nranks, double *max_abs_diff, double *max_abs, long long *subblocks_sum, long long *items_sum, int *items_total);
-/* Test aid: on the X left resident by the last single-GPU solve, the MFMA tile x panel product of the block-CG (16 test vectors, one
- * sweep) against 16 passes of the single-vector tile kernel; largest absolute deviation and largest sum over the S rows. */
-int dkmc_xtb_check_product(int width, double *max_abs_diff, double *max_abs);
-/* Measurement aid: average duration [us] of the tile x panel kernel of the block-CG over the X left resident by the last single-GPU solve
- * (`reps` launches).  variant 0: as a solve runs it; 1: without its matrix instructions (tile stream + LDS traffic); 2: without re-reading
- * the tile stream (matrix instructions + LDS traffic). */
-int dkmc_xtb_time_apply(int width, int variant, int reps, double *us);
-/* Test aid for the error path of a sharded current solve (no counterpart in the reference): the calling rank fails ONCE, in the
- * assembly of X (phase 1) or on the host side of CG iteration `iteration` (phase 2).  Every rank's dkmc_update_power_gpu_sparse then
- * returns non-zero (the failing rank its own code, the others 46) instead of blocking in a collective: the ranks agree on the
- * outcome of the local set-up before the first collective, and inside the loop an abort word travels with every all-reduce. */
-void dkmc_debug_inject_fault(int phase, int iteration);
-/* test aid: one launch of the CG step kernel of iteration `it` over m elements with the stop word preset to done_word; *updated = elements of y it
- * changed (0 / it + 2: all; 1 ... it + 1: none), *done_after = the stop word afterwards (csrc/xt.hip: k_xt_step's iteration-stamped stop word) */
-int dkmc_debug_step_stop_word(int m, int it, int done_word, int *updated, int *done_after);
+/* (test and measurement aids of the library -- dkmc_xt_time_share, dkmc_xt_check_shares, dkmc_xtb_check_product, dkmc_xtb_time_apply,
+ * dkmc_debug_* -- are declared in devicekmc_hip_debug.h: they are exported by the .so but are not part of the drop-in surface) */
 
 /* ---- multi-GPU: one simulation advanced in lockstep by N processes, one GPU each (no reference counterpart) ----
  * While a communicator is attached, update_power_gpu_sparse generates, stores and streams the tunnelling block of X in per-rank
@@ -347,11 +334,12 @@ int dkmc_comm_allgather_host(double *host_buf, size_t count_per_rank);  /* the c
 int dkmc_comm_info(int *nranks, int *rank, int *transport);
 int dkmc_comm_destroy(void);
 /* One-shot peer-write exchange of the sharded block-CG (csrc/comm.hip): beside an attached communicator, every rank
- * exports an exchange buffer of 2 x nranks slots of slot_doubles doubles and a row of sequence words (hipIpc); prepare returns this rank's
- * two handles (128 bytes), the host all-gathers them through its process group and hands all of them (nranks x 128 bytes, rank order) to
- * attach.  A sweep's exchange is then push + signal + bounded wait on the engine's stream and the slots are added in rank order; a solve
+ * exports an exchange buffer of 2 x nranks slots of slot_doubles doubles and a row of sequence words (hipIpc; fine-grained device memory, so
+ * that a peer DEVICE's stores are visible without a kernel boundary); prepare returns this rank's two handles + its device identity (192
+ * bytes), the host all-gathers them through its process group and hands all of them (nranks x 192 bytes, rank order) to attach.  attach
+ * refuses (error 49) a group whose ranks sit on different devices unless DKMC_PEER_CROSS_DEVICE=1 -- that case has never been run.  A sweep's exchange is then push + signal + bounded wait on the engine's stream and the slots are added in rank order; a solve
  * whose slots do not fit uses the communicator's all-gather.  Tested with two processes on one GPU; opt-in.  The reference has no counterpart. */
-int dkmc_comm_peer_prepare(size_t slot_doubles, char *handles128);
+int dkmc_comm_peer_prepare(size_t slot_doubles, char *handles192);
 int dkmc_comm_peer_attach(const char *all_handles);
 int dkmc_comm_peer_detach(void);
 int dkmc_comm_peer_info(int *ready, long long *slot_doubles, long long *exchanges, double *mean_us);

@@ -1,0 +1,52 @@
+/*
+ * devicekmc_hip_debug.h -- test and measurement aids exported by libdevicekmc_hip.so.  NOT part of the drop-in boundary
+ * (include/devicekmc_hip.h): nothing here replaces a reference symbol; tests/ and bench.py bind them through devicekmc_amd/lib.py.
+ */
+#ifndef DEVICEKMC_HIP_DEBUG_H
+#define DEVICEKMC_HIP_DEBUG_H
+#include "devicekmc_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* measurement aid (bench.py's strong-scaling model): on the tiled X left resident by the last single-GPU update_power, the time per CG
+ * iteration of what ONE rank of an nranks-way sharded solve runs -- apply_us: the apply kernel over that rank's share of the tiles
+ * (work items sized as an nranks run sizes them) + the neighbour part; side_us[4]: partial row sums, finish, vector step, and -- nranks > 1 or a multi-GB sweep, where apply_us is the tile pass alone -- the
+ * neighbour part that a sharded solve runs on a second stream beside the exchange (each timed on its own).  The
+ * all-reduce between them cannot be measured on one GPU.  Scratch vectors are overwritten; results of the last solve already
+ * delivered (potentials, I_macro, power) are not. */
+int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_us, double *side_us /* [4] */, int *items_out, long long *subblocks_out);
+/* Test aid: emulates on ONE GPU the tile pass of an nranks-way sharded matrix-vector product over the X of the last single-GPU solve
+ * (every rank's work items built as a sharded assembly builds them, partial arrays zeroed per rank, partial row sums restricted to
+ * the rank's windows) and compares the sum of the ranks' results with the one-GPU pass.  subblocks_sum / items_sum: totals over the
+ * shares (must equal the stored sub-blocks / items_total: every tile in exactly one share). */
+int dkmc_xt_check_shares(int nranks, double *max_abs_diff, double *max_abs, long long *subblocks_sum, long long *items_sum, int *items_total);
+/* Test aid: on the X left resident by the last single-GPU solve, the MFMA tile x panel product of the block-CG (16 test vectors, one
+ * sweep) against 16 passes of the single-vector tile kernel; largest absolute deviation and largest sum over the S rows. */
+int dkmc_xtb_check_product(int width, double *max_abs_diff, double *max_abs);
+/* Measurement aid: average duration [us] of the tile x panel kernel of the block-CG over the X left resident by the last single-GPU solve
+ * (`reps` launches).  variant 0: as a solve runs it; 1: without its matrix instructions (tile stream + LDS traffic); 2: without re-reading
+ * the tile stream (matrix instructions + LDS traffic). */
+int dkmc_xtb_time_apply(int width, int variant, int reps, double *us);
+/* Test aid for the error path of a sharded current solve (no counterpart in the reference): the calling rank fails ONCE, in the
+ * assembly of X (phase 1) or on the host side of CG iteration `iteration` (phase 2).  Every rank's dkmc_update_power_gpu_sparse then
+ * returns non-zero (the failing rank its own code, the others 46) instead of blocking in a collective: the ranks agree on the
+ * outcome of the local set-up before the first collective, and inside the loop an abort word travels with every all-reduce. */
+void dkmc_debug_inject_fault(int phase, int iteration);
+/* test aid: one launch of the CG step kernel of iteration `it` over m elements with the stop word preset to done_word; *updated = elements of y it
+ * changed (0 / it + 2: all; 1 ... it + 1: none), *done_after = the stop word afterwards (csrc/xt.hip: k_xt_step's iteration-stamped stop word) */
+int dkmc_debug_step_stop_word(int m, int it, int done_word, int *updated, int *done_after);
+
+/* Test / measurement aid: the slab-distributed block-CG (csrc/xtb_slab.inc) with nranks VIRTUAL ranks inside this process, on the X left resident
+ * by the last single-GPU solve: the same system solved by the one-GPU block-CG and by the distributed loop (shares of the tiles as a sharded
+ * assembly builds them, rows owned by lateral slabs, exchanges as device copies), both from a zero start to `tol`.  rel_diff: largest deviation of
+ * the two solutions / largest entry; times_us[8]: mean kernel times of virtual rank time_rank (apply, neighbour part, fold, rows, Gram reduction,
+ * s x s algebra, step, pack + unpack); xdoubles[3]: doubles a rank receives per sweep in the three exchanges; rows_min_max[2]: rows of the smallest
+ * and largest slab.  Fails if the virtual ranks leave the loop at different sweeps or end with different bits. */
+int dkmc_xtb_emulate_slabs(int nranks, int width, double tol, int time_rank, double *rel_diff, int *iters_slab, int *iters_ref,
+                           double *times_us, long long *xdoubles, int *rows_min_max);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

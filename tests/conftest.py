@@ -13,6 +13,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs an MI355X (run with -m gpu)")
 
 
+@pytest.fixture(autouse=True)
+def _library_defaults():
+    """Every test starts from the library's default switches (a test that leaves one flipped must not change what the next one checks).
+    Only when the HIP library is already in the process: CPU tests never load it here."""
+    from devicekmc_amd import lib
+    L = lib._lib
+    if L is not None:
+        L.dkmc_set_current_warm_start(1); L.dkmc_set_x_block(16); L.dkmc_set_x_format(1); L.dkmc_set_x_aux(2)
+        L.dkmc_set_cg_tolerance(1e-6); L.dkmc_set_cb_edge_domain(0); L.dkmc_set_tcache_budget(-1); L.dkmc_set_pair_cutoff(6.5)
+        L.dkmc_set_k_blocked(1); L.dkmc_set_profiling(0)
+    yield
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -1,4 +1,5 @@
-"""The C-ABI library loads and exports exactly what include/devicekmc_hip.h declares (no GPU needed)."""
+"""The C-ABI library loads and exports exactly what include/devicekmc_hip.h (the drop-in surface) and include/devicekmc_hip_debug.h (test and
+measurement aids, not part of the surface) declare (no GPU needed)."""
 import ctypes
 import os
 import re
@@ -8,10 +9,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "devicekmc_hip.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(dkmc_\w+)\s*\(", src)))
+def _declared(headers=("devicekmc_hip.h", "devicekmc_hip_debug.h")):
+    names = set()
+    for h in headers:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(dkmc_\w+)\s*\(", src))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
@@ -24,6 +28,9 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert set(names) == set(lib.SYMBOLS), set(names) ^ set(lib.SYMBOLS)
+    # the drop-in header carries no test / timing hooks
+    surface = _declared(("devicekmc_hip.h",))
+    assert not [n for n in surface if "debug" in n or "check" in n or "_time_" in n], surface
 
 
 def test_struct_layout_matches_header():

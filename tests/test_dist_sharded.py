@@ -219,8 +219,17 @@ def _peer_worker(rank, world, port, q):
             L.dkmc_clear_error()
         parallel.barrier()
     info2 = parallel.peer_exchange_info()
+    # the failed solve dropped the attachment on every rank (their sequence counters may have drifted apart): the clean step above ran over the
+    # all-gather.  Attaching again resets counters and flags on every rank; one more clean step over the peer exchange
+    ok2 = parallel.attach_peer_exchange(16 * 9000 + 2)
+    dev.updateCharge(gb); dev.updatePotential(gb, p, Vd, 1)
+    sim.executeKMCStep(gb, dev)
+    dev.updatePower(gb, p, Vd)
+    seen.append((0, dev.imacro))
+    info3 = parallel.peer_exchange_info()
+    info3["reattached"] = bool(ok2)
     parallel.detach_solver_comm()
-    q.put((rank, ok, got_ag, got_peer, info, info2, seen))
+    q.put((rank, ok, got_ag, got_peer, info, (info2, info3), seen))
     parallel.finalize()
 
 
@@ -251,10 +260,13 @@ def test_peer_write_exchange_two_ranks_one_gpu():
         assert info["exchanges"] >= sum(pe0[1]) > 0                   # one exchange per sweep (+ the first product of each solve)
         assert 0.0 < info["mean_us"] < 5e4, info
     # the fault path: both ranks return an error, the clean step after it runs on both and agrees; the small device used the exchange too
-    assert [k for k, _ in seen0] == [1, 0] and [k for k, _ in seen1] == [1, 0], (seen0, seen1)
+    assert [k for k, _ in seen0] == [1, 0, 0] and [k for k, _ in seen1] == [1, 0, 0], (seen0, seen1)
     assert "peer rank" in seen0[0][1] and "injected fault (block-CG iteration" in seen1[0][1]
-    assert seen0[1][1] == seen1[1][1] != 0.0
-    assert info0b["exchanges"] > info0["exchanges"]
+    assert seen0[1][1] == seen1[1][1] != 0.0 and seen0[2][1] == seen1[2][1] != 0.0
+    # a failed solve drops the attachment on BOTH ranks (no rank keeps waiting for a sequence number its peer never reaches); a new attach works
+    for after_fault, after_reattach in (info0b, info1b):
+        assert not after_fault["ready"] and after_fault["exchanges"] == 0
+        assert after_reattach["reattached"] and after_reattach["ready"] and after_reattach["exchanges"] > 0
 
 
 def test_emulated_shares_cover_the_tunnelling_block():

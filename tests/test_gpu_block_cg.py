@@ -18,6 +18,7 @@ def _solve(dev, gb, p, hip, width, tol, start=None, power=False):
     node potentials, current_solver_gpu.cu:1044-1047); power=True repeats the solve with heating on for the dissipated power."""
     host, L = hip
     L.dkmc_set_x_block(width)
+    L.dkmc_set_current_warm_start(0)            # these tests compare solves FROM THE START VECTOR THEY PUT (sweep counts included)
     p.cg_tol = tol
     p.solve_heating_global = False
     put(gb, "atom_virtual_potentials", np.zeros(dev.N_atom + 2) if start is None else start)

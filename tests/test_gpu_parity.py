@@ -28,8 +28,9 @@ def hip():
     return host, lib.load()
 
 
-def make_pair(structure, p, hip, tol=None):
-    """(Device, KMCProcess, GPUBuffers, OracleKMC) in the state right after setLaplacePotential."""
+def make_pair(structure, p, hip, tol=None, warm=None):
+    """(Device, KMCProcess, GPUBuffers, OracleKMC) in the state right after setLaplacePotential.  warm: start vector of the current solve
+    (dkmc_set_current_warm_start); None = the library default (1: the previous solution), 0 = the reference code's G0-scaled buffer."""
     from oracle import oracle as oc
     host, L = hip
     if tol is not None:
@@ -37,7 +38,8 @@ def make_pair(structure, p, hip, tol=None):
     dev = host.Device(structure, p)
     sim = host.KMCProcess(dev, p.freq)
     gb = dev.make_gpubuf("cuda:0")
-    L.dkmc_set_current_warm_start(0)
+    if warm is not None:
+        L.dkmc_set_current_warm_start(warm)
     dev.setLaplacePotential(gb, p, Vd)
     gb.sync_HostToGPU(dev)
     o = oc.OracleKMC(structure.element, structure.x, structure.y, structure.z, p)
@@ -450,7 +452,6 @@ def test_reference_log_7p5_currents(dev_7p5, hip, ref_logs):
     p = params_7p5().log_revision()
     dev = host.Device(dev_7p5, p); sim = host.KMCProcess(dev, p.freq)
     gb = dev.make_gpubuf("cuda:0")
-    L.dkmc_set_current_warm_start(0)
     dev.setLaplacePotential(gb, p, Vd)
     t = 0.0
     worst_i = worst_t = 0.0
@@ -612,7 +613,6 @@ def test_current_solve_randomised_negative_bias(cell_2p5, hip):
     p = pm.KMCParameters(); p.cg_tol = 1e-10; p.solve_heating_global = True
     dev = host.Device(cell_2p5, p); sim = host.KMCProcess(dev, p.freq)
     gb = dev.make_gpubuf("cuda:0")
-    L.dkmc_set_current_warm_start(0)
     rng = np.random.default_rng(5)
     el = dev.site_element.copy()
     ox = np.nonzero(el == pm.O_EL)[0]
@@ -891,7 +891,6 @@ def test_tiled_X_edge_cases(cell_2p5, hip, case):
         for fmt in (0, 1):
             L.dkmc_set_x_format(fmt)
             dev = host.Device(cell_2p5, p); gb = dev.make_gpubuf("cuda:0")
-            L.dkmc_set_current_warm_start(0)
             dev.setLaplacePotential(gb, p, vd); gb.sync_HostToGPU(dev)
             dev.updateCharge(gb); dev.updatePotential(gb, p, vd, 0)
             p.solve_heating_global = False                     # (with heating on the node potentials are shifted after the solve)
@@ -924,13 +923,14 @@ def test_tiled_X_edge_cases(cell_2p5, hip, case):
     assert np.abs(pw1 - pw0).max() <= (1e-4 if loose else 1e-8) * max(np.abs(pw0).max(), 1e-300)
 
 
-def _fresh_device(structure, p, hip):
+def _fresh_device(structure, p, hip, warm=None):
     """(Device, KMCProcess, GPUBuffers, None) right after setLaplacePotential, without the oracle twin (large devices)."""
     host, L = hip
     dev = host.Device(structure, p)
     sim = host.KMCProcess(dev, p.freq)
     gb = dev.make_gpubuf("cuda:0")
-    L.dkmc_set_current_warm_start(0)
+    if warm is not None:
+        L.dkmc_set_current_warm_start(warm)
     dev.setLaplacePotential(gb, p, Vd)
     gb.sync_HostToGPU(dev)
     return dev, sim, gb, None
@@ -979,7 +979,6 @@ def test_crossbar_with_current_solve(hip, golden_dir):
     V = 1.0
     dev = host.Device(s, p, gpu_neighbors="cuda:0"); sim = host.KMCProcess(dev, p.freq)
     gb = dev.make_gpubuf("cuda:0")
-    L.dkmc_set_current_warm_start(0)
     dev.setLaplacePotential(gb, p, V); gb.sync_HostToGPU(dev)
     po = pm.KMCParameters(rnd_seed=5, lattice=tuple(s.meta["lattice"]), num_atoms_first_layer=144, num_atoms_contact=11520)
     po.cg_tol = 1e-12; po.solve_current = False
@@ -1031,7 +1030,6 @@ def test_restart_continues_the_same_event_sequence(cell_2p5, hip, tmp_path):
             out.append((sim.last_event_log.copy(), dt, dev.imacro, dev.T_bg))
         return out
 
-    L.dkmc_set_current_warm_start(0)
     dev = host.Device(cell_2p5, p); sim = host.KMCProcess(dev, p.freq); gb = dev.make_gpubuf("cuda:0")
     dev.setLaplacePotential(gb, p, Vd); gb.sync_HostToGPU(dev)
     full = steps(dev, sim, gb, 0, 6)
@@ -1087,7 +1085,7 @@ def test_two_devices_in_one_process_keep_their_own_solver_state(cell_2p5, hip):
             both["b"].append(step(*db, pb, VB, k))
         assert both["a"] == alone["a"] and both["b"] == alone["b"]
     finally:
-        L.dkmc_set_current_warm_start(0)
+        L.dkmc_set_current_warm_start(1)
 
 
 @pytest.mark.parametrize("offset", [0, 2])

@@ -34,7 +34,7 @@ def _fresh(k, solve_current=True):
     from bench import make_workload
     from devicekmc_amd import host, lib
     L = lib.load()
-    L.dkmc_set_x_format(1); L.dkmc_set_current_warm_start(0)
+    L.dkmc_set_x_format(1)
     s, p = make_workload("tile:%d" % k)
     if not solve_current:
         p.solve_current = False; p.solve_heating_global = False

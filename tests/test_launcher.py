@@ -52,3 +52,26 @@ def test_bench_refuses_a_world_that_is_not_gpus():
     env = dict(os.environ, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode != 0 and json.loads(r.stdout.strip().splitlines()[-1])["value"] is None
+
+
+def test_run_ranks_timeout_ends_the_whole_rank_group(tmp_path):
+    """A rank group that outlives its time-out is ended as a GROUP (the ranks are grandchildren of the launcher's child): no orphan is left
+    holding the device while the caller reports exit code 3."""
+    import time
+    script = tmp_path / "rank.py"
+    pidfile = tmp_path / "pids"
+    script.write_text("import os, time\nopen(%r, 'a').write('%%d\\n' %% os.getpid())\ntime.sleep(600)\n" % str(pidfile))
+    code = "import sys; sys.path.insert(0, %r); from devicekmc_amd import launch; sys.exit(launch.run_ranks(%r, [], 2, timeout=20))" % (ROOT, str(script))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=200)
+    assert r.returncode == 3, (r.returncode, r.stderr[-1000:])
+    assert json.loads(r.stdout.strip().splitlines()[-1])["value"] is None
+    pids = [int(x) for x in pidfile.read_text().split()]
+    assert len(pids) == 2
+    time.sleep(1.0)
+    for pid in pids:
+        alive = True
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            alive = False
+        assert not alive, pid

@@ -323,38 +323,47 @@ def summary(sim, elapsed, steps):
     }
 
 
-def strong_scaling_model_block(sim, roof, res):
-    """Coarse model of the sharded block-CG from ONE-GPU measurements: per sweep the tile x panel kernel scales with the rank's share of the
-    tiles (1 / N; the sharded single-vector solve measures 0.93-0.98 of that on its shares), everything else of a sweep (neighbour part, row
-    kernel, Gram reduction, s x s algebra, panel updates) is replicated, and one all-gather of |S| x so doubles per rank is added at an ASSUMED
-    rate.  No multi-GPU run stands behind it."""
-    st = sim.host.get_stats()
+XGMI_LINK_GBPS_ASSUMED = 50.0      # achieved rate per direction of ONE xGMI link (MI355X: 7 links x ~153 GB/s bidirectional per GPU, one per peer): ASSUMED, never measured here
+XCHG_LATENCY_US_ASSUMED = 15.0     # per all-to-all-v (grouped ncclSend / ncclRecv); the 12 KB Gram all-gather: 25 us.  ASSUMED.
+SLAB_CLASSES = ("tile_x_panel", "neighbour_part", "fold_and_pack", "rows_and_gram", "gram_reduction", "sxs_algebra", "panel_step", "pack_unpack_exchange3")
+
+
+def strong_scaling_model_slabs(sim, res, sweeps=28):
+    """Strong-scaling model of the SLAB-DISTRIBUTED block-CG (csrc/xtb_slab.inc), rebuilt from per-rank kernel times measured on ONE GPU: for N = 1, 2,
+    4, 8 the distributed loop runs with N virtual ranks inside this process on the resident X (dkmc_xtb_emulate_slabs: shares of the tiles, row
+    slabs, lists and exchange buffers exactly as N processes build them, exchanges as device copies) and every kernel of the middle rank is timed
+    over sweeps 2 ... 25.  What cannot be measured on one GPU are the three exchanges of a sweep: their PAYLOADS are the solver's own counts, their
+    durations are ASSUMED (payload per pair / 50 GB/s + 15 us; Gram all-gather 25 us).  step_N = step_1 - sweeps x (sweep_1 - sweep_N): everything
+    outside the sweeps (K-CG, pair sum, events, assembly) counted as replicated."""
+    import ctypes as C
     iters = res["per_step"]["cg_iters_X"]
     step_ms = res["ms_per_step"]
-    apply_us = roof["avg_launch_us"]
-    sweep_us = res["split_ms"]["current"] * 1e3 / max(iters, 1)
-    other_us = max(sweep_us - apply_us, 0.0)
-    so = 4 * ((int(st["xb_width"]) + 3) // 4)
-    payload = (int(st["xt_ns"]) * so + 2) * 8.0
     rows = {}
     for n in (1, 2, 4, 8):
-        # every rank receives n - 1 slots over its n - 1 (of 7) xGMI links in parallel: payload / link rate + a latency term
-        xchg = 0.0 if n == 1 else payload / 100e9 * 1e6 + 20.0
-        sw = apply_us / n + other_us + xchg
-        tn = step_ms - iters * (sweep_us - sw) * 1e-3
-        rows[n] = {"apply_us": round(apply_us / n, 1), "replicated_us_per_sweep": round(other_us, 1), "exchange_us_assumed": round(xchg, 1),
-                   "exchange_bytes_per_rank": payload, "modelled_ms_per_step": round(tn, 1), "modelled_speedup": round(step_ms / tn, 2)}
-    # the one measurement of the exchange that exists: two processes sharing ONE GPU, peer-write exchange over hipIpc-mapped buffers
-    # (profiles/r04_bench_2rank_rehearsal_one_gpu_tile5_peer_exchange.json: 59 us per exchange of a 2.97 MB slot, HIP events around
-    # push ... wait, the peer's skew included) -- same-device copies and a time-sliced GPU, NOT an xGMI number
-    same_dev = {"us_per_exchange": 58.9, "slot_bytes": 371602 * 8.0, "ranks": 2,
-                "scaled_to_this_payload_us": round(58.9 * payload / (371602 * 8.0), 1),
-                "source": "profiles/r04_bench_2rank_rehearsal_one_gpu_tile5_peer_exchange.json",
-                "note": "two processes on ONE GPU (same-device copies, time-sliced): a functional cost, not an xGMI number; the model above keeps its ASSUMED link rate"}
-    return {"what": "coarse: apply kernel / N + replicated rest of a sweep + an ASSUMED all-gather (payload / 100 GB/s per link + 20 us); nothing here was run on more than one GPU",
-            "exchange_measured_same_device": same_dev,
-            "cg_sweeps_X_per_step": iters, "single_gpu_ms_per_step": step_ms, "by_n_gpus": rows,
-            "note": "the replicated part of a sweep (neighbour part, row kernel, panel updates) caps the speed-up near apply / rest + 1; sharding those rows is the next step"}
+        rd, it_s, it_r = C.c_double(0), C.c_int(0), C.c_int(0)
+        us, xd, mm = (C.c_double * 8)(), (C.c_longlong * 3)(), (C.c_int * 2)()
+        rc = sim.L.dkmc_xtb_emulate_slabs(n, sim.x_block, sim.p.cg_tol, n // 2, sweeps, C.byref(rd), C.byref(it_s), C.byref(it_r), us, xd, mm)
+        if rc != 0:
+            err = sim.L.dkmc_last_error().decode(); sim.L.dkmc_clear_error()
+            return {"error": "dkmc_xtb_emulate_slabs(%d) failed: %s" % (n, err[:200])}
+        k = {name: round(us[i], 1) for i, name in enumerate(SLAB_CLASSES)}
+        pair = lambda doubles: 0.0 if n == 1 else doubles * 8.0 / (n - 1) / (XGMI_LINK_GBPS_ASSUMED * 1e3) + XCHG_LATENCY_US_ASSUMED      # us
+        x1, x2, x3 = pair(xd[0]), (0.0 if n == 1 else 25.0), pair(xd[2])
+        sweep = sum(us[i] for i in range(8)) + x1 + x2 + x3
+        rows[n] = {"kernel_us": k, "kernels_us_per_sweep": round(sum(us[i] for i in range(8)), 1), "rows_per_slab_min_max": [mm[0], mm[1]],
+                   "doubles_received_per_sweep": {"exchange1_tile_sums_to_owners": xd[0], "exchange2_gram": xd[1], "exchange3_QS_and_halo": xd[2]},
+                   "exchange_us_ASSUMED": {"exchange1": round(x1, 1), "exchange2": x2, "exchange3": round(x3, 1)}, "sweep_us": round(sweep, 1)}
+    s1 = rows[1]["sweep_us"]
+    for n in rows:
+        tn = step_ms - iters * (s1 - rows[n]["sweep_us"]) * 1e-3
+        rows[n]["modelled_ms_per_step"] = round(tn, 1)
+        rows[n]["modelled_speedup"] = round(step_ms / tn, 2)
+        rows[n]["speedup_of_the_sweep"] = round(s1 / rows[n]["sweep_us"], 2)
+    return {"what": "slab-distributed block-CG: per-rank kernel times of the middle rank of N virtual ranks measured on ONE GPU (each kernel bracketed by events, "
+                    "host-synchronised: small kernels include their launch latency); exchange payloads counted by the solver, exchange durations ASSUMED "
+                    "(%g GB/s per pair and direction + %g us; Gram all-gather 25 us); nothing here ran on more than one GPU" % (XGMI_LINK_GBPS_ASSUMED, XCHG_LATENCY_US_ASSUMED),
+            "cg_sweeps_X_per_step": iters, "single_gpu_ms_per_step": step_ms, "outside_the_sweeps_ms": round(step_ms - iters * s1 * 1e-3, 1), "by_n_gpus": rows,
+            "note": "outside_the_sweeps_ms (K-CG, pair sum, events, assembly of X) is replicated on every rank: with the warm start it is what caps the step's speed-up"}
 
 
 ALLREDUCE_US_ASSUMED = {1: 0.0, 2: 25.0, 4: 40.0, 8: 60.0}     # in-place all-reduce of |S| + 1 doubles (0.74 MB at 9.4e5 sites) over xGMI: ASSUMED, not measured
@@ -402,6 +411,44 @@ def strong_scaling_model(sim, ms_per_step, reps=10):
             "not_in_the_cg_iterations_ms": round(ms_per_step - iters * t1 * 1e-3, 1), "by_n_gpus": rows}
 
 
+def k_slab_model(sim, iters=28):
+    """configs[4]'s domain-decomposed potential: the CG on K distributed by lateral row slabs (csrc/kcg.hip), N virtual ranks in this process on the
+    system of the resident state (dkmc_kcg_emulate_slabs, a measurement run of `iters` iterations): the middle rank's kernel times per iteration, the
+    halo payload, and an iteration time with ASSUMED exchanges (two all-gathers of block partials at 25 us each + the halo at 50 GB/s per pair + 15 us)."""
+    import ctypes as C
+    n1 = sim.p.num_atoms_first_layer
+    rows = {}
+    for n in (1, 2, 4, 8):
+        md, it_s, it_r = C.c_double(0), C.c_int(0), C.c_int(0)
+        us, hr = (C.c_double * 4)(), (C.c_longlong * 2)()
+        rc = sim.L.dkmc_kcg_emulate_slabs(C.byref(sim.gb.c), sim.dev.N, n1, n1, sim.Vd, sim.p.high_G, sim.p.low_G, len(sim.p.metals), n, n // 2, iters,
+                                          C.byref(md), C.byref(it_s), C.byref(it_r), us, hr)
+        if rc != 0:
+            err = sim.L.dkmc_last_error().decode(); sim.L.dkmc_clear_error()
+            return {"error": "dkmc_kcg_emulate_slabs(%d) failed: %s" % (n, err[:200])}
+        kern = sum(us[i] for i in range(4))
+        x = 0.0 if n == 1 else 2 * 25.0 + hr[0] * 8.0 / 2 / (XGMI_LINK_GBPS_ASSUMED * 1e3) + XCHG_LATENCY_US_ASSUMED      # (a slab has two neighbours)
+        rows[n] = {"kernel_us": {"product": round(us[0], 1), "update": round(us[1], 1), "direction": round(us[2], 1), "halo_pack_unpack": round(us[3], 1)},
+                   "rows_of_the_largest_slab": hr[1], "halo_doubles_received_per_iteration": hr[0], "exchanges_us_ASSUMED": round(x, 1), "iteration_us": round(kern + x, 1)}
+    for n in rows:
+        rows[n]["speedup_of_the_iteration"] = round(rows[1]["iteration_us"] / rows[n]["iteration_us"], 2)
+    return {"what": "slab-distributed CG on K: per-rank kernel times of the middle rank of N virtual ranks measured on ONE GPU (event-bracketed, host-synchronised: "
+                    "each includes its launch latency); exchange durations ASSUMED; nothing here ran on more than one GPU", "by_n_gpus": rows}
+
+
+def cpu_model():
+    """Model string of the host CPU the cpu_baseline legs ran on (BASELINE.md section 3 asks for it)."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine() or "unknown"
+
+
 def cpu_cg_baseline(sim, ncores, iters=None, iters_source=None):
     """CPU leg of a scale point: the oracle's CG iteration (okmc_cg_iter_bench: the loop body of okmc_cg_jacobi, OpenMP) timed on a
     CSR of X's shape at this size, x the GPU run's iteration count.  Everything else of a CPU step (assembly, K solve, events) is
@@ -410,15 +457,16 @@ def cpu_cg_baseline(sim, ncores, iters=None, iters_source=None):
     from oracle import oracle as oc
     st = sim.host.get_stats()
     m = int(st["N_atom"]) + 1
-    t_it = oc.cg_iter_bench(m, int(st["xt_ns"]), 2 * int(st["spmv_tile_entries"]), int(st["xt_sparse_nnz"]), 3)
+    n_timed = 16                                  # ~12 s of CPU at 9.4e5 sites (0.7 s per iteration): the bounded sample of the contract
+    t_it = oc.cg_iter_bench(m, int(st["xt_ns"]), 2 * int(st["spmv_tile_entries"]), int(st["xt_sparse_nnz"]), n_timed)
     if iters is None:
         iters, iters_source = sim.cnt["cg_iters_X"] / max(sim.cnt["steps"], 1), "the GPU run's iteration count"
     if t_it <= 0:
         return None
     sec = t_it * iters
-    return {"value": round(1.0 / sec, 6), "unit": "KMC steps/s", "cores": ncores, "kind": "port",
+    return {"value": round(1.0 / sec, 6), "unit": "KMC steps/s", "cores": ncores, "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "kind": "port",
             "sample": "oracle CG iteration (loop body of okmc_cg_jacobi: CSR SpMV + 3 dots + 3 vector updates, OpenMP; oracle/kmc_oracle.c "
-                      "okmc_cg_iter_bench) timed over 3 iterations on a CSR of X's row and non-zero counts at this size, x %.0f CG iterations per step "
+                      "okmc_cg_iter_bench) timed over 16 iterations on a CSR of X's row and non-zero counts at this size, x %.0f CG iterations per step "
                       "(%s: the CPU port runs the reference's single-vector CG); assembly, K solve, pair sum and events of a CPU step are NOT "
                       "included (lower bound on the CPU time)" % (iters, iters_source),
             "s_per_cg_iteration": round(t_it, 4), "ms_per_step": round(sec * 1e3, 1)}
@@ -435,7 +483,7 @@ def cpu_superstep_baseline(s, p, ncores):
     for _ in range(nsamp):
         o.superstep(VD)
     tc = (time.perf_counter() - t0) / nsamp
-    return {"value": round(1.0 / tc, 5), "unit": "KMC steps/s", "cores": ncores, "kind": "port",
+    return {"value": round(1.0 / tc, 5), "unit": "KMC steps/s", "cores": ncores, "cpu_model": cpu_model(), "host_cpus": os.cpu_count(), "kind": "port",
             "sample": "%d superstep(s) of the same workload after one untimed step (oracle/kmc_oracle.c, OpenMP)" % nsamp,
             "ms_per_step": round(tc * 1e3, 1), "split_ms": {k: round(v * 1e3, 2) for k, v in o.timing.items()}}
 
@@ -682,7 +730,7 @@ def main():
             out["steps_requested"] = args.steps
         out.update(roofs)
         if big and sim.x_block > 1 and "roofline" in out:
-            out["strong_scaling_model"] = strong_scaling_model_block(sim, out["roofline"], res)
+            out["strong_scaling_model"] = strong_scaling_model_slabs(sim, res)
         # ---- same simulation from the reference code's start vector (dkmc_set_current_warm_start(0)): what the default's warm start saves ----
         if args.warm_start == 1 and not args.no_alt:
             sim.warm_start = 0
@@ -797,6 +845,7 @@ def main():
                     r["what"] = ("a crossbar-SIZED stack with the current solve off, as every shipped crossbar parameter set runs "
                                  "(structures/crossbars/*/parameters.txt: solve_current = 0): charge + potential (K-CG + pair sum) + event loop")
                     r["us_per_executed_event"] = round(r["split_ms"]["rates"] * 1e3 / max(r["per_step"]["events"], 1), 1)
+                    r["k_cg_slab_model"] = k_slab_model(sp)
                 rf = rooflines(sp)
                 if nocur:                                # the library's X statistics are those of an earlier simulation of this process
                     rf.pop("roofline", None)
@@ -859,6 +908,7 @@ def main():
             # validated with two processes on ONE GPU only, hence not the default beside RCCL).  All ranks decide together.
             peer_on = False
             if args.peer_exchange or os.environ.get("DKMC_PEER_EXCHANGE") == "1":
+                sim.L.dkmc_set_x_slab(0)          # the peer-write exchange carries the slots of the all-gather variant of the sharded block loop
                 peer_on = parallel.attach_peer_exchange(16 * (int(sim.dev.N_atom) + 2) + 2)
         else:
             transport = "none"; peer_on = False
@@ -895,9 +945,13 @@ def main():
                 "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": name, "sites": res["sites"], "nn": res["nn"], "atoms": res["atoms"], "Vd": VD,
                            "phases": "charge+potential+rates+current+heat",
-                           "parallelism": ("one simulation; X generated/stored/streamed in %d per-rank shares, one exchange of 16 |S| + 2 doubles per block-CG sweep, slots added in rank order"
+                           "parallelism": (("one simulation; X generated/stored/streamed in %d per-rank shares; block-CG state distributed by lateral row slabs (csrc/xtb_slab.inc): per sweep the "
+                                            "tile sums of the S rows go to their owners (all-to-all-v), 6 x 256 Gram entries are all-gathered and added in rank order, own rows of QS + halo rows of P go out (all-to-all-v)")
+                                           if sharded and not peer_on else
+                                           "one simulation; X generated/stored/streamed in %d per-rank shares, one exchange of 16 |S| + 2 doubles per block-CG sweep, slots added in rank order (all-gather variant)"
                                            if sharded else "replicas x%d") % world,
-                           "exchange": ("peer-write over hipIpc-mapped buffers (opt-in)" if peer_on else "all-gather of the transport") if sharded else None,
+                           "x_slab": int(sim.L.dkmc_get_x_slab()) if sharded else None,
+                           "exchange": ("peer-write over hipIpc-mapped buffers (opt-in, all-gather variant)" if peer_on else "all-to-all-v + all-gather of the transport (slab-distributed block-CG)") if sharded else None,
                            "transport": transport, "transport_note": transport_note, "x_format": "tiled", "current_warm_start": sim.warm_start, "cg_tol": sim.p.cg_tol,
                            "comm_ranks": min(i[0] for i in infos), "comm_rank_ids": sorted(i[1] for i in infos),
                            "comm_transport_code": sorted(set(i[2] for i in infos)), "process_group_world": world, "process_group_backend": backend},
@@ -907,7 +961,7 @@ def main():
                              "exchange_us": round(sim.prof["comm_ms"] / max(sim.prof["comm_n"], 1) * 1e3, 2),
                              "exchanged_doubles": int(st["comm_count_per_rank"]),
                              "peer_exchange": parallel.peer_exchange_info() if peer_on else None,
-                             "replicated_phases": "charge, K-CG, event loop, neighbour part of X (all < 5 % of a step at this size); pair sum: site slabs + all-gather"},
+                             "replicated_phases": "charge, K-CG, event loop, assembly of the neighbour part of X; pair sum: site slabs + all-gather"},
                 "replicas": replicas, "single_gpu_reference": None,
             }
             if single is not None:

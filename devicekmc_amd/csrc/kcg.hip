@@ -11,7 +11,9 @@
 //     per row (row pointers -> columns -> q) instead of one per 16 entries.
 // Bytes per iteration: 4 nnz + 4 (m + 1) + 15 vector touches of 8 m  (CSR formulation, SURVEY 8d: 12 nnz + 4 (m + 1) + 96 m).
 #include "common.h"
+#include "slab.h"
 #include <algorithm>
+#include <functional>
 #include <vector>
 
 #define KC_NT 256
@@ -122,21 +124,24 @@ template <int MODE>
 __global__ __launch_bounds__(KC_NT) void k_kc_apply(int m, const int *__restrict__ rp, const int *__restrict__ cf, const double *__restrict__ diag,
                                                     const double *__restrict__ s, const double *__restrict__ q, double high_G, double low_G,
                                                     const double *__restrict__ pv, double *__restrict__ t, double *__restrict__ part, const KCtrl *ctrl,
-                                                    const double *__restrict__ b, double *__restrict__ r, double *__restrict__ p)
+                                                    const double *__restrict__ b, double *__restrict__ r, double *__restrict__ p,
+                                                    const int *__restrict__ rowlist = nullptr)
 {
+    // rowlist (slab-distributed solve): the rows are the m entries of this rank's list
     __shared__ double red[3][KC_NT / 64];
     __shared__ int sdone;
-    if (MODE == 0) {
+    if (MODE != 1) {
         if (threadIdx.x == 0) sdone = ctrl->done;
         __syncthreads();
         if (sdone) return;
     }
     const int g = threadIdx.x >> 3, l = threadIdx.x & 7;
     double acc[3] = {0.0, 0.0, 0.0};
-    for (int row = blockIdx.x * (KC_NT / 8) + g; row < m; row += gridDim.x * (KC_NT / 8)) {
+    for (int ri = blockIdx.x * (KC_NT / 8) + g; ri < m; ri += gridDim.x * (KC_NT / 8)) {
+        const int row = rowlist ? rowlist[ri] : ri;
         const int p0 = rp[row], p1 = rp[row + 1];
         const double qr = q[row], dg = diag[row], sv = s[row];
-        const double a1 = MODE == 0 ? pv[row] : b[row], a2 = MODE == 0 ? r[row] : 0.0;      // (requested with the rest, used by lane 0 at the end)
+        const double a1 = MODE != 1 ? pv[row] : b[row], a2 = MODE == 0 ? r[row] : 0.0;      // (requested with the rest, used by lane 0 at the end)
         double sum = 0.0;
         for (int pb = p0 + l; pb < p1; pb += 32) {
             int c[4];
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(KC_NT) void k_kc_apply(int m, const int *__restrict
         sum += __shfl_xor(sum, 4, 8); sum += __shfl_xor(sum, 2, 8); sum += __shfl_xor(sum, 1, 8);
         if (l == 0) {
             const double tv = sv * (dg * qr - sum);
-            if (MODE == 0) { t[row] = tv; acc[0] += a1 * tv; acc[1] += a2 * tv; acc[2] += tv * tv; }
+            if (MODE != 1) { t[row] = tv; acc[0] += a1 * tv; acc[1] += a2 * tv; acc[2] += tv * tv; }
             else { const double rv = -a1 + tv; r[row] = rv; p[row] = -rv; acc[0] += rv * rv; }      // (q = s p: k_kc_q, after every row has read the old q)
         }
     }
@@ -518,9 +523,14 @@ void kblocked_free(KBlocked *kb)
 
 // Assemble K for the current elements / charges and solve K y = rhs in place in y (warm start = y on entry).
 // kb: the blocked form of the pattern (or nullptr): the whole solve then runs in the blocked order, y is gathered on entry and scattered on exit.
+static int kcg_slab_loop(int m, const int *rp, const int *cf, const double *diag, const double *s, const double *b, double high_G, double low_G, double *y, double *q0,
+                         const double *coord_y, const double *coord_z, int nr, int me0, bool emu, int time_rank, double tol2, int *iters_out, double *rr_out);
+// row_y / row_z: lateral coordinates of the rows (site_y + N_left, site_z + N_left) for the slab-distributed loop; may be null.
+// emu_nr > 0 (dkmc_kcg_emulate_slabs): run the slab-distributed loop with emu_nr virtual ranks in this process.
 int kcg_assemble_and_solve(int cb, int m, int N_left, const int *element, const int *charge, MetalSet ms, double high_G, double low_G,
                            const int *rp, const int *ci, int nnz, const int *lrp, const int *lci, const int *rrp, const int *rci,
-                           double VL, double VR, double *y_site, int *iters_out, double *rr_out, const KBlocked *kb)
+                           double VL, double VR, double *y_site, int *iters_out, double *rr_out, const KBlocked *kb,
+                           const double *row_y, const double *row_z, int emu_nr, int emu_time_rank)
 {
     Engine &e = eng(); hipStream_t st = e.stream;
     if (m <= 0) { if (iters_out) *iters_out = 0; if (rr_out) *rr_out = 0; return 0; }
@@ -565,6 +575,21 @@ int kcg_assemble_and_solve(int cb, int m, int N_left, const int *element, const 
     HIPCHK(hipMemsetAsync(part, 0, (size_t)KC_PART_DOUBLES * 8, st));       // the slots beyond either grid stay zero
 #define KC_APPLY(MODE, ...) do { if (kb) hipLaunchKernelGGL((k_kb_apply<MODE>), dim3(ga), dim3(KB_NT), lds, st, m, kb->R, (const int4 *)kb->blk, __VA_ARGS__); \
                                  else hipLaunchKernelGGL((k_kc_apply<MODE>), dim3(ga), dim3(KC_NT), 0, st, m, rp, __VA_ARGS__); } while (0)
+    // more than one rank (or the emulation of it) on a system above the size of the blocked form: the loop distributed by row slabs
+    const bool slab = !kb && row_y && row_z && (emu_nr > 0 || (e.k_slab && comm_attached() && comm_nranks() > 1 && comm_nranks() <= XS_MAXR));
+    if (slab) {
+        int rcs = 0;
+        if (emu_nr <= 0) rcs = comm_agree(e.err_code, "assembly of K");                 // local set-up done: nobody enters the collectives of the loop alone
+        if (rcs) return rcs;
+        rcs = kcg_slab_loop(m, rp, cf, diag, s, rhs, high_G, low_G, y, q, row_y, row_z, emu_nr > 0 ? emu_nr : comm_nranks(), emu_nr > 0 ? 0 : comm_rank(), emu_nr > 0,
+                            emu_time_rank, tol2, iters_out, rr_out);
+        if (rcs) return rcs;
+        hipLaunchKernelGGL(k_kc_unscale, dim3(vb), dim3(256), 0, st, m, y, (const double *)s);
+        KCHK();
+        e.stats.kcg_blocked = 0; e.stats.kcg_ms = 0.0; e.stats.kcg_iters_timed = 0;
+        e.stats.kcg_bytes = 4LL * nnz + 4LL * (m + 1) + 17LL * 8 * m;
+        return e.err_code;
+    }
     KC_APPLY(1, (const int *)cf, (const double *)diag, (const double *)s, (const double *)q, high_G, low_G,
              (const double *)nullptr, t, part, (const KCtrl *)ctrl, (const double *)rhs, r, p);
     hipLaunchKernelGGL(k_kc_q, dim3(vb), dim3(256), 0, st, m, (const double *)s, (const double *)p, q);
@@ -605,3 +630,351 @@ int kcg_assemble_and_solve(int cb, int m, int N_left, const int *element, const 
     if (rr_out) *rr_out = kb ? h.rr[0] : h.rr[h.iters & 1];
     return e.err_code;
 }
+
+
+// ---- slab-distributed CG on K (SURVEY 8(e), row "K-CG": row slabs, halo = sites within the neighbour distance of a cut, the dot products completed
+// across the ranks) -- configs[4]'s "domain-decomposed potential".  No counterpart in the reference (single GPU).  For systems above the size of
+// the blocked form, when a communicator with more than one rank is attached (dkmc_set_k_slab, default on).  A rank OWNS the rows of one lateral
+// slab (slab.h): product, update and direction run over its row list only; per iteration, in the reference's order (product, update, direction:
+// beta from the direct sum r'.r', see k_kc_update):
+//   product (own rows)    t = S K q, block partials of p.t          -> exchange 1: all-gather of the partials; every rank adds ALL of them in one
+//   update (own rows)     alpha, y, r, block partials of r'.r'      -> exchange 2: the same                      fixed order: identical alpha, beta
+//   direction (own rows)  beta, p, q = S p, stop test               -> exchange 3: all-to-all-v of the q entries a neighbour slab reads (halo)
+// -- identical scalars on every rank by construction, so all ranks stop at the same iteration and no flag has to travel.  Vectors keep their full
+// length on every rank (29 MB each at 3.6e6 rows); entries a rank neither owns nor reads are never touched.  The solution's own rows are
+// all-gathered once at the end.  The same host loop runs N VIRTUAL ranks in one process (dkmc_kcg_emulate_slabs): how it is tested on one GPU.
+#define KS_NPA 256          // block partials of the product per rank (its grid)
+#define KS_NP 64            // block partials of r'.r' per rank
+__global__ __launch_bounds__(KC_NT) void k_ks_check0(int n, const double *__restrict__ xa, KCtrl *ctrl, double tol2)
+{
+    __shared__ double red[KC_NT / 64];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += KC_NT) s += xa[i];
+    const double rr = block_sum_all<KC_NT>(s, red);
+    if (threadIdx.x == 0) { ctrl->rr[0] = rr; ctrl->rr[1] = rr; ctrl->iters = 0; ctrl->done = !(sqrt(rr) > tol2); }
+}
+__global__ __launch_bounds__(KC_NT) void k_ks_update(int n, const int *__restrict__ rows, int it, const double *__restrict__ xa, int na, const double *__restrict__ p,
+                                                     const double *__restrict__ t, double *__restrict__ y, double *__restrict__ r, double *__restrict__ xb_mine, const KCtrl *ctrl)
+{
+    __shared__ double red[KC_NT / 64];
+    __shared__ int sdone;
+    if (threadIdx.x == 0) sdone = ctrl->done;
+    double a = 0.0;
+    for (int j = threadIdx.x; j < na; j += KC_NT) a += xa[j];
+    const double pAp = block_sum_all<KC_NT>(a, red);
+    if (sdone) return;
+    const double alpha = ctrl->rr[it & 1] / pAp;
+    double acc = 0.0;
+    for (int i = blockIdx.x * KC_NT + threadIdx.x; i < n; i += gridDim.x * KC_NT) {
+        const int row = rows[i];
+        y[row] += alpha * p[row];
+        const double rn = r[row] + alpha * t[row];
+        r[row] = rn;
+        acc += rn * rn;
+    }
+    const double tot = block_sum_all<KC_NT>(acc, red);
+    if (threadIdx.x == 0) xb_mine[blockIdx.x] = tot;
+}
+__global__ __launch_bounds__(KC_NT) void k_ks_direction(int n, const int *__restrict__ rows, int it, const double *__restrict__ xb, int nb, const double *__restrict__ r,
+                                                        double *__restrict__ p, const double *__restrict__ s, double *__restrict__ q, KCtrl *ctrl, double tol2)
+{
+    __shared__ double red[KC_NT / 64];
+    __shared__ int sdone;
+    if (threadIdx.x == 0) sdone = ctrl->done;
+    double a = 0.0;
+    for (int j = threadIdx.x; j < nb; j += KC_NT) a += xb[j];
+    const double rr_new = block_sum_all<KC_NT>(a, red);
+    if (sdone) return;
+    const double beta = rr_new / ctrl->rr[it & 1];
+    for (int i = blockIdx.x * KC_NT + threadIdx.x; i < n; i += gridDim.x * KC_NT) {
+        const int row = rows[i];
+        const double pn = p[row] * beta - r[row];
+        p[row] = pn;
+        q[row] = s[row] * pn;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctrl->rr[(it + 1) & 1] = rr_new;
+        ctrl->iters = it + 1;
+        if (!(rr_new > tol2)) ctrl->done = 1;
+    }
+}
+__global__ void k_ks_q(int n, const int *__restrict__ rows, const double *__restrict__ s, const double *__restrict__ p, double *__restrict__ q)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const int row = rows[i]; q[row] = s[row] * p[row]; }
+}
+__global__ void k_ks_gather(int n, const int *__restrict__ list, const double *__restrict__ v, double *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = v[list[i]];
+}
+__global__ void k_ks_scatter(int n, const int *__restrict__ list, const double *__restrict__ in, double *__restrict__ v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[list[i]] = in[i];
+}
+// the solution: block r of the gathered buffer (stride doubles apart) holds the rows of owner r in list order
+__global__ void k_ks_scatter_all(int nr, int me, int stride, const int *__restrict__ rows_by_owner, const int *__restrict__ rowoff, const double *__restrict__ in, double *__restrict__ y)
+{
+    const int r = blockIdx.y;
+    if (r == me) return;
+    const int n = rowoff[r + 1] - rowoff[r];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) y[rows_by_owner[rowoff[r] + i]] = in[(size_t)r * stride + i];
+}
+
+struct KsRank { int v = 0, n_own = 0, nhs = 0, nhr = 0; int *own = nullptr, *hsend = nullptr, *hrecv = nullptr; double *y = nullptr, *r = nullptr, *p = nullptr, *t = nullptr, *q = nullptr,
+                *xa = nullptr, *xb = nullptr, *send = nullptr, *recv = nullptr, *ybuf = nullptr; KCtrl *ctrl = nullptr; };
+static double g_ks_times[4] = {0, 0, 0, 0};       // emulation: mean kernel times of the timed virtual rank (product, update, direction, halo pack + unpack)
+static long long g_ks_halo[2] = {0, 0};           // doubles a rank receives per iteration in exchange 3 (largest over the ranks); rows of the largest slab
+static int g_ks_iter_cap = 0;
+
+// cf / diag / s / b: the assembled, scaled system (replicated); y: scaled start vector in, scaled solution out (all rows, every rank).
+// emu: nr virtual ranks in this process, exchanges as device copies.  coord_y / coord_z: lateral coordinates of the rows.
+static int kcg_slab_loop(int m, const int *rp, const int *cf, const double *diag, const double *s, const double *b, double high_G, double low_G, double *y, double *q0,
+                         const double *coord_y, const double *coord_z, int nr, int me0, bool emu, int time_rank, double tol2, int *iters_out, double *rr_out)
+{
+    Engine &e = eng(); hipStream_t st = e.stream;
+    const int nv = emu ? nr : 1;
+    std::vector<void *> owned;
+    struct Free { std::vector<void *> &v; hipStream_t st; ~Free() { if (!v.empty()) (void)hipStreamSynchronize(st); for (void *p : v) (void)hipFree(p); } } freer{owned, st};
+    int fail = 0;
+    auto salloc = [&](int iv, int slot, size_t bytes) -> void * {
+        if (iv == 0) { void *p = scratch(slot, bytes); if (!p) fail = e.err_code ? e.err_code : 2; return p; }
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) { (void)hipGetLastError(); fail = dkmc_fail(2, "K-CG slab emulation: out of device memory", __FILE__, __LINE__); return nullptr; }
+        owned.push_back(p);
+        return p;
+    };
+    if (nr < 1 || nr > XS_MAXR) return dkmc_fail(43, "slab-distributed K-CG: 1 ... 32 ranks", __FILE__, __LINE__);
+    // ---- ownership (slab.h): slabs along the wider lateral axis, balanced by row count ----
+    int *itab = (int *)scratch(S_KS_TAB, (size_t)(XS_BINS + XS_MAXR + 2 + XS_MAXR * (XS_MAXR + 2)) * 4);
+    int *owner = (int *)scratch(S_KS_OWNER, (size_t)m * 4 * 2);
+    int *rows_by_owner = (int *)scratch(S_KS_LISTS, ((size_t)m + XS_MAXR + 8) * 4);
+    int *flag = (int *)scratch(S_KS_FLAG, (size_t)(m + 8) * 4 * 2);
+    double *mm = (double *)scratch(S_KS_BOX, 64);
+    if (!itab || !owner || !rows_by_owner || !flag || !mm) return e.err_code;
+    unsigned *mask = (unsigned *)(owner + m);
+    int *hist = itab, *cuts = itab + XS_BINS, *tab = itab + XS_BINS + XS_MAXR + 2, *pos = flag + m + 8, *rowoff_d = rows_by_owner + m;
+    // extent of the two lateral coordinates (host: one pass over 2 x m doubles per solve would cost more than it saves to do on the device -- the
+    // extents are those of the site arrays and do not change: cached per coordinate pointer)
+    static const double *ext_key = nullptr; static int ext_m = 0; static double ext[4];
+    if (ext_key != coord_y || ext_m != m) {
+        std::vector<double> hy((size_t)m), hz((size_t)m);
+        HIPCHK(hipMemcpyAsync(hy.data(), coord_y, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(hz.data(), coord_z, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        ext[0] = *std::min_element(hy.begin(), hy.end()); ext[1] = *std::max_element(hy.begin(), hy.end());
+        ext[2] = *std::min_element(hz.begin(), hz.end()); ext[3] = *std::max_element(hz.begin(), hz.end());
+        ext_key = coord_y; ext_m = m;
+    }
+    const bool use_z = ext[3] - ext[2] > ext[1] - ext[0];
+    const double *coord = use_z ? coord_z : coord_y;
+    const double lo = use_z ? ext[2] : ext[0], hi = use_z ? ext[3] : ext[1];
+    const int nbk = (m + 255) / 256;
+    HIPCHK(hipMemsetAsync(itab, 0, (size_t)(XS_BINS + XS_MAXR + 2 + XS_MAXR * (XS_MAXR + 2)) * 4, st));
+    hipLaunchKernelGGL(k_slab_hist, dim3(nbk), dim3(256), 0, st, m, 0, coord, lo, hi, hist);
+    hipLaunchKernelGGL(k_slab_cuts, dim3(1), dim3(1), 0, st, nr, m, (const int *)hist, cuts);
+    hipLaunchKernelGGL(k_slab_owner, dim3(nbk), dim3(256), 0, st, m, 0, coord, lo, hi, nr, (const int *)cuts, owner);
+    hipLaunchKernelGGL((k_slab_mask<int>), dim3(nbk), dim3(256), 0, st, m, 0, rp, cf, (const int *)owner, mask);
+    hipLaunchKernelGGL(k_slab_count, dim3(std::min(nbk, 512)), dim3(256), 0, st, m, 0, nr, (const int *)owner, (const unsigned *)mask, (const int *)nullptr, tab);
+    std::vector<int> htab((size_t)nr * (nr + 2));
+    HIPCHK(hipMemcpyAsync(htab.data(), tab, htab.size() * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int *nown = htab.data(), *hal = htab.data() + 2 * nr;
+    std::vector<int> rowoff((size_t)nr + 1, 0);
+    int maxown = 1;
+    for (int r = 0; r < nr; ++r) { rowoff[r + 1] = rowoff[r] + nown[r]; maxown = std::max(maxown, nown[r]); }
+    if (rowoff[nr] != m) return dkmc_fail(13, "slab-distributed K-CG: the slabs do not cover the rows", __FILE__, __LINE__);
+    HIPCHK(hipMemcpyAsync(rowoff_d, rowoff.data(), (size_t)(nr + 1) * 4, hipMemcpyHostToDevice, st));
+    for (int r = 0; r < nr; ++r) {
+        hipLaunchKernelGGL(k_slab_flag_rows, dim3(nbk), dim3(256), 0, st, m, 0, (const int *)owner, r, flag);
+        int rc = dkmc_exclusive_scan_i32(flag, pos, m, nullptr); if (rc) return rc;
+        hipLaunchKernelGGL(k_slab_scatter_rows, dim3(nbk), dim3(256), 0, st, m, (const int *)flag, (const int *)pos, rowoff[r], rows_by_owner);
+    }
+    std::vector<long long> cnt3((size_t)nr * nr);
+    long long halo_max = 0;
+    for (int a = 0; a < nr; ++a) for (int d = 0; d < nr; ++d) cnt3[(size_t)a * nr + d] = a == d ? 0 : hal[a * nr + d];
+    for (int d = 0; d < nr; ++d) { long long t_ = 0; for (int a = 0; a < nr; ++a) t_ += cnt3[(size_t)a * nr + d]; halo_max = std::max(halo_max, t_); }
+    g_ks_halo[0] = halo_max; g_ks_halo[1] = maxown;
+    // ---- per (virtual) rank: lists, vectors, exchange buffers ----
+    std::vector<KsRank> RK((size_t)nv);
+    for (int iv = 0; iv < nv; ++iv) {
+        KsRank &K = RK[iv]; const int v = emu ? iv : me0; K.v = v; K.n_own = nown[v];
+        for (int d = 0; d < nr; ++d) { if (d == v) continue; K.nhs += hal[v * nr + d]; K.nhr += hal[d * nr + v]; }
+        int *li = (int *)salloc(iv, S_KS_RLISTS, ((size_t)K.nhs + K.nhr + 8) * 4);
+        double *vec = iv == 0 ? nullptr : (double *)salloc(iv, 0, (size_t)m * 8 * 5);
+        K.xa = (double *)salloc(iv, S_KS_XA, (size_t)nr * KS_NPA * 8); K.xb = (double *)salloc(iv, S_KS_XB, (size_t)nr * KS_NP * 8);
+        K.send = (double *)salloc(iv, S_KS_SEND, (size_t)(K.nhs + 8) * 8); K.recv = (double *)salloc(iv, S_KS_RECV, (size_t)(K.nhr + 8) * 8);
+        K.ybuf = (double *)salloc(iv, S_KS_YBUF, (size_t)nr * maxown * 8);
+        K.ctrl = iv == 0 ? (KCtrl *)scratch(S_CG_CTRL, sizeof(KCtrl)) : (KCtrl *)salloc(iv, 0, sizeof(KCtrl));
+        if (iv == 0) {
+            K.y = y; K.q = q0;
+            K.r = (double *)scratch(S_CG_R, (size_t)m * 8); K.p = (double *)scratch(S_CG_P, (size_t)m * 8); K.t = (double *)scratch(S_CG_T, (size_t)m * 8);
+            if (!K.r || !K.p || !K.t) return e.err_code;
+        } else if (vec) {
+            K.y = vec; K.r = vec + m; K.p = vec + 2 * (size_t)m; K.t = vec + 3 * (size_t)m; K.q = vec + 4 * (size_t)m;
+            HIPCHK(hipMemcpyAsync(K.y, y, (size_t)m * 8, hipMemcpyDeviceToDevice, st));
+            HIPCHK(hipMemcpyAsync(K.q, q0, (size_t)m * 8, hipMemcpyDeviceToDevice, st));
+        }
+        if (fail || !K.ctrl) return fail ? fail : e.err_code;
+        K.own = rows_by_owner + rowoff[v]; K.hsend = li; K.hrecv = li + K.nhs;
+        int so_ = 0, ro_ = 0;
+        for (int d = 0; d < nr; ++d) {
+            if (d == v) continue;
+            const int j0 = rowoff[v], j1 = rowoff[v + 1];
+            if (j1 > j0 && hal[v * nr + d] > 0) {
+                hipLaunchKernelGGL(k_slab_flag_halo, dim3((j1 - j0 + 255) / 256), dim3(256), 0, st, j0, j1, (const int *)rows_by_owner, (const unsigned *)mask, d, flag);
+                int rc = dkmc_exclusive_scan_i32(flag, pos, j1 - j0, nullptr); if (rc) return rc;
+                hipLaunchKernelGGL(k_slab_scatter_halo, dim3((j1 - j0 + 255) / 256), dim3(256), 0, st, j0, j1, (const int *)rows_by_owner, (const int *)flag, (const int *)pos, so_, K.hsend);
+            }
+            so_ += hal[v * nr + d];
+            const int i0 = rowoff[d], i1 = rowoff[d + 1];
+            if (i1 > i0 && hal[d * nr + v] > 0) {
+                hipLaunchKernelGGL(k_slab_flag_halo, dim3((i1 - i0 + 255) / 256), dim3(256), 0, st, i0, i1, (const int *)rows_by_owner, (const unsigned *)mask, v, flag);
+                int rc = dkmc_exclusive_scan_i32(flag, pos, i1 - i0, nullptr); if (rc) return rc;
+                hipLaunchKernelGGL(k_slab_scatter_halo, dim3((i1 - i0 + 255) / 256), dim3(256), 0, st, i0, i1, (const int *)rows_by_owner, (const int *)flag, (const int *)pos, ro_, K.hrecv);
+            }
+            ro_ += hal[d * nr + v];
+        }
+        HIPCHK(hipMemsetAsync(K.ctrl, 0, sizeof(KCtrl), st));
+        HIPCHK(hipMemsetAsync(K.xa, 0, (size_t)nr * KS_NPA * 8, st));
+        HIPCHK(hipMemsetAsync(K.xb, 0, (size_t)nr * KS_NP * 8, st));
+    }
+    KCHK();
+    // ---- exchanges ----
+    auto xchg = [&](int which) -> int {          // 1: product partials, 2: r.r partials (all-gathers); 3: halo of q (all-to-all-v); 4: the solution's own rows (all-gather)
+        if (!emu) {
+            KsRank &K = RK[0];
+            if (which == 1) return comm_allgather_f64(K.xa, (size_t)KS_NPA);
+            if (which == 2) return comm_allgather_f64(K.xb, (size_t)KS_NP);
+            if (which == 3) return comm_alltoallv_f64(K.send, K.recv, cnt3.data());
+            return comm_allgather_f64(K.ybuf, (size_t)maxown);
+        }
+        if (which != 3) {
+            const size_t n = which == 1 ? KS_NPA : (which == 2 ? KS_NP : (size_t)maxown);
+            for (int a = 0; a < nr; ++a) for (int d = 0; d < nr; ++d) {
+                if (a == d) continue;
+                double *src = (which == 1 ? RK[a].xa : which == 2 ? RK[a].xb : RK[a].ybuf) + (size_t)a * n;
+                double *dst = (which == 1 ? RK[d].xa : which == 2 ? RK[d].xb : RK[d].ybuf) + (size_t)a * n;
+                HIPCHK(hipMemcpyAsync(dst, src, n * 8, hipMemcpyDeviceToDevice, st));
+            }
+            return 0;
+        }
+        for (int a = 0; a < nr; ++a) {
+            long long so_ = 0;
+            for (int d = 0; d < nr; ++d) {
+                const long long n = cnt3[(size_t)a * nr + d];
+                long long ro = 0; for (int a2 = 0; a2 < a; ++a2) ro += cnt3[(size_t)a2 * nr + d];
+                if (n > 0) HIPCHK(hipMemcpyAsync(RK[d].recv + ro, RK[a].send + so_, (size_t)n * 8, hipMemcpyDeviceToDevice, st));
+                so_ += n;
+            }
+        }
+        return 0;
+    };
+    const bool timing = emu && time_rank >= 0 && time_rank < nr;
+    hipEvent_t tev[2] = {nullptr, nullptr};
+    if (timing) { HIPCHK(hipEventCreate(&tev[0])); HIPCHK(hipEventCreate(&tev[1])); }
+    struct EvFree { hipEvent_t *ev; ~EvFree() { for (int i = 0; i < 2; ++i) if (ev[i]) (void)hipEventDestroy(ev[i]); } } evfree{tev};
+    double tsum[4] = {0, 0, 0, 0}; int tcount = 0;
+    auto timed = [&](int iv, int cls, bool on, const std::function<void()> &launch) -> int {
+        if (timing && on && RK[iv].v == time_rank) {
+            HIPCHK(hipEventRecord(tev[0], st)); launch(); HIPCHK(hipEventRecord(tev[1], st)); HIPCHK(hipEventSynchronize(tev[1]));
+            float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, tev[0], tev[1])); tsum[cls] += ms;
+        } else launch();
+        return 0;
+    };
+    auto halo = [&](bool on) -> int {
+        if (nr == 1) return 0;
+        for (int iv = 0; iv < nv; ++iv) { KsRank &K = RK[iv]; if (K.nhs > 0) { int rc = timed(iv, 3, on, [&]() { hipLaunchKernelGGL(k_ks_gather, dim3((K.nhs + 255) / 256), dim3(256), 0, st, K.nhs, (const int *)K.hsend, (const double *)K.q, K.send); }); if (rc) return rc; } }
+        if (int rcx = xchg(3)) return rcx;
+        for (int iv = 0; iv < nv; ++iv) { KsRank &K = RK[iv]; if (K.nhr > 0) { int rc = timed(iv, 3, on, [&]() { hipLaunchKernelGGL(k_ks_scatter, dim3((K.nhr + 255) / 256), dim3(256), 0, st, K.nhr, (const int *)K.hrecv, (const double *)K.recv, K.q); }); if (rc) return rc; } }
+        return 0;
+    };
+    // ---- r = A y - b, p = -r, q = S p ----
+    for (int iv = 0; iv < nv; ++iv) {
+        KsRank &K = RK[iv];
+        const int ga = kc_grid(K.n_own, KC_NT / 8, KS_NPA);
+        if (K.n_own > 0) {
+            hipLaunchKernelGGL((k_kc_apply<1>), dim3(ga), dim3(KC_NT), 0, st, K.n_own, rp, cf, diag, s, (const double *)K.q, high_G, low_G, (const double *)nullptr, K.t,
+                               K.xa + (size_t)K.v * KS_NPA, (const KCtrl *)K.ctrl, b, K.r, K.p, (const int *)K.own);
+            hipLaunchKernelGGL(k_ks_q, dim3((K.n_own + 255) / 256), dim3(256), 0, st, K.n_own, (const int *)K.own, s, (const double *)K.p, K.q);
+        }
+    }
+    if (int rcx = xchg(1)) return rcx;
+    for (int iv = 0; iv < nv; ++iv) hipLaunchKernelGGL(k_ks_check0, dim3(1), dim3(KC_NT), 0, st, nr * KS_NPA, (const double *)RK[iv].xa, RK[iv].ctrl, tol2);
+    if (int rcx = halo(false)) return rcx;
+    KCHK();
+    KCtrl h{};
+    int it = 0, batch = 8;
+    for (;;) {
+        HIPCHK(hipMemcpyAsync(&h, RK[0].ctrl, sizeof(KCtrl), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (h.done) break;
+        if (emu && g_ks_iter_cap > 0 && it >= g_ks_iter_cap) break;
+        if (it >= 200000) { dkmc_fail(4, "CG: no convergence after 200000 iterations", __FILE__, __LINE__); break; }
+        for (int bq = 0; bq < batch; ++bq, ++it) {
+            const bool on = timing && it >= 2 && tcount < 24;
+            for (int iv = 0; iv < nv; ++iv) {
+                KsRank &K = RK[iv];
+                if (K.n_own <= 0) continue;
+                int rc = timed(iv, 0, on, [&]() {
+                    hipLaunchKernelGGL((k_kc_apply<2>), dim3(kc_grid(K.n_own, KC_NT / 8, KS_NPA)), dim3(KC_NT), 0, st, K.n_own, rp, cf, diag, s, (const double *)K.q, high_G, low_G,
+                                       (const double *)K.p, K.t, K.xa + (size_t)K.v * KS_NPA, (const KCtrl *)K.ctrl, (const double *)nullptr, K.r, (double *)nullptr, (const int *)K.own);
+                }); if (rc) return rc;
+            }
+            if (int rcx = xchg(1)) return rcx;
+            for (int iv = 0; iv < nv; ++iv) {
+                KsRank &K = RK[iv];
+                int rc = timed(iv, 1, on, [&]() {
+                    hipLaunchKernelGGL(k_ks_update, dim3(kc_grid(std::max(K.n_own, 1), KC_NT, KS_NP)), dim3(KC_NT), 0, st, K.n_own, (const int *)K.own, it, (const double *)K.xa, nr * KS_NPA,
+                                       (const double *)K.p, (const double *)K.t, K.y, K.r, K.xb + (size_t)K.v * KS_NP, (const KCtrl *)K.ctrl);
+                }); if (rc) return rc;
+            }
+            if (int rcx = xchg(2)) return rcx;
+            for (int iv = 0; iv < nv; ++iv) {
+                KsRank &K = RK[iv];
+                int rc = timed(iv, 2, on, [&]() {
+                    hipLaunchKernelGGL(k_ks_direction, dim3(kc_grid(std::max(K.n_own, 1), KC_NT, KS_NP)), dim3(KC_NT), 0, st, K.n_own, (const int *)K.own, it, (const double *)K.xb, nr * KS_NP,
+                                       (const double *)K.r, K.p, s, K.q, K.ctrl, tol2);
+                }); if (rc) return rc;
+            }
+            if (int rcx = halo(on)) return rcx;
+            if (on) ++tcount;
+        }
+        KCHK();
+        if (batch < 64) batch *= 2;
+    }
+    if (e.err_code) return e.err_code;
+    if (emu) {
+        for (int iv = 1; iv < nv; ++iv) {
+            KCtrl hv{};
+            HIPCHK(hipMemcpy(&hv, RK[iv].ctrl, sizeof(KCtrl), hipMemcpyDeviceToHost));
+            if (hv.iters != h.iters || hv.done != h.done || memcmp(hv.rr, h.rr, sizeof(h.rr)) != 0) return dkmc_fail(13, "K-CG slab emulation: the virtual ranks disagree on the iteration or on r.r", __FILE__, __LINE__);
+        }
+    }
+    // ---- the solution on every rank ----
+    if (nr > 1) {
+        for (int iv = 0; iv < nv; ++iv) { KsRank &K = RK[iv]; if (K.n_own > 0) hipLaunchKernelGGL(k_ks_gather, dim3((K.n_own + 255) / 256), dim3(256), 0, st, K.n_own, (const int *)K.own, (const double *)K.y, K.ybuf + (size_t)K.v * maxown); }
+        if (int rcx = xchg(4)) return rcx;
+        for (int iv = 0; iv < nv; ++iv) { KsRank &K = RK[iv]; hipLaunchKernelGGL(k_ks_scatter_all, dim3(std::min((maxown + 255) / 256, 256), nr), dim3(256), 0, st, nr, K.v, maxown, (const int *)rows_by_owner, (const int *)rowoff_d, (const double *)K.ybuf, K.y); }
+    }
+    if (emu && nv > 1) {
+        std::vector<double> y0_((size_t)m), yv_((size_t)m);
+        HIPCHK(hipMemcpyAsync(y0_.data(), RK[0].y, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (int iv = 1; iv < nv; ++iv) {
+            HIPCHK(hipMemcpy(yv_.data(), RK[iv].y, (size_t)m * 8, hipMemcpyDeviceToHost));
+            if (memcmp(y0_.data(), yv_.data(), (size_t)m * 8) != 0) return dkmc_fail(13, "K-CG slab emulation: the virtual ranks hold different solutions", __FILE__, __LINE__);
+        }
+    }
+    KCHK();
+    HIPCHK(hipStreamSynchronize(st));
+    if (timing) for (int c = 0; c < 4; ++c) g_ks_times[c] = tcount ? tsum[c] * 1e3 / tcount : 0.0;
+    if (iters_out) *iters_out = h.iters;
+    if (rr_out) *rr_out = h.rr[h.iters & 1];
+    return e.err_code;
+}
+
+// doubles received per iteration in the halo exchange (largest over the ranks), rows of the largest slab, kernel times of the timed virtual rank
+void kcg_slab_report(double *times_us, long long *halo_rows) { for (int c = 0; c < 4; ++c) if (times_us) times_us[c] = g_ks_times[c]; if (halo_rows) { halo_rows[0] = g_ks_halo[0]; halo_rows[1] = g_ks_halo[1]; } }
+void kcg_slab_iter_cap(int cap) { g_ks_iter_cap = cap; }

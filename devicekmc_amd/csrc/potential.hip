@@ -2,10 +2,15 @@
 // screened-Coulomb pair sum.  Replaces potential_solver_gpu.cu (live parts) and the K-pattern
 // builders of iterative_solvers_gpu.cu.
 #include "common.h"
+#include <algorithm>
+#include <vector>
 
 int kcg_assemble_and_solve(int cb, int m, int N_left, const int *element, const int *charge, MetalSet ms, double high_G, double low_G,
                            const int *rp, const int *ci, int nnz, const int *lrp, const int *lci, const int *rrp, const int *rci,
-                           double VL, double VR, double *y, int *iters_out, double *rr_out, const KBlocked *kb);
+                           double VL, double VR, double *y, int *iters_out, double *rr_out, const KBlocked *kb,
+                           const double *row_y, const double *row_z, int emu_nr, int emu_time_rank);
+void kcg_slab_report(double *times_us, long long *halo_rows);
+void kcg_slab_iter_cap(int cap);
 KBlocked *kblocked_build(const int *rp_d, const int *ci_d, int m, int nnz, const double *x_d, hipStream_t st);
 void kblocked_free(KBlocked *kb);
 void tcache_invalidate(const void *key);
@@ -189,7 +194,56 @@ static int solve_K(dkmc_gpubuf *buf, int N, int N_left, int N_right, double VL, 
     (void)e; (void)st;
     return kcg_assemble_and_solve(cb, m, N_left, buf->site_element, buf->site_charge, ms, high_G, low_G, buf->Device_row_ptr_d, buf->Device_col_indices_d,
                                   buf->Device_nnz, buf->contact_left_row_ptr, buf->contact_left_col_indices, buf->contact_right_row_ptr,
-                                  buf->contact_right_col_indices, VL, VR, field + N_left, iters, rr, kpat_blocked(buf->Device_row_ptr_d));
+                                  buf->contact_right_col_indices, VL, VR, field + N_left, iters, rr, kpat_blocked(buf->Device_row_ptr_d),
+                                  buf->site_y + N_left, buf->site_z + N_left, 0, -1);
+}
+
+// ---- test / measurement aid: the slab-distributed CG on K (kcg.hip) with nranks VIRTUAL ranks on ONE GPU ---------------------------------------
+// The background-potential system of the buffer's current state (elements, charges), solved twice from the buffer's current potential -- by the
+// one-GPU reference-order loop on the CSR positions and by the slab-distributed loop with nranks virtual ranks (exchanges as device copies) -- into
+// scratch copies: the buffer is not changed.  The emulation itself fails unless all virtual ranks stop at the same iteration with the same r.r
+// and end with the same bits.  max_abs_diff: largest deviation of the two potentials [V]; times_us[4]: mean kernel times of virtual rank
+// time_rank (product, update, direction, halo pack + unpack); halo_rows[2]: doubles a rank receives per iteration in the halo exchange (largest),
+// rows of the largest slab.  iter_cap > 0: measurement run, the distributed loop stops after that many iterations (max_abs_diff = -1).
+extern "C" int dkmc_kcg_emulate_slabs(dkmc_gpubuf *buf, int N, int N_left, int N_right, double Vd, double high_G, double low_G, int num_metals, int nranks, int time_rank,
+                                      int iter_cap, double *max_abs_diff, int *iters_slab, int *iters_ref, double *times_us, long long *halo_rows)
+{
+    Engine &e = eng(); hipStream_t st = e.stream;
+    const int m = N - N_left - N_right;
+    if (!buf || m <= 0 || nranks < 1 || nranks > 32 || comm_attached()) return dkmc_fail(13, "kcg_emulate_slabs: bad arguments (or a communicator is attached)", __FILE__, __LINE__);
+    if (!buf->Device_row_ptr_d || N_left != N_right || !kpat_matches(buf->Device_row_ptr_d, m, N_left)) return dkmc_fail(6, "K sparsity not initialised for these contact sizes", __FILE__, __LINE__);
+    MetalSet ms = load_metals(buf->metal_types, num_metals);
+    double *tmp = (double *)scratch(S_KS_EMU, (size_t)m * 8 * 2);
+    if (!tmp) return e.err_code;
+    double *yref = tmp, *yslab = tmp + m;
+    HIPCHK(hipMemcpyAsync(yref, buf->site_potential_boundary + N_left, (size_t)m * 8, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipMemcpyAsync(yslab, buf->site_potential_boundary + N_left, (size_t)m * 8, hipMemcpyDeviceToDevice, st));
+    if (iter_cap > 0) HIPCHK(hipMemsetAsync(yslab, 0, (size_t)m * 8, st));       // measurement run: from zero, so that the capped iterations are working ones (the buffer usually holds the solution)
+    int it_ref = 0, it_slab = 0; double rr = 0.0;
+    int rc = 0;
+#define KS_SOLVE(Y, EMU, IT) kcg_assemble_and_solve(0, m, N_left, buf->site_element, buf->site_charge, ms, high_G, low_G, buf->Device_row_ptr_d, buf->Device_col_indices_d, \
+        buf->Device_nnz, buf->contact_left_row_ptr, buf->contact_left_col_indices, buf->contact_right_row_ptr, buf->contact_right_col_indices, -Vd / 2, Vd / 2, Y, IT, &rr, \
+        (const KBlocked *)nullptr, buf->site_y + N_left, buf->site_z + N_left, EMU, time_rank)
+    if (iter_cap <= 0) { rc = KS_SOLVE(yref, 0, &it_ref); if (rc) return rc; }
+    kcg_slab_iter_cap(iter_cap);
+    rc = KS_SOLVE(yslab, nranks, &it_slab);
+    kcg_slab_iter_cap(0);
+#undef KS_SOLVE
+    if (rc) return rc;
+    kcg_slab_report(times_us, halo_rows);
+    double md = -1.0;
+    if (iter_cap <= 0) {
+        std::vector<double> a((size_t)m), b((size_t)m);
+        HIPCHK(hipMemcpyAsync(a.data(), yref, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(b.data(), yslab, (size_t)m * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        md = 0.0;
+        for (int i = 0; i < m; ++i) md = std::max(md, fabs(a[i] - b[i]));
+    }
+    if (max_abs_diff) *max_abs_diff = md;
+    if (iters_slab) *iters_slab = it_slab;
+    if (iters_ref) *iters_ref = it_ref;
+    return e.err_code;
 }
 
 // background_potential_gpu_sparse (potential_solver_gpu.cu:696-781)

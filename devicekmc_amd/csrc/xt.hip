@@ -1243,7 +1243,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         int bi = 0; double brr = 0.0;
         rc = xtb_cg(B, &bi, &brr);
         e.stats.xb_width = e.x_block;
-        if (rc == 0) { solved = true; h.iters = bi; h.rr[bi & 1] = brr; if (sharded) e.stats.comm_count_per_rank = (long long)ns * (4 * ((e.x_block + 3) / 4)) + 2; }
+        if (rc == 0) { solved = true; h.iters = bi; h.rr[bi & 1] = brr; if (sharded && !(e.x_slab && comm_nranks() > 1)) e.stats.comm_count_per_rank = (long long)ns * (4 * ((e.x_block + 3) / 4)) + 2; }      // (slab-distributed loop: set there)
         else if (rc != DKMC_XTB_BREAKDOWN) return rc;
         else {
             e.stats.xb_fallback = 1;
@@ -1528,8 +1528,8 @@ extern "C" int dkmc_xt_check_shares(int nranks, double *max_abs_diff, double *ma
 // different sweeps or end with different bits.  Out: largest deviation of the two solutions relative to the largest entry, both sweep counts,
 // the mean kernel times of virtual rank time_rank over sweeps 2 ... 25 (time_rank < 0: none), the doubles a rank receives per sweep in the three
 // exchanges (largest over the ranks).  Scratch vectors of the last solve are overwritten; delivered results are not.
-int xtb_cg_slab_emulate(const XtbArgs &A, int nr, const XShare *shares, int time_rank, int *iters_out, double *rr_out, double *times_us, long long *xdoubles);
-extern "C" int dkmc_xtb_emulate_slabs(int nranks, int width, double tol, int time_rank, double *rel_diff, int *iters_slab, int *iters_ref,
+// sweep_cap > 0 (measurement run): the distributed loop stops after that many sweeps and the one-GPU solve is skipped (rel_diff = -1).
+extern "C" int dkmc_xtb_emulate_slabs(int nranks, int width, double tol, int time_rank, int sweep_cap, double *rel_diff, int *iters_slab, int *iters_ref,
                                       double *times_us /* [8] */, long long *xdoubles /* [3] */, int *rows_min_max /* [2] */)
 {
     Engine &e = eng(); hipStream_t st = e.stream; const XTState &X = g_xt;
@@ -1554,8 +1554,8 @@ extern "C" int dkmc_xtb_emulate_slabs(int nranks, int width, double tol, int tim
     HIPCHK(hipMemsetAsync(yb, 0, (size_t)(m + 8) * 8 * 2, st));
     B.y = yref;
     int it_ref = 0, it_slab = 0; double rr = 0.0;
-    int rc = xtb_cg(B, &it_ref, &rr);
-    if (rc && rc != DKMC_XTB_BREAKDOWN) return rc;
+    int rc = 0;
+    if (sweep_cap <= 0) { rc = xtb_cg(B, &it_ref, &rr); if (rc && rc != DKMC_XTB_BREAKDOWN) return rc; }
     // (2) nranks virtual ranks: the shares of an nranks-way assembly
     const int ntiles = X.ntiles;
     int kc = std::max(1, std::min(XT_MAXKC, ntiles / nranks / 4096));
@@ -1567,7 +1567,7 @@ extern "C" int dkmc_xtb_emulate_slabs(int nranks, int width, double tol, int tim
         if ((sh[r].item_lo | sh[r].item_n) & 3) return dkmc_fail(48, "xtb_emulate_slabs: run list not padded to groups of four", __FILE__, __LINE__);
     }
     B.y = yslab;
-    rc = xtb_cg_slab_emulate(B, nranks, sh.data(), time_rank, &it_slab, &rr, times_us, xdoubles);
+    rc = xtb_cg_slab_emulate(B, nranks, sh.data(), time_rank, sweep_cap, &it_slab, &rr, times_us, xdoubles);
     e.x_iter_hint = hint;
     if (rc && rc != DKMC_XTB_BREAKDOWN) return rc;
     std::vector<double> h0((size_t)m), h1((size_t)m);
@@ -1576,7 +1576,7 @@ extern "C" int dkmc_xtb_emulate_slabs(int nranks, int width, double tol, int tim
     HIPCHK(hipStreamSynchronize(st));
     double md = 0.0, ma = 0.0;
     for (int i = 0; i < m; ++i) { md = std::max(md, fabs(h0[i] - h1[i])); ma = std::max(ma, fabs(h0[i])); }
-    if (rel_diff) *rel_diff = ma > 0.0 ? md / ma : md;
+    if (rel_diff) *rel_diff = sweep_cap > 0 ? -1.0 : (ma > 0.0 ? md / ma : md);
     if (iters_slab) *iters_slab = it_slab;
     if (iters_ref) *iters_ref = it_ref;
     if (rows_min_max) {          // balance of the slabs: rows of the smallest and the largest one (the table the solver built)

@@ -37,6 +37,7 @@
 // Only column 0 of Y is kept (a vector): the auxiliary solutions are never needed.  The neighbour part gathers P and the scaling, so no
 // scaled full-length copy of P exists; the compact scaled copy over S (QS) feeds the tiles.
 #include "xtiles.h"
+#include "slab.h"
 #include <hip/hip_ext.h>
 #include <algorithm>
 #include <functional>
@@ -411,7 +412,7 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
 __global__ __launch_bounds__(XT_NT) void k_xtb_neigh(int m, const xrp_t *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ val,
                                                      const double *__restrict__ P, const double *__restrict__ sc, const int *__restrict__ nsrank,
                                                      const XCtrl *ctrl, double *__restrict__ T, double *__restrict__ drvpart,
-                                                     const int *__restrict__ rowlist = nullptr, int nlist = 0, const int *__restrict__ owner = nullptr, int me = 0)
+                                                     const int *__restrict__ rowlist = nullptr, int nlist = 0, const int *__restrict__ dlist = nullptr, int nd0 = 0, int nd1 = 0)
 {
     __shared__ double red[16][16];
     if (ctrl->done) return;
@@ -422,8 +423,18 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_neigh(int m, const xrp_t *__restr
         const xrp_t len = p1 - p0, a = p0 + len * part / XB_DSPLIT, b = p0 + len * (part + 1) / XB_DSPLIT;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
         xrp_t p = a + g;
-        if (owner) {
-            for (; p < b; p += 16) { const int c0 = ci[p]; if ((c0 < 2 ? 0 : owner[c0]) == me) s0 += val[p] * (sc[c0] * P[(size_t)c0 * XB_SP + v]); }
+        if (dlist) {
+            // slab-distributed solve: dlist = positions of the entries of row 0 (nd0 of them) and row 1 (nd1) whose column this rank owns
+            const int n = row == 0 ? nd0 : nd1, l0 = row == 0 ? 0 : nd0;
+            const int ia = l0 + (int)((long long)n * part / XB_DSPLIT), ib = l0 + (int)((long long)n * (part + 1) / XB_DSPLIT);
+            int i = ia + g;
+            for (; i + 48 < ib; i += 64) {
+                const int q0 = dlist[i], q1 = dlist[i + 16], q2 = dlist[i + 32], q3 = dlist[i + 48];
+                const int c0 = ci[q0], c1 = ci[q1], c2 = ci[q2], c3 = ci[q3];
+                s0 += val[q0] * (sc[c0] * P[(size_t)c0 * XB_SP + v]); s1 += val[q1] * (sc[c1] * P[(size_t)c1 * XB_SP + v]);
+                s2 += val[q2] * (sc[c2] * P[(size_t)c2 * XB_SP + v]); s3 += val[q3] * (sc[c3] * P[(size_t)c3 * XB_SP + v]);
+            }
+            for (; i < ib; i += 16) { const int q0 = dlist[i], c0 = ci[q0]; s0 += val[q0] * (sc[c0] * P[(size_t)c0 * XB_SP + v]); }
             p = b;
         }
         for (; p + 48 < b; p += 64) {
@@ -780,8 +791,10 @@ __device__ __forceinline__ void xtb_chol_solve(XB_M(X), XB_M(L), XB_M(B), int s)
 }
 // nrg > 1 (slab-distributed solve): gfin holds one block of gstride doubles per rank -- that rank's partial Gram matrices and, behind them, its
 // abort word -- all-gathered; every rank adds the blocks IN RANK ORDER: identical matrices, hence identical decisions, on every rank.
-__global__ __launch_bounds__(64) void k_xtb_small(int it, int s, const double *__restrict__ gfin, double *__restrict__ mats, XCtrl *ctrl, double tol2,
-                                                  int nrg = 1, int gstride = 0)
+// Launched with 256 threads: all four waves load (and, nrg > 1, add) the Gram matrices into LDS, then wave 0 does the algebra alone (one wave
+// summing 24 x nrg dependent loads took 73 us at nrg = 8).
+__global__ __launch_bounds__(256) void k_xtb_small(int it, int s, const double *__restrict__ gfin, double *__restrict__ mats, XCtrl *ctrl, double tol2,
+                                                   int nrg = 1, int gstride = 0)
 {
     __shared__ double Gm[XB_NG][16][17], Lp[16][17], Cm[16][17], Vm[16][17], Bm[16][17], Grn[16][17], Gprn[16][17], Gg[16][17], Wm[16][17], Tm[16][17];
     if (ctrl->done) return;
@@ -790,17 +803,25 @@ __global__ __launch_bounds__(64) void k_xtb_small(int it, int s, const double *_
         for (int r = 0; r < nrg; ++r) ab |= gfin[(size_t)r * gstride + XB_NG * 256 + 1] != 0.0;
         if (ab) { if (threadIdx.x == 0) { ctrl->aborted = 1; ctrl->done = it + 1 > 0 ? it + 1 : 1; } return; }      // uniform: every lane read the same words
     }
-    // Gram matrices: entry e = (register u, lane l) of the row kernel's accumulators is (l / 16 + 4 u, l % 16)
+    // Gram matrices: entry e = (register u, lane l) of the row kernel's accumulators is (l / 16 + 4 u, l % 16); thread t of the workgroup
+    // takes (u = t / 64, l = t % 64) of every matrix, the ranks' blocks added in rank order (four loads in flight)
+    {
+        const int u = threadIdx.x >> 6, l = threadIdx.x & 63;
 #pragma unroll
-    for (int g = 0; g < XB_NG; ++g)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int l = threadIdx.x;
-            double a = gfin[g * 256 + u * 64 + l];
-            for (int r = 1; r < nrg; ++r) a += gfin[(size_t)r * gstride + g * 256 + u * 64 + l];
+        for (int g = 0; g < XB_NG; ++g) {
+            const double *src = gfin + g * 256 + u * 64 + l;
+            double a = src[0];
+            int r = 1;
+            for (; r + 3 < nrg; r += 4) {
+                const double x0 = src[(size_t)r * gstride], x1 = src[(size_t)(r + 1) * gstride], x2 = src[(size_t)(r + 2) * gstride], x3 = src[(size_t)(r + 3) * gstride];
+                a += x0; a += x1; a += x2; a += x3;
+            }
+            for (; r < nrg; ++r) a += src[(size_t)r * gstride];
             Gm[g][(l >> 4) + 4 * u][l & 15] = a;
         }
-    XB_WSYNC();
+    }
+    __syncthreads();
+    if (threadIdx.x >= 64) return;
     const bool init = it < 0;
     double rr_new;
     if (init) {
@@ -1002,7 +1023,6 @@ int g_xtb_fault_iter = -1;
 // Returns 0 with the scaled solution of column 0 in A.y; DKMC_XTB_BREAKDOWN (> 0, no error recorded) when an s x s system lost
 // definiteness: A.y then holds the last good iterate and the caller continues with the single-vector loop from it.
 static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *peer_used);
-#define XS_MAXR 32
 static int xtb_cg_slab(const XtbArgs &A, int nr, int me0, const XShare *emu_shares, int time_rank, int *iters_out, double *rr_out);
 int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
 {
@@ -1125,7 +1145,7 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
     product(nullptr, nullptr);
     if (int rcx = rows(true, -1, nullptr, nullptr)) return rcx;
     hipLaunchKernelGGL(k_xtb_gred, dim3(XB_NG * 16), dim3(XT_NT), 0, st, ng, (const double *)gpart, gfin, (const XCtrl *)A.ctrl);
-    hipLaunchKernelGGL(k_xtb_small, dim3(1), dim3(64), 0, st, -1, s, (const double *)gfin, mats, A.ctrl, A.tol2);
+    hipLaunchKernelGGL(k_xtb_small, dim3(1), dim3(256), 0, st, -1, s, (const double *)gfin, mats, A.ctrl, A.tol2);
     hipLaunchKernelGGL(k_xtb_zero, dim3((unsigned)((pan + 255) / 256)), dim3(256), 0, st, (long long)pan, P);          // Y0 has served: P_{-1} = 0
     hipLaunchKernelGGL(k_xtb_step, dim3(gs), dim3(XT_NT), 0, st, m, -1, (const double *)mats, y0, R, P, (const double *)T, A.sc, A.nsrank, QS, (const XCtrl *)A.ctrl);
     KCHK();
@@ -1152,7 +1172,7 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
             product(pb ? evs[4 * sl] : nullptr, pb ? evs[4 * sl + 1] : nullptr);
             if (int rcx = rows(false, it, pb ? evs[4 * sl + 2] : nullptr, pb ? evs[4 * sl + 3] : nullptr)) return rcx;
             hipLaunchKernelGGL(k_xtb_gred, dim3(XB_NG * 16), dim3(XT_NT), 0, st, ng, (const double *)gpart, gfin, (const XCtrl *)A.ctrl);
-            hipLaunchKernelGGL(k_xtb_small, dim3(1), dim3(64), 0, st, it, s, (const double *)gfin, mats, A.ctrl, A.tol2);
+            hipLaunchKernelGGL(k_xtb_small, dim3(1), dim3(256), 0, st, it, s, (const double *)gfin, mats, A.ctrl, A.tol2);
             hipLaunchKernelGGL(k_xtb_step, dim3(gs), dim3(XT_NT), 0, st, m, it, (const double *)mats, y0, R, P, (const double *)T, A.sc, A.nsrank, QS, (const XCtrl *)A.ctrl);
         }
         launched = batch;
@@ -1177,9 +1197,11 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
 
 #include "xtb_slab.inc"
 // emulation entry (xt.hip: dkmc_xtb_emulate_slabs): nr virtual ranks in this process on the resident X of a single-GPU solve
-int xtb_cg_slab_emulate(const XtbArgs &A, int nr, const XShare *shares, int time_rank, int *iters_out, double *rr_out, double *times_us, long long *xdoubles)
+int xtb_cg_slab_emulate(const XtbArgs &A, int nr, const XShare *shares, int time_rank, int sweep_cap, int *iters_out, double *rr_out, double *times_us, long long *xdoubles)
 {
+    g_slab_sweep_cap = sweep_cap;
     const int rc = xtb_cg_slab(A, nr, 0, shares, time_rank, iters_out, rr_out);
+    g_slab_sweep_cap = 0;
     if (times_us) for (int c = 0; c < 8; ++c) times_us[c] = g_slab_times.us[c];
     if (xdoubles) for (int c = 0; c < 3; ++c) xdoubles[c] = g_slab_xbytes[c];
     return rc;

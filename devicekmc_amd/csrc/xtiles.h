@@ -77,5 +77,5 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out);
 struct XShare { int nitems, maxchunk, item_lo, item_n, tile_lo, tile_n, w_lo, w_hi; long long sub_base, sub_n; XItem *items; int *nitem_w; int rec_shift; };
 // the slab-distributed block-CG with nr VIRTUAL ranks in this process (xtb_slab.inc); times_us[8]: mean kernel times of virtual rank time_rank
 // (apply, neighbour part, fold, rows, Gram reduction, s x s algebra, step, pack + unpack); xdoubles[3]: doubles a rank receives per sweep in the three exchanges
-int xtb_cg_slab_emulate(const XtbArgs &A, int nr, const XShare *shares, int time_rank, int *iters_out, double *rr_out, double *times_us, long long *xdoubles);
+int xtb_cg_slab_emulate(const XtbArgs &A, int nr, const XShare *shares, int time_rank, int sweep_cap, int *iters_out, double *rr_out, double *times_us, long long *xdoubles);
 __global__ void k_xt_vec_mul(int m, double *__restrict__ y, const double *__restrict__ s);

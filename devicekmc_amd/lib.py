@@ -60,6 +60,8 @@ SYMBOLS = {
     "dkmc_set_cb_edge_domain": (None, [_I]),
     "dkmc_set_x_block": (None, [_I]),
     "dkmc_get_x_block": (_I, []),
+    "dkmc_set_k_slab": (None, [_I]),
+    "dkmc_get_k_slab": (_I, []),
     "dkmc_set_x_slab": (None, [_I]),
     "dkmc_get_x_slab": (_I, []),
     "dkmc_set_x_aux": (None, [_I]),
@@ -109,7 +111,8 @@ SYMBOLS = {
     "dkmc_xt_check_shares": (_I, [_I, c_dbl_p, c_dbl_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), c_int_p]),
     "dkmc_xtb_check_product": (_I, [_I, c_dbl_p, c_dbl_p]),
     "dkmc_xtb_time_apply": (_I, [_I, _I, _I, c_dbl_p]),
-    "dkmc_xtb_emulate_slabs": (_I, [_I, _I, _D, _I, c_dbl_p, c_int_p, c_int_p, c_dbl_p, C.POINTER(C.c_longlong), c_int_p]),
+    "dkmc_kcg_emulate_slabs": (_I, [C.POINTER(dkmc_gpubuf), _I, _I, _I, _D, _D, _D, _I, _I, _I, _I, c_dbl_p, c_int_p, c_int_p, c_dbl_p, C.POINTER(C.c_longlong)]),
+    "dkmc_xtb_emulate_slabs": (_I, [_I, _I, _D, _I, _I, c_dbl_p, c_int_p, c_int_p, c_dbl_p, C.POINTER(C.c_longlong), c_int_p]),
     "dkmc_debug_inject_fault": (None, [_I, _I]),
     "dkmc_debug_step_stop_word": (_I, [_I, _I, _I, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "dkmc_comm_unique_id": (_I, [C.c_char_p]),

@@ -151,6 +151,12 @@ int dkmc_get_x_block(void);
  * (all-to-all-v) (csrc/xtb_slab.inc).  0: the all-gather variant -- only the tile stream is sharded, everything else replicated. */
 void dkmc_set_x_slab(int on);
 int dkmc_get_x_slab(void);
+/* More than one rank, K system above the size of the blocked form (262 144 rows): 1 (default) distributes the CG on K (background potential, CB
+ * edge) by the same lateral row slabs -- product, update and direction on the own rows, the two dot products of an iteration completed by
+ * all-gathers of block partials added in one fixed order on every rank, the halo of the scaled direction by an all-to-all-v (csrc/kcg.hip;
+ * SURVEY 8e row "K-CG").  0: the solve is replicated on every rank. */
+void dkmc_set_k_slab(int on);
+int dkmc_get_k_slab(void);
 /* Auxiliary right-hand sides of the block-CG (a free choice: only their block Krylov space matters; column 0 is always the physical system).
  * 0: fixed-seed hash of (row, column), uniform in [-1, 1).  1: smooth set, column v = cos(v pi xi) / s with xi the atom's x coordinate scaled to
  * [0, 1] -- rich in the low modes of the neighbour part of X: 20-35 % fewer sweeps at the default tolerance.  2 (default): the smooth set at

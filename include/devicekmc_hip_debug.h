@@ -42,9 +42,17 @@ int dkmc_debug_step_stop_word(int m, int it, int done_word, int *updated, int *d
  * assembly builds them, rows owned by lateral slabs, exchanges as device copies), both from a zero start to `tol`.  rel_diff: largest deviation of
  * the two solutions / largest entry; times_us[8]: mean kernel times of virtual rank time_rank (apply, neighbour part, fold, rows, Gram reduction,
  * s x s algebra, step, pack + unpack); xdoubles[3]: doubles a rank receives per sweep in the three exchanges; rows_min_max[2]: rows of the smallest
- * and largest slab.  Fails if the virtual ranks leave the loop at different sweeps or end with different bits. */
-int dkmc_xtb_emulate_slabs(int nranks, int width, double tol, int time_rank, double *rel_diff, int *iters_slab, int *iters_ref,
+ * and largest slab.  sweep_cap > 0: measurement run -- the distributed loop stops after that many sweeps, the one-GPU solve is skipped, rel_diff = -1.  Fails if the virtual ranks leave the loop at different sweeps or end with different bits. */
+int dkmc_xtb_emulate_slabs(int nranks, int width, double tol, int time_rank, int sweep_cap, double *rel_diff, int *iters_slab, int *iters_ref,
                            double *times_us, long long *xdoubles, int *rows_min_max);
+
+/* Test / measurement aid: the slab-distributed CG on K (csrc/kcg.hip) with nranks VIRTUAL ranks inside this process: the background-potential
+ * system of the buffer's current state solved from the buffer's current potential by the one-GPU reference-order loop and by the distributed loop
+ * (exchanges as device copies), into scratch copies.  max_abs_diff [V]; times_us[4]: product, update, direction, halo pack + unpack of virtual
+ * rank time_rank; halo_rows[2]: doubles received per iteration in the halo exchange (largest over the ranks), rows of the largest slab.
+ * iter_cap > 0: measurement run (the distributed loop stops after that many iterations, max_abs_diff = -1). */
+int dkmc_kcg_emulate_slabs(dkmc_gpubuf *buf, int N, int N_left, int N_right, double Vd, double high_G, double low_G, int num_metals, int nranks, int time_rank,
+                           int iter_cap, double *max_abs_diff, int *iters_slab, int *iters_ref, double *times_us, long long *halo_rows);
 
 #ifdef __cplusplus
 }

@@ -142,64 +142,86 @@ def test_tile10_full_superstep_properties():
 
 
 
-@pytest.mark.skipif(os.environ.get("DKMC_SLOW_TESTS") != "1", reason="5 min of CPU oracle at 3.8e6 sites (event table, K assembly): DKMC_SLOW_TESTS=1; "
-                    "the run of round 4 is profiles/r04_test_tile20_current_off.log")
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
 def test_tile20_current_off_first_superstep():
     """A crossbar-SIZED stack with the current solve off, as every shipped crossbar parameter set runs (structures/crossbars/*/
     parameters.txt: solve_current = 0; configs[4] is 3.8e6 sites): the 2.5 nm cell tiled 20 x 20, 3 759 600 sites.  A superstep is then
     charge + potential (K-CG on 3.6e6 rows, on the CSR positions: above the size of the blocked form; pair sum over 3.4e4 charged sites) +
-    the event loop.  Against the oracle at full size: charges identical; the background potential meets the reference's stop test in the
-    TRUE scaled residual of the oracle's K (assembled from the same state; the oracle's own CG at this size would take minutes and prove
-    the same); the pair-sum potential on sampled sites equals the reference's all-pairs sum (gpu_solvers.h:259-265, no cut-off) to 1e-12;
-    and the oracle FED the GPU's potentials builds the same event table and executes the same (slot, i, j, type) sequence, same KMC time."""
-    import math
+    the event loop.  The oracle's side of this check -- minutes of CPU -- was run ONCE in the build container
+    (tests/golden/make_tile20_fixture.py -> tests/golden/tile20_current_off.npz: hashes, sampled values, the event log); here the HIP path is
+    compared with it at full size: the neighbour index, the substoichiometric structure, the charges and the published K pattern are
+    identical (sha256 of the arrays); the background potential at the DEFAULT tolerance meets the reference's stop test in the TRUE scaled residual of
+    the oracle's K (okmc_k_assemble on the published pattern, potential_solver_gpu.cu:397-593 restated); solved on to 1e-12 it lies within 1e-6 V
+    of the oracle's own converged CG solve on 4 096 sampled sites; the pair-sum potential on 48 sampled sites equals the reference's all-pairs sum (gpu_solvers.h:259-265, no
+    cut-off) to 1e-12; and the event loop, from the GPU's OWN (converged) potentials, executes the (slot, i, j, type) sequence the oracle executed from
+    its own, with the same KMC time and the same elements / charges afterwards."""
     import ctypes as C
     import scipy.sparse as sp
     import torch
     from oracle import oracle as oc
+    from test_gpu_parity import _d2h_i32
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "tile20_current_off.npz"))
     s, p, dev, sim, gb, host = _fresh(20, solve_current=False)
-    assert s.N == 3759600
-    o = oc.OracleKMC(s.element, s.x, s.y, s.z, p, neigh=dev.neigh_idx)
-    o.CB_edge[:] = gb.site_CB_edge.cpu().numpy()
-    dev.updateCharge(gb); o.update_charge()
-    assert np.array_equal(gb.site_charge.cpu().numpy(), o.charge)
+    assert s.N == 3759600 == int(fx["N"]) and dev.max_num_neighbors == int(fx["nn"]) and p.cg_tol == 1e-6 and float(fx["cg_tol"]) == 1e-12
+    assert _sha(dev.neigh_idx.astype(np.int32)) == str(fx["neigh_sha"])            # HIP cell-list neighbour index = the O(N log N) host build
+    assert _sha(dev.site_element.astype(np.int32)) == str(fx["element0_sha"])      # same substoichiometry stream
+    dev.updateCharge(gb)
+    charge = gb.site_charge.cpu().numpy()
+    assert _sha(charge.astype(np.int32)) == str(fx["charge_sha"]) and int((charge != 0).sum()) == int(fx["n_charged"])
     dev.updatePotential(gb, p, Vd, 0)
     torch.cuda.synchronize()
     st = host.get_stats()
     assert st["kcg_blocked"] == 0 and st["cg_rr_K"] <= p.cg_tol ** 2
     pb, pc = gb.site_potential_boundary.cpu().numpy(), gb.site_potential_charge.cpu().numpy()
-    # ---- K phi = rhs in the oracle's K (okmc_k_assemble: potential_solver_gpu.cu:397-593 restated) ----
-    if o._K is None:
-        o.initialize_sparsity()
-    nl, m, ((rp, ci), (lrp, lci), (rrp, rci)) = o._K
+    # ---- the K pattern initialize_sparsity published = the oracle's (hashes), and K phi = rhs in the oracle's K values on it ----
+    nl = p.num_atoms_first_layer
+    m = s.N - 2 * nl
+    c = gb.c
+    assert m == int(fx["K_rows"]) and int(c.Device_nnz) == int(fx["K_nnz"])
+    rp, ci = _d2h_i32(c.Device_row_ptr_d, m + 1), _d2h_i32(c.Device_col_indices_d, int(c.Device_nnz))
+    assert _sha(rp) == str(fx["K_rowptr_sha"]) and _sha(ci) == str(fx["K_col_sha"])
+    lrp, lci = _d2h_i32(c.contact_left_row_ptr, m + 1), _d2h_i32(c.contact_left_col_indices, max(int(c.contact_left_nnz), 1))[:int(c.contact_left_nnz)]
+    rrp, rci = _d2h_i32(c.contact_right_row_ptr, m + 1), _d2h_i32(c.contact_right_col_indices, max(int(c.contact_right_nnz), 1))[:int(c.contact_right_nnz)]
     data = np.zeros(len(ci)); rhs = np.zeros(m)
     _p = oc._p
-    oc.lib().okmc_k_assemble(o.N, nl, nl, _p(o.element), _p(o.charge), _p(o.metals), len(o.metals), C.c_double(p.high_G), C.c_double(p.low_G), 0,
+    metals = np.asarray(list(p.metals), dtype=np.int32)
+    el32 = np.ascontiguousarray(dev.site_element.astype(np.int32)); q32 = np.ascontiguousarray(charge.astype(np.int32))
+    oc.lib().okmc_k_assemble(s.N, nl, nl, _p(el32), _p(q32), _p(metals), len(metals), C.c_double(p.high_G), C.c_double(p.low_G), 0,
                              _p(rp), _p(ci), _p(lrp), _p(lci), _p(rrp), _p(rci), C.c_double(-Vd / 2), C.c_double(Vd / 2), _p(data), _p(rhs))
     K = sp.csr_matrix((data, ci, rp), shape=(m, m))
-    assert int(gb.c.Device_nnz) == len(ci) and m == s.N - 2 * nl
     sres = (K @ pb[nl:nl + m] - rhs) / np.sqrt(K.diagonal())
     assert np.linalg.norm(sres) <= 10 * p.cg_tol, np.linalg.norm(sres)
     assert (pb[:nl] == -Vd / 2).all() and (pb[-nl:] == Vd / 2).all()
-    # ---- pair sum on sampled sites against the all-pairs sum of the reference ----
-    q = o.charge; cs = np.flatnonzero(q != 0)
-    assert len(cs) > 3e4
-    rng = np.random.default_rng(11)
-    erfc = np.vectorize(math.erfc)
-    worst, scale = 0.0, np.abs(pc).max()
-    for i in rng.choice(s.N, 48, replace=False):
-        d = np.sqrt((s.x[cs] - s.x[i]) ** 2 + (s.y[cs] - s.y[i]) ** 2 + (s.z[cs] - s.z[i]) ** 2)
-        keep = cs != i
-        r = 1e-10 * d[keep]
-        v = (q[cs][keep] * erfc(r / (p.sigma * math.sqrt(2.0))) * p.k * 1.60217663e-19 / r).sum()
-        worst = max(worst, abs(v - pc[i]))
-    assert worst <= 1e-12 * scale, (worst, scale)
-    # ---- events: the oracle fed these potentials ----
-    o.pot_boundary[:] = pb; o.pot_charge[:] = pc
+    # ---- the same system CONVERGED (1e-12, warm-started from the solution above), as the oracle's own CG solve in the fixture is: the event
+    # sequence below is compared event by event, and at 1e-6 two correct solves differ by cond(K) x 1e-6 (2.7e-4 V measured here between the
+    # oracle's iterate and the GPU's), enough to select other events after a few hundred ----
+    p.cg_tol = 1e-12
+    dev.updatePotential(gb, p, Vd, 1)
+    torch.cuda.synchronize()
+    assert host.get_stats()["cg_rr_K"] <= 1e-24
+    pb2, pc2 = gb.site_potential_boundary.cpu().numpy(), gb.site_potential_charge.cpu().numpy()
+    assert np.array_equal(pc2, pc)                                               # same charges, same pair sum, bit for bit
+    assert np.abs(pb2 - pb).max() <= 1e-3                                         # the default-tolerance solution sits within cond(K) x 1e-6 of it
+    sres2 = (K @ pb2[nl:nl + m] - rhs) / np.sqrt(K.diagonal())
+    assert np.linalg.norm(sres2) <= 1e-9, np.linalg.norm(sres2)                   # (true residual: the recurrence's 1e-12 minus the rounding of K phi)
+    pb = pb2
+    ps = fx["pb_sites"]
+    dpb = np.abs(pb[ps] - fx["pb_values"]).max()
+    print("tile:20 max |phi_gpu - phi_oracle| on the sampled sites (both at 1e-12): %.2e V" % dpb)
+    assert dpb <= 1e-6, dpb
+    assert np.abs(pc[ps] - fx["pc_values"]).max() <= 1e-12 * float(fx["pc_absmax"])
+    # ---- pair sum on 48 sampled sites against the all-pairs sum of the reference ----
+    assert int(fx["n_charged"]) > 3e4
+    worst = np.abs(pc[fx["pair_sites"]] - fx["pair_values"]).max()
+    assert worst <= 1e-12 * float(fx["pc_absmax"]), (worst, float(fx["pc_absmax"]))
+    # ---- events from the GPU's own potentials: the sequence the oracle executed from its own ----
     _, dt = sim.executeKMCStep(gb, dev, want_log=True)
-    odt = o.execute_kmc_step()
-    assert len(sim.last_event_log) > 30
-    assert np.array_equal(sim.last_event_log, o.last_events["log"])
-    assert abs(dt - odt) <= 1e-12 * odt
+    assert len(sim.last_event_log) > 30 and float(fx["event_margin_min"]) > 1e-9
+    assert np.array_equal(sim.last_event_log, fx["event_log"])
+    assert abs(dt / float(fx["event_time"]) - 1) <= 1e-5
     gb.sync_GPUToHost(dev)
-    assert np.array_equal(dev.site_element, o.element) and np.array_equal(dev.site_charge, o.charge)
+    assert _sha(dev.site_element.astype(np.int32)) == str(fx["element1_sha"]) and _sha(dev.site_charge.astype(np.int32)) == str(fx["charge1_sha"])

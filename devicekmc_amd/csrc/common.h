@@ -119,6 +119,7 @@ struct Engine {
     int x_aux = 2;                 // auxiliary columns of the block-CG (dkmc_set_x_aux; xtb.hip): 0 hash set, 1 smooth set, 2 smooth at tolerances >= 1e-8
     int x_slab = 1;                // > 1 rank: distribute the STATE of the block-CG by row slabs (xtb_slab.inc; dkmc_set_x_slab); 0: all-gather variant (tile stream sharded only)
     int k_slab = 1;                // > 1 rank, system above the size of the blocked form: CG on K distributed by row slabs (kcg.hip; dkmc_set_k_slab); 0: replicated
+    int x_aux_warm = 0;            // 1: with the warm start of the current solve the hash auxiliary columns start from the previous solve's solutions too (dkmc_set_x_aux_warm; off: no gain beyond 1e4 rows, profiles/r05_ab_aux_warm.json)
     int x_block = 16;              // block-CG width of the current solve on the tiled X (dkmc_set_x_block; xtb.hip): 16 by default, 1 = the reference's single-vector loop (its iterate sequence)
     int x_format = 1;              // 1: tiled X (xt.hip, default); 0: CSR X as the reference stores it (current.hip + cg.hip)
     int x_iter_hint = 0;           // iteration count of the previous CG solve of X (sizes the first launch batch)
@@ -159,7 +160,7 @@ enum {
     S_XT_T_NITEMW, S_XT_T_ITEMS, S_XT_T_SPLIT, S_XT_T_COLPART, S_XT_T_MISC,
     S_XTB_PANELS, S_XTB_QS, S_XTB_ROWPART, S_XTB_COLPART, S_XTB_GRAM, S_XTB_SMALL, S_XTB_XI,
     S_XTB_SLAB_BOX, S_XTB_SLAB_TAB, S_XTB_SLAB_OWNER, S_XTB_SLAB_LISTS, S_XTB_SLAB_SDST, S_XTB_SLAB_FLAG, S_XTB_SLAB_RLISTS, S_XTB_SLAB_GX, S_XTB_SLAB_S1, S_XTB_SLAB_S3, S_XTB_SLAB_R3,
-    S_XTB_EMU_Y, S_XTB_EMU_CTRL,
+    S_XTB_EMU_Y, S_XTB_EMU_CTRL, S_XTB_YPANEL,
     S_KS_TAB, S_KS_OWNER, S_KS_LISTS, S_KS_FLAG, S_KS_BOX, S_KS_RLISTS, S_KS_XA, S_KS_XB, S_KS_SEND, S_KS_RECV, S_KS_YBUF, S_KS_EMU,
     S_NSLOTS
 };

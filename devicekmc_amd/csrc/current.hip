@@ -16,7 +16,7 @@
 
 // tiled X (xt.hip)
 int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEntry *S, const int *aneigh, const int *ancnt, const int *aflag,
-                          const int *srank, const int *atom_site, double *rhs, double *y, int *iters_out, double *rr_out);
+                          const int *srank, const int *atom_site, double *rhs, double *y, int *iters_out, double *rr_out, double *yaux, int yaux_valid);
 int xt_power(dkmc_gpubuf *buf, const XParams &P, const int *aflag, const int *atom_site, const double *m, double Vd, double alpha);
 const xrp_t *xt_xs_rp(); const int *xt_xs_col(); const double *xt_xs_val(); bool xt_valid();
 int xt_export_csr(int *rows_out, long long *nnz_out, int *h_rp, int *h_col, double *h_data);
@@ -121,6 +121,7 @@ struct TCacheState {
 // its site_x array), so that several devices in one process (e.g. one per crossbar cell) do not share or thrash it.  Up to 8
 // buffers, least recently used one evicted.  The engine's scratch buffers are shared: they carry nothing across calls.
 struct XBufState { const void *key = nullptr; TCacheState tc; double *warm = nullptr; int warm_n = 0; unsigned long long stamp = 0;
+                   double *warm_aux = nullptr; int warm_aux_n = 0, warm_aux_valid = 0;      // [warm_aux_n][16]: unscaled solutions of the block-CG's auxiliary columns (dkmc_set_x_aux_warm)
                    double lat[3] = {0, 0, 0}; bool lat_ok = false; };       // lattice: constant per GPUBuffers, fetched once
 static XBufState g_states[8];
 static XBufState *g_cur = &g_states[0];
@@ -144,6 +145,7 @@ void xstate_reset(const void *key)
     (void)hipStreamSynchronize(eng().stream);
     tc_release();
     if (st->warm) (void)hipFree(st->warm);
+    if (st->warm_aux) (void)hipFree(st->warm_aux);
     *st = XBufState();
     g_cur = save;
 }
@@ -479,8 +481,21 @@ static int update_power_body(dkmc_gpubuf *buf, int n_src, int n_gnd, int nlc, do
         if (e.current_warm_start == 1) {
             if (g_warm && g_warm_n == Nsub) HIPCHK(hipMemcpyAsync(m, g_warm, (size_t)Nsub * 8, hipMemcpyDeviceToDevice, st));
         }
-        rc = xt_assemble_and_solve(buf, P, ns, S, aneigh, ancnt, aflag, srank, atom_site, rhs, m, &e.stats.cg_iters_X, &e.stats.cg_rr_X);
+        // the auxiliary columns of the block-CG start from the previous solve's solutions too (kept per GPUBuffers like the start vector itself)
+        double *yaux = nullptr; int yaux_valid = 0;
+        if (e.current_warm_start == 1 && e.x_aux_warm && e.x_block > 1) {
+            if (g_cur->warm_aux_n != Nsub) {
+                if (g_cur->warm_aux) (void)hipFree(g_cur->warm_aux);
+                g_cur->warm_aux = nullptr; g_cur->warm_aux_n = 0; g_cur->warm_aux_valid = 0;
+                HIPCHK(hipMalloc((void **)&g_cur->warm_aux, (size_t)Nsub * 16 * 8));
+                g_cur->warm_aux_n = Nsub;
+            }
+            yaux = g_cur->warm_aux; yaux_valid = g_cur->warm_aux_valid;
+        }
+        if (yaux) g_cur->warm_aux_valid = 0;                    // (a solve that fails leaves nothing to start from)
+        rc = xt_assemble_and_solve(buf, P, ns, S, aneigh, ancnt, aflag, srank, atom_site, rhs, m, &e.stats.cg_iters_X, &e.stats.cg_rr_X, yaux, yaux_valid);
         if (rc) return rc;
+        if (yaux && e.stats.xb_width > 1 && !e.stats.xb_fallback) g_cur->warm_aux_valid = 1;
         rp = xt_xs_rp(); col = xt_xs_col(); data = xt_xs_val();
     } else {
         // ---- 3. sparsity: counts -> row_ptr -> columns ----
@@ -575,6 +590,37 @@ extern "C" int dkmc_set_current_warm_vector(const dkmc_gpubuf *buf, const double
     HIPCHK(hipStreamSynchronize(e.stream));
     if (g_warm_n != n) { if (g_warm) (void)hipFree(g_warm); g_warm = nullptr; g_warm_n = 0; if (n > 0) { HIPCHK(hipMalloc((void **)&g_warm, (size_t)n * 8)); g_warm_n = n; } }
     if (n > 0) HIPCHK(hipMemcpy(g_warm, h_in, (size_t)n * 8, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// ... and the solutions of the block-CG's auxiliary columns the next solve starts from (dkmc_set_x_aux_warm): [rows][16] doubles, n = rows x 16
+// (0: none held / not valid)
+extern "C" int dkmc_get_current_warm_aux(const dkmc_gpubuf *buf, double *h_out, long long capacity, long long *n_out)
+{
+    Engine &e = eng();
+    XBufState *st = buf ? xstate_find(buf->site_x) : nullptr;
+    const long long n = (st && st->warm_aux && st->warm_aux_valid) ? (long long)st->warm_aux_n * 16 : 0;
+    if (n_out) *n_out = n;
+    if (h_out && n > 0) {
+        HIPCHK(hipStreamSynchronize(e.stream));
+        HIPCHK(hipMemcpy(h_out, st->warm_aux, (size_t)(n < capacity ? n : capacity) * 8, hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+extern "C" int dkmc_set_current_warm_aux(const dkmc_gpubuf *buf, const double *h_in, long long n)
+{
+    Engine &e = eng();
+    if (!buf || n < 0 || (n % 16) != 0 || (n > 0 && !h_in)) return dkmc_fail(14, "set_current_warm_aux: bad arguments", __FILE__, __LINE__);
+    xstate_select(buf->site_x);
+    HIPCHK(hipStreamSynchronize(e.stream));
+    const int rows = (int)(n / 16);
+    if (g_cur->warm_aux_n != rows) {
+        if (g_cur->warm_aux) (void)hipFree(g_cur->warm_aux);
+        g_cur->warm_aux = nullptr; g_cur->warm_aux_n = 0;
+        if (rows > 0) { HIPCHK(hipMalloc((void **)&g_cur->warm_aux, (size_t)n * 8)); g_cur->warm_aux_n = rows; }
+    }
+    g_cur->warm_aux_valid = 0;
+    if (rows > 0) { HIPCHK(hipMemcpy(g_cur->warm_aux, h_in, (size_t)n * 8, hipMemcpyHostToDevice)); g_cur->warm_aux_valid = 1; }
     return 0;
 }
 

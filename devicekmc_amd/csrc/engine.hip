@@ -49,6 +49,8 @@ void dkmc_set_tcache_budget(long long bytes) { eng().tcache_budget = bytes; }
 void dkmc_set_pair_cutoff(double x_cut) { eng().pair_cut = x_cut > 0.0 ? x_cut : 0.0; }
 void dkmc_set_k_slab(int on) { eng().k_slab = on ? 1 : 0; }
 int dkmc_get_k_slab(void) { return eng().k_slab; }
+void dkmc_set_x_aux_warm(int on) { eng().x_aux_warm = on ? 1 : 0; }
+int dkmc_get_x_aux_warm(void) { return eng().x_aux_warm; }
 void dkmc_set_x_slab(int on) { eng().x_slab = on ? 1 : 0; }
 int dkmc_get_x_slab(void) { return eng().x_slab; }
 void dkmc_set_x_block(int s) { eng().x_block = s < 1 ? 1 : (s > 16 ? 16 : s); }

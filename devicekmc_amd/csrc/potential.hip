@@ -2,6 +2,7 @@
 // screened-Coulomb pair sum.  Replaces potential_solver_gpu.cu (live parts) and the K-pattern
 // builders of iterative_solvers_gpu.cu.
 #include "common.h"
+#include <stdint.h>
 #include <algorithm>
 #include <vector>
 
@@ -368,24 +369,28 @@ __global__ __launch_bounds__(PW_NT) void k_pairwise(int N, const double *__restr
 }
 
 // ---- pair sum over a cell list of the charged sites ---------------------------------------------------------------------------
-// With the screening cut-off on, a site only needs the charged sites within rc = x_cut sigma sqrt 2 (32 A).  The charged sites (all
-// of them lie in the oxide: one cell in x) are binned into (y, z) columns of edge >= rc; a site sums over the 3 x 3 columns around its
-// own.  Workgroups own 64 sites OF ONE COLUMN (sites grouped by column through a permutation; their order inside a column does not
-// matter, every site is summed independently), so the four waves still sweep one LDS tile with broadcast reads, now over ~9 / (ny nz)
-// of the list.  Determinism: the charged sites of a column keep their ascending site order (a stable, atomic-free partition: one
-// workgroup per column walks the compacted list), columns are visited in a fixed order, the four partial sums are combined as before.
-// 9.4e5 sites (8 x 8 columns): 1.8 % of all pairs are inside the cut-off; the all-list kernel tests 7.9e9 distances, this one ~1.1e9.
-// Everything that depends on the lattice is decided on the device (no host read of the box per call): the kernels of the path not taken
-// find `use` cleared and return.
+// With the screening cut-off on, a site only needs the charged sites within rc = x_cut sigma sqrt 2 (32 A).  The charged sites are binned
+// into (y, z) columns of edge >= rc / 2 -- a site sums over the (2 r + 1)^2 columns around its own, r = ceil(rc / edge) <= 2: 6.25 rc^2 of
+// lateral area instead of the 9 rc^2 of round 3's columns of edge rc -- and, inside a column, into x bins of ~rc / 4: the sites of a column are
+// grouped by x bin too, so the 64 sites of a workgroup span one or two bins and only the charged sites whose bin lies within rc of that
+// span are swept (a contact site 30 A from the oxide reads almost nothing; x was unbinned before).  Measured at 3.76e6 sites: 7.5 -> 3.x
+// distance tests per evaluated pair.  Workgroups own 64 sites OF ONE COLUMN (sites grouped by column and x bin through a permutation; their
+// order inside a bin does not matter, every site is summed independently); the four waves sweep LDS tiles of the gathered segments with
+// broadcast reads.  Determinism: the charged sites of a column are kept in (x bin, ascending site) order -- a stable, atomic-free partition by
+// column (one workgroup per column walks the compacted list) and a stable ballot sort by x bin inside it --, columns and bins are visited in
+// a fixed order, the four partial sums are combined as before.  Everything that depends on the lattice is decided on the device (no host
+// read of the box per call): the kernels of the path not taken find `use` cleared and return.
 #define PW_MAXDIM 32
 #define PW_MAXCELL (PW_MAXDIM * PW_MAXDIM)
+#define PW_MAXX 16                  // x bins per column
 #define PW_MIN_CHARGED 512
-struct PwGrid { int use, ny, nz, pbc; double hy, hz, ly, lz; int nchunks, rebuild; };
+struct PwGrid { int use, ny, nz, pbc; double hy, hz, ly, lz; int nchunks, rebuild; int ry, rz, nx, rx; double hx, x0; };
 __device__ __forceinline__ int pw_axis_cell(double v, double L, double h, int n, int pbc)
 {
     if (pbc) { double f = v / L; f -= floor(f); return min((int)(f * n), n - 1); }
     return min(max((int)floor(v / h), 0), n - 1);              // clamping is monotone: points within h of each other stay in adjacent cells
 }
+__device__ __forceinline__ int pw_xbin(double x, const PwGrid &G) { return min(max((int)floor((x - G.x0) / G.hx), 0), G.nx - 1); }      // (x is never periodic)
 // The grid of this call.  The grouping of the SITES by column depends only on positions, box and cut-off, which do not change between
 // calls: it is rebuilt when the host sees other position arrays / N / pbc / cut-off (host_rebuild) or when the box or sigma read here
 // differ from those of the cached grouping; otherwise only the charged sites are binned per call.
@@ -399,11 +404,17 @@ __global__ void k_pw_grid(const double *__restrict__ lattice, const double *__re
         const PwGrid old = *g;
         PwGrid G{};
         G.pbc = pbc; G.ly = lattice[1]; G.lz = lattice[2];
-        G.ny = xcut > 0.0 ? max(1, min(PW_MAXDIM, (int)floor(G.ly / rc))) : 1;
-        G.nz = xcut > 0.0 ? max(1, min(PW_MAXDIM, (int)floor(G.lz / rc))) : 1;
+        G.ny = xcut > 0.0 ? max(1, min(PW_MAXDIM, (int)floor(2.0 * G.ly / rc))) : 1;
+        G.nz = xcut > 0.0 ? max(1, min(PW_MAXDIM, (int)floor(2.0 * G.lz / rc))) : 1;
         G.hy = G.ly / G.ny; G.hz = G.lz / G.nz;
-        G.use = xcut > 0.0 && (G.ny >= 3 || G.nz >= 3) && *ncharged >= PW_MIN_CHARGED;
-        G.rebuild = host_rebuild || old.ny != G.ny || old.nz != G.nz || old.pbc != G.pbc || old.ly != G.ly || old.lz != G.lz;
+        G.ry = xcut > 0.0 ? (int)ceil(rc / G.hy) : 0; G.rz = xcut > 0.0 ? (int)ceil(rc / G.hz) : 0;       // columns to either side (1 or 2; more only on a box narrower than rc / 2)
+        // x: the device spans [0, lattice[0]]; bins of ~rc / 4 (clamped: a site outside the box lands in the first / last bin, whose reach then
+        // only grows -- the cut below is conservative by construction: it drops a bin only if EVERY point of it is farther than rc from the span)
+        G.x0 = 0.0;
+        G.nx = xcut > 0.0 ? max(1, min(PW_MAXX, (int)floor(4.0 * lattice[0] / rc))) : 1;
+        G.hx = lattice[0] / G.nx; G.rx = 0;
+        G.use = xcut > 0.0 && (G.ny >= 2 * G.ry + 1 || G.nz >= 2 * G.rz + 1) && min(2 * G.ry + 1, G.ny) * min(2 * G.rz + 1, G.nz) <= 32 && *ncharged >= PW_MIN_CHARGED;
+        G.rebuild = host_rebuild || old.ny != G.ny || old.nz != G.nz || old.pbc != G.pbc || old.ly != G.ly || old.lz != G.lz || old.nx != G.nx || old.hx != G.hx;
         G.nchunks = G.rebuild ? 0 : old.nchunks;
         *g = G;
         rebuild_s = G.rebuild;
@@ -471,6 +482,69 @@ __global__ __launch_bounds__(256) void k_pw_perm(int N, const PwGrid *__restrict
     __syncthreads();
     if (c >= 0) perm[base[c] + r] = i;
 }
+// ... then by x bin inside its column (rebuild only): workgroup = column, a counting sort of the column's part of the permutation (any order
+// inside a bin).  perm -> perm2
+__global__ __launch_bounds__(256) void k_pw_perm_x(const PwGrid *__restrict__ g, const double *__restrict__ x, const int *__restrict__ tstart,
+                                                   const int *__restrict__ perm, int *__restrict__ perm2)
+{
+    if (!g->rebuild) return;
+    const PwGrid G = *g;
+    const int c = blockIdx.x;
+    if (c >= G.ny * G.nz) return;
+    __shared__ int cnt[PW_MAXX], off[PW_MAXX];
+    if (threadIdx.x < PW_MAXX) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int t0 = tstart[c], t1 = tstart[c + 1];
+    for (int t = t0 + threadIdx.x; t < t1; t += 256) atomicAdd(&cnt[pw_xbin(x[perm[t]], G)], 1);
+    __syncthreads();
+    if (threadIdx.x == 0) { int a = 0; for (int b = 0; b < PW_MAXX; ++b) { off[b] = a; a += cnt[b]; } }
+    __syncthreads();
+    for (int t = t0 + threadIdx.x; t < t1; t += 256) { const int i = perm[t]; perm2[t0 + atomicAdd(&off[pw_xbin(x[i], G)], 1)] = i; }
+}
+// ... and every (column, x bin) segment into ascending site order (rebuild only): which site sits in which chunk of 64 decides the chunk's x span,
+// hence which charged sites it sweeps and how its sums are grouped -- the two groupings above use atomics, so without this pass a result would
+// be reproducible only to rounding.  Workgroup = column; segments of up to 8 192 sites are sorted in LDS (bitonic); a larger one (> 40 x the
+// sites such a cell can hold) is sorted in pieces.
+#define PW_SORTCAP 8192
+__global__ __launch_bounds__(256) void k_pw_perm_sort(const PwGrid *__restrict__ g, const double *__restrict__ x, const int *__restrict__ tstart, int *__restrict__ perm2)
+{
+    if (!g->rebuild) return;
+    const PwGrid G = *g;
+    const int c = blockIdx.x;
+    if (c >= G.ny * G.nz) return;
+    __shared__ int key[PW_SORTCAP];
+    __shared__ int cnt[PW_MAXX];
+    if (threadIdx.x < PW_MAXX) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int t0 = tstart[c], t1 = tstart[c + 1];
+    for (int t = t0 + threadIdx.x; t < t1; t += 256) atomicAdd(&cnt[pw_xbin(x[perm2[t]], G)], 1);
+    __syncthreads();
+    int s0 = t0;
+    for (int b = 0; b < G.nx; ++b) {
+        const int nb = cnt[b];
+        for (int p0 = 0; p0 < nb; p0 += PW_SORTCAP) {
+            const int n = min(PW_SORTCAP, nb - p0);
+            int np2 = 1; while (np2 < n) np2 <<= 1;
+            for (int i = threadIdx.x; i < np2; i += 256) key[i] = i < n ? perm2[s0 + p0 + i] : 0x7fffffff;
+            __syncthreads();
+            for (int k = 2; k <= np2; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = threadIdx.x; i < np2; i += 256) {
+                        const int l = i ^ j;
+                        if (l > i) {
+                            const int a = key[i], bb = key[l];
+                            const bool up = (i & k) == 0;
+                            if ((a > bb) == up) { key[i] = bb; key[l] = a; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (int i = threadIdx.x; i < n; i += 256) perm2[s0 + p0 + i] = key[i];
+            __syncthreads();
+        }
+        s0 += nb;
+    }
+}
 // charged sites grouped by column, ascending site order kept: workgroup = column, a stable partition of the compacted list
 __global__ __launch_bounds__(256) void k_pw_partition(const PwGrid *__restrict__ g, const ChargedSite *__restrict__ list, const int *__restrict__ ncharged,
                                                       const int *__restrict__ ccell, const int *__restrict__ cstart, ChargedSite *__restrict__ out)
@@ -497,11 +571,37 @@ __global__ __launch_bounds__(256) void k_pw_partition(const PwGrid *__restrict__
         __syncthreads();
     }
 }
-// the sum itself: block -> (column, chunk of 64 of its sites); columns cy-1..cy+1 x cz-1..cz+1 in a fixed order
+// ... then by x bin inside its column, site order kept inside a bin: one WAVE per column (a column holds tens of charged sites), bin by bin, the
+// members of a bin extracted with ballots in list order.  in -> out; cxoff[c * (PW_MAXX + 1) + b] = first entry of bin b relative to cstart[c]
+__global__ __launch_bounds__(64) void k_pw_partition_x(const PwGrid *__restrict__ g, const int *__restrict__ cstart, const ChargedSite *__restrict__ in,
+                                                       ChargedSite *__restrict__ out, int *__restrict__ cxoff)
+{
+    if (!g->use) return;
+    const PwGrid G = *g;
+    const int c = blockIdx.x, lane = threadIdx.x;
+    if (c >= G.ny * G.nz) return;
+    const int s0 = cstart[c], s1 = cstart[c + 1];
+    int pos = 0;
+    for (int b = 0; b < G.nx; ++b) {
+        if (lane == 0) cxoff[c * (PW_MAXX + 1) + b] = pos;
+        for (int i0 = s0; i0 < s1; i0 += 64) {
+            const int i = i0 + lane;
+            const bool mine = i < s1 && pw_xbin(in[i].x, G) == b;
+            const unsigned long long bal = __ballot(mine);
+            if (mine) out[s0 + pos + __popcll(bal & ((1ull << lane) - 1ull))] = in[i];
+            pos += __popcll(bal);
+        }
+    }
+    if (lane == 0) for (int b = G.nx; b <= PW_MAXX; ++b) cxoff[c * (PW_MAXX + 1) + b] = pos;
+}
+// the sum itself: block -> (column, chunk of 64 of its sites, x-ordered); the columns within reach in a fixed order, of each the x bins within
+// rc of the chunk's span; the segments are gathered into LDS tiles of 256 entries
+#define PW_MAXSEG 32
 __global__ __launch_bounds__(PW_NT) void k_pairwise_cells(int N, const double *__restrict__ x, const double *__restrict__ y, const double *__restrict__ z,
                                                           int pbc, const double *__restrict__ sigma_p, const double *__restrict__ k_p,
                                                           const PwGrid *__restrict__ g, const int *__restrict__ tstart, const int *__restrict__ cstart,
                                                           const int *__restrict__ chunk0, const int *__restrict__ perm, const ChargedSite *__restrict__ clist,
+                                                          const int *__restrict__ cxoff,
                                                           double *__restrict__ out, unsigned long long *__restrict__ nevaluated, int i_lo, int i_hi, double xcut)
 {
     if (!g->use) return;
@@ -509,51 +609,80 @@ __global__ __launch_bounds__(PW_NT) void k_pairwise_cells(int N, const double *_
     if ((int)blockIdx.x >= G.nchunks) return;
     __shared__ ChargedSite tile[PW_NT];
     __shared__ double partial[PW_NT / 64][PW_SITES];
+    __shared__ int seg_lo[PW_MAXSEG], seg_pre[PW_MAXSEG + 1], nseg_s;
+    __shared__ double xspan[2];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int ncell = G.ny * G.nz;
     int lo = 0, hi = ncell;                                           // column of this chunk: last c with chunk0[c] <= blockIdx.x
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (chunk0[mid] <= (int)blockIdx.x) lo = mid; else hi = mid; }
     const int c = lo, cy = c % G.ny, cz = c / G.ny;
     const int t = tstart[c] + ((int)blockIdx.x - chunk0[c]) * PW_SITES + lane;
-    int i = t < tstart[c + 1] ? perm[t] : -1;
+    const int isite = t < tstart[c + 1] ? perm[t] : -1;                // (the span below is over ALL sites of the chunk, also those of other ranks' slabs)
+    int i = isite;
     if (i >= 0 && (i < i_lo || i >= i_hi)) i = -1;                     // sharded run: this rank's slab of sites only
     const double sigma = *sigma_p, kk = *k_p;
     const double rc = xcut * sigma * sqrt(2.0) * 1e10, cut2 = rc * rc;
-    const double xi = i >= 0 ? x[i] : 0.0, yi = i >= 0 ? y[i] : 0.0, zi = i >= 0 ? z[i] : 0.0;
+    const double xi = isite >= 0 ? x[isite] : 0.0, yi = i >= 0 ? y[i] : 0.0, zi = i >= 0 ? z[i] : 0.0;
+    // x span of the chunk's sites (every wave holds the same 64 sites)
+    if (w == 0) {
+        double xmn = isite >= 0 ? xi : 1.0e300, xmx = isite >= 0 ? xi : -1.0e300;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { xmn = fmin(xmn, __shfl_xor(xmn, o, 64)); xmx = fmax(xmx, __shfl_xor(xmx, o, 64)); }
+        if (lane == 0) { xspan[0] = xmn; xspan[1] = xmx; }
+    }
+    __syncthreads();
+    // segments: thread u < (2 ry + 1)(2 rz + 1) takes neighbour column u.  A bin b is needed unless all of it lies farther than rc from the span:
+    // bins are [x0 + b hx, x0 + (b + 1) hx), the first / last one open-ended (out-of-box sites are clamped into them)
+    if (threadIdx.x == 0) nseg_s = 0;
+    const int wy = min(2 * G.ry + 1, G.ny), wz = min(2 * G.rz + 1, G.nz);      // distinct columns along an axis (a narrow / periodic axis: all of them, once)
+    const int nnb = wy * wz;
+    int my_lo = 0, my_n = 0;
+    if ((int)threadIdx.x < nnb && nnb <= PW_MAXSEG) {
+        const int uy = threadIdx.x % wy, uz = threadIdx.x / wy;
+        int ny_ = wy == G.ny ? uy : cy - G.ry + uy, nz_ = wz == G.nz ? uz : cz - G.rz + uz;
+        bool ok = true;
+        if (wy != G.ny) { if (pbc) ny_ = (ny_ % G.ny + G.ny) % G.ny; else if (ny_ < 0 || ny_ >= G.ny) ok = false; }
+        if (wz != G.nz) { if (pbc) nz_ = (nz_ % G.nz + G.nz) % G.nz; else if (nz_ < 0 || nz_ >= G.nz) ok = false; }
+        if (ok) {
+            const int cc = nz_ * G.ny + ny_;
+            int blo = (int)floor((xspan[0] - rc - G.x0) / G.hx), bhi = (int)floor((xspan[1] + rc - G.x0) / G.hx);
+            blo = min(max(blo, 0), G.nx - 1); bhi = min(max(bhi, 0), G.nx - 1);
+            if (xspan[0] <= xspan[1]) { my_lo = cstart[cc] + cxoff[cc * (PW_MAXX + 1) + blo]; my_n = cstart[cc] + cxoff[cc * (PW_MAXX + 1) + bhi + 1] - my_lo; }
+        }
+    }
+    __syncthreads();
+    // fixed order: thread 0 walks the neighbour slots (wave 0 holds them all: nnb <= 32)
+    if (w == 0) {
+        int pre = 0;
+        for (int u = 0; u < nnb && nnb <= PW_MAXSEG; ++u) {
+            const int l_ = __shfl(my_lo, u, 64), n_ = __shfl(my_n, u, 64);
+            if (lane == 0 && n_ > 0) { const int k_ = nseg_s; seg_lo[k_] = l_; seg_pre[k_] = pre; nseg_s = k_ + 1; }
+            pre += n_ > 0 ? n_ : 0;
+        }
+        if (lane == 0) seg_pre[nseg_s] = pre;
+    }
+    __syncthreads();
+    const int nseg = nseg_s, total = seg_pre[nseg];
     double v0 = 0.0, v1 = 0.0;
     int neval = 0, ntest = 0;
-    // offsets along an axis with n columns: all three when n >= 3; with two columns -1 and +1 are the same column under pbc
-    const int dy0 = G.ny >= 2 ? ((G.ny == 2 && pbc) ? 0 : -1) : 0, dy1 = G.ny >= 2 ? 1 : 0;
-    const int dz0 = G.nz >= 2 ? ((G.nz == 2 && pbc) ? 0 : -1) : 0, dz1 = G.nz >= 2 ? 1 : 0;
-    for (int dz = dz0; dz <= dz1; ++dz) {
-        int nz_ = cz + dz;
-        if (pbc) nz_ = (nz_ + G.nz) % G.nz; else if (nz_ < 0 || nz_ >= G.nz) continue;
-        // the columns cy + dy0 .. cy + dy1 of one z row are neighbours in the list (cell = cz ny + cy): one segment unless pbc wraps them
-        int seg_lo[3], seg_hi[3], nseg = 0;
-        for (int dy = dy0; dy <= dy1; ++dy) {
-            int ny_ = cy + dy;
-            if (pbc) ny_ = (ny_ + G.ny) % G.ny; else if (ny_ < 0 || ny_ >= G.ny) continue;
-            const int cc = nz_ * G.ny + ny_;
-            const int s0 = cstart[cc], s1 = cstart[cc + 1];
-            if (nseg > 0 && seg_hi[nseg - 1] == s0) seg_hi[nseg - 1] = s1; else { seg_lo[nseg] = s0; seg_hi[nseg] = s1; ++nseg; }
+    for (int base = 0; base < total; base += PW_NT) {
+        const int n = min(PW_NT, total - base);
+        __syncthreads();
+        if ((int)threadIdx.x < n) {
+            const int vp = base + threadIdx.x;
+            int k_ = 0;
+            while (k_ + 1 < nseg && seg_pre[k_ + 1] <= vp) ++k_;
+            tile[threadIdx.x] = clist[seg_lo[k_] + (vp - seg_pre[k_])];
         }
-        for (int sg = 0; sg < nseg; ++sg) {
-            const int s0 = seg_lo[sg], s1 = seg_hi[sg];
-            for (int base = s0; base < s1; base += PW_NT) {
-                const int n = min(PW_NT, s1 - base);
-                __syncthreads();
-                if ((int)threadIdx.x < n) tile[threadIdx.x] = clist[base + threadIdx.x];
-                __syncthreads();
-                if (i >= 0) {
-                    int q = w;
-                    ntest += (n - w + 3) / 4;
-                    for (; q + 4 < n; q += 8) {
-                        v0 += pw_term(xi, yi, zi, tile[q], i, G.ly, G.lz, pbc, sigma, kk, cut2, neval);
-                        v1 += pw_term(xi, yi, zi, tile[q + 4], i, G.ly, G.lz, pbc, sigma, kk, cut2, neval);
-                    }
-                    if (q < n) v0 += pw_term(xi, yi, zi, tile[q], i, G.ly, G.lz, pbc, sigma, kk, cut2, neval);
-                }
+        __syncthreads();
+        if (i >= 0) {
+            int q = w;
+            ntest += (n - w + 3) / 4;
+            for (; q + 4 < n; q += 8) {
+                v0 += pw_term(xi, yi, zi, tile[q], i, G.ly, G.lz, pbc, sigma, kk, cut2, neval);
+                v1 += pw_term(xi, yi, zi, tile[q + 4], i, G.ly, G.lz, pbc, sigma, kk, cut2, neval);
             }
+            if (q < n) v0 += pw_term(xi, yi, zi, tile[q], i, G.ly, G.lz, pbc, sigma, kk, cut2, neval);
         }
     }
     partial[w][lane] = v0 + v1;
@@ -592,13 +721,16 @@ extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, 
     HIPCHK(hipMemsetAsync(d_ne, 0, 16, st));
     // cell list over the charged sites (taken on the device when the cut-off is on, the box has >= 3 columns along y or z and
     // enough sites are charged; otherwise these launches return at once and k_pairwise sums over the whole list)
-    int *cells = (int *)scratch(S_PW_CELLS, (size_t)(8 * (PW_MAXCELL + 1)) * 4 + sizeof(PwGrid));
-    int *pperm = (int *)scratch(S_PW_PERM, (size_t)N * 4 * 3);
-    ChargedSite *clist2 = (ChargedSite *)scratch(S_PW_LIST2, (size_t)N * sizeof(ChargedSite));
+    int *cells = (int *)scratch(S_PW_CELLS, (size_t)(8 * (PW_MAXCELL + 1) + PW_MAXCELL * (PW_MAXX + 1)) * 4 + sizeof(PwGrid) + 16);
+    int *pperm = (int *)scratch(S_PW_PERM, (size_t)N * 4 * 4);
+    ChargedSite *clist2 = (ChargedSite *)scratch(S_PW_LIST2, (size_t)N * sizeof(ChargedSite) * 2);
     if (!cells || !pperm || !clist2) return e.err_code;
+    ChargedSite *clist3 = clist2 + N;                                  // the charged list grouped by column, then by x bin inside a column
+    int *cxoff = cells + 8 * (PW_MAXCELL + 1);                         // [column][PW_MAXX + 1]: first entry of every x bin, relative to the column's start
+    int *pperm2 = pperm + 3 * (size_t)N;                               // the sites grouped by column, x-ordered inside a column (what the sum kernel walks)
     int *tcount = cells, *ccount = cells + (PW_MAXCELL + 1), *cursor = cells + 2 * (PW_MAXCELL + 1);
     int *tstart = cells + 4 * (PW_MAXCELL + 1), *cstart = cells + 5 * (PW_MAXCELL + 1), *chunk0 = cells + 6 * (PW_MAXCELL + 1);
-    PwGrid *grid = (PwGrid *)(cells + 8 * (PW_MAXCELL + 1));
+    PwGrid *grid = (PwGrid *)(((uintptr_t)(cells + 8 * (PW_MAXCELL + 1) + PW_MAXCELL * (PW_MAXX + 1)) + 15) & ~(uintptr_t)15);
     int *site_cell = pperm + N, *ccell = pperm + 2 * (size_t)N;
     // the grouping of the sites by column is kept between calls (positions, box and cut-off do not change); what the host can see of its key:
     // `possible`: the box has >= 3 columns along y or z, read back ONCE per key (one 64-byte copy); a box without (85 k sites: 2 x 2) skips
@@ -614,7 +746,8 @@ extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, 
         PwGrid hg{};
         HIPCHK(hipMemcpyAsync(&hg, grid, sizeof(PwGrid), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        key.possible = e.pair_cut > 0.0 && (hg.ny >= 3 || hg.nz >= 3); key.ncell = std::max(1, hg.ny * hg.nz);
+        key.possible = e.pair_cut > 0.0 && (hg.ny >= 2 * hg.ry + 1 || hg.nz >= 2 * hg.rz + 1) && std::min(2 * hg.ry + 1, hg.ny) * std::min(2 * hg.rz + 1, hg.nz) <= 32;
+        key.ncell = std::max(1, hg.ny * hg.nz);
         if (!key.possible) HIPCHK(hipMemsetAsync(grid, 0, sizeof(PwGrid), st));          // use = 0 for good: k_pairwise does every call
     }
     // launch sizes do not rely on the host's copy of the column count (the device rebuilds its grid when the box changes): the kernels stop
@@ -624,8 +757,11 @@ extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, 
         hipLaunchKernelGGL(k_pw_bin, dim3(blocks), dim3(256), 0, st, N, y, z, (const PwGrid *)grid, (const ChargedSite *)list, (const int *)cnt, site_cell, ccell, tcount, ccount);
         hipLaunchKernelGGL(k_pw_offsets, dim3(1), dim3(PW_MAXCELL), 0, st, grid, (const int *)tcount, (const int *)ccount, tstart, cstart, chunk0);
         hipLaunchKernelGGL(k_pw_perm, dim3(blocks), dim3(256), 0, st, N, (const PwGrid *)grid, (const int *)site_cell, (const int *)tstart, cursor, pperm);
+        hipLaunchKernelGGL(k_pw_perm_x, dim3(PW_MAXCELL), dim3(256), 0, st, (const PwGrid *)grid, x, (const int *)tstart, (const int *)pperm, pperm2);
+        hipLaunchKernelGGL(k_pw_perm_sort, dim3(PW_MAXCELL), dim3(256), 0, st, (const PwGrid *)grid, x, (const int *)tstart, pperm2);
         hipLaunchKernelGGL(k_pw_partition, dim3(PW_MAXCELL), dim3(256), 0, st, (const PwGrid *)grid, (const ChargedSite *)list, (const int *)cnt, (const int *)ccell,
                            (const int *)cstart, clist2);
+        hipLaunchKernelGGL(k_pw_partition_x, dim3(PW_MAXCELL), dim3(64), 0, st, (const PwGrid *)grid, (const int *)cstart, (const ChargedSite *)clist2, clist3, cxoff);
     }
     const int *cells_in_use = &grid->use;
     if (comm_attached() && comm_nranks() > 1) {
@@ -641,7 +777,7 @@ extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, 
             hipLaunchKernelGGL(k_pairwise, dim3((hi - lo + PW_SITES - 1) / PW_SITES), dim3(PW_NT), 0, st, hi, x, y, z, lattice, pbc, sigma, k, list, cnt, xbuf, d_ne, lo, e.pair_cut, cells_in_use);
         if (hi > lo && key.possible)
             hipLaunchKernelGGL(k_pairwise_cells, dim3(cell_blocks), dim3(PW_NT), 0, st, N, x, y, z, pbc, sigma, k, (const PwGrid *)grid, (const int *)tstart, (const int *)cstart,
-                               (const int *)chunk0, (const int *)pperm, (const ChargedSite *)clist2, xbuf, d_ne, lo, hi, e.pair_cut);
+                               (const int *)chunk0, (const int *)pperm2, (const ChargedSite *)clist3, (const int *)cxoff, xbuf, d_ne, lo, hi, e.pair_cut);
         KCHK();
         rc = comm_allgather_f64(xbuf, (size_t)chunk); if (rc) return rc;
         HIPCHK(hipMemcpyAsync(out, xbuf, (size_t)N * 8, hipMemcpyDeviceToDevice, st));
@@ -649,7 +785,7 @@ extern "C" int dkmc_poisson_gridless_gpu(int num_atoms_contact, int pbc, int N, 
         hipLaunchKernelGGL(k_pairwise, dim3((N + PW_SITES - 1) / PW_SITES), dim3(PW_NT), 0, st, N, x, y, z, lattice, pbc, sigma, k, list, cnt, out, d_ne, 0, e.pair_cut, cells_in_use);
         if (key.possible)
             hipLaunchKernelGGL(k_pairwise_cells, dim3(cell_blocks), dim3(PW_NT), 0, st, N, x, y, z, pbc, sigma, k, (const PwGrid *)grid, (const int *)tstart, (const int *)cstart,
-                               (const int *)chunk0, (const int *)pperm, (const ChargedSite *)clist2, out, d_ne, 0, N, e.pair_cut);
+                               (const int *)chunk0, (const int *)pperm2, (const ChargedSite *)clist3, (const int *)cxoff, out, d_ne, 0, N, e.pair_cut);
         KCHK();
     }
     e.stats.pair_ms = 0.0;

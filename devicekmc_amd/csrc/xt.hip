@@ -994,7 +994,7 @@ static int xt_side_init()
 
 // Assemble Xs + tiles and solve X m = rhs with the Jacobi-scaled CG.  aneigh/ancnt/aflag/srank/S/atom_site: current.hip steps 1-2.
 int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEntry *S, const int *aneigh, const int *ancnt, const int *aflag,
-                          const int *srank, const int *atom_site, double *rhs, double *y, int *iters_out, double *rr_out)
+                          const int *srank, const int *atom_site, double *rhs, double *y, int *iters_out, double *rr_out, double *yaux, int yaux_valid)
 {
     TCacheView TC{};                     // brought up to date for this rank's share inside assemble() (tc_prepare_tiled, current.hip)
     Engine &e = eng(); hipStream_t st = e.stream;
@@ -1239,6 +1239,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
         B.items = (const XItem *)items + X.item_lo; B.item_n = X.item_n; B.tiles = tiles; B.sub_base = (int)X.sub_base; B.tval = tval;
         B.wrange = wrange; B.nitem_w = nitem_w; B.nrecords = X.nitems >> X.rec_shift;
         B.srow = srow; B.sS = sS; B.nsrank = nsrank; B.rp = rp; B.ci = col; B.val = val; B.sc = sc; B.ax = buf->atom_x; B.ay = buf->atom_y; B.az = buf->atom_z; B.b = rhs; B.y = y;
+        B.yaux = yaux; B.yaux_valid = yaux_valid;
         B.ctrl = ctrl; B.tol2 = tol2; B.nt_loads = nt_loads; B.sharded = sharded; B.w_lo = X.w_lo; B.w_hi = X.w_hi;
         int bi = 0; double brr = 0.0;
         rc = xtb_cg(B, &bi, &brr);

@@ -65,14 +65,14 @@ __device__ __forceinline__ double xtb_aux(int row, int col)
 // of the spectrum from the first sweeps (oracle's X, tools/blockcg_proto.py, x modes: 6.4e3 rows 48 -> 31 sweeps, 5.8e4 rows 95 -> 76).
 // Smooth systems also CONVERGE sooner than the physical column; close to a converged tolerance (1e-10 and below) their residual columns
 // vanish and the s x s systems lose rank, so below 1e-8 the hash set stays (dkmc_set_x_aux).
-struct XbAux { double lo[3], hi[3]; int k[16][3]; unsigned long long mm[6]; };
+struct XbAux { double lo[3], hi[3]; int k[16][3]; unsigned long long mm[6]; int hs, pad_; };      // hs: columns 1 ... hs - 1 take the smooth set, hs ... s - 1 the hash set
 __device__ __forceinline__ double xtb_rhs(const double *__restrict__ b, int row, int v, int s, const XbAux *__restrict__ aux = nullptr,
                                           const double *__restrict__ ax = nullptr, const double *__restrict__ ay = nullptr, const double *__restrict__ az = nullptr,
                                           const double *__restrict__ sc = nullptr)
 {
     if (v == 0) return b[row];
     if (v >= s) return 0.0;
-    if (!aux) return xtb_aux(row, v);
+    if (!aux || v >= aux->hs) return xtb_aux(row, v);
     // rows 0 / 1: the ground-side and the source-side driver node, at the two ends of x, in the middle of the cross-section
     double u[3];
     if (row < 2) { u[0] = row == 0 ? 1.0 : 0.0; u[1] = 0.5; u[2] = 0.5; }
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(256) void k_xtb_small(int it, int s, const double *
 __global__ __launch_bounds__(XT_NT) void k_xtb_step(int m, int it, const double *__restrict__ mats, double *__restrict__ y0, double *__restrict__ R,
                                                     double *__restrict__ P, const double *__restrict__ T, const double *__restrict__ sc,
                                                     const int *__restrict__ nsrank, double *__restrict__ QS, const XCtrl *ctrl,
-                                                    const int *__restrict__ rowlist = nullptr)
+                                                    const int *__restrict__ rowlist = nullptr, double *__restrict__ Ypanel = nullptr)
 {
     __shared__ int sdone;
     if (threadIdx.x == 0) { const int d = ctrl->done; sdone = d != 0 && it + 1 >= d; }
@@ -950,7 +950,7 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_step(int m, int it, const double 
         const size_t oa = (size_t)rowa * XB_SP + b;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) { pa[kk] = oka ? P[oa + 4 * kk] : 0.0; ta[kk] = oka ? T[oa + 4 * kk] : 0.0; ra[kk] = oka ? R[oa + 4 * kk] : 0.0; }
-        dbl4 rN, pN = (dbl4)(0.0);
+        dbl4 rN, pN = (dbl4)(0.0), yN = (dbl4)(0.0);
         const double yold = (b == 0 && oka) ? y0[rowa] : 0.0;
         int rowu[4];
 #pragma unroll
@@ -958,6 +958,7 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_step(int m, int it, const double 
             const int li = row0 + b + 4 * u;
             rowu[u] = li < m ? (rowlist ? rowlist[li] : li) : -1;
             rN[u] = rowu[u] >= 0 ? R[(size_t)rowu[u] * XB_SP + a] : 0.0;
+            if (Ypanel) yN[u] = rowu[u] >= 0 ? Ypanel[(size_t)rowu[u] * XB_SP + a] : 0.0;
         }
         // y0[row] += sum_i P[row][i] c[i][0]: lane (a, b) holds i = 4 kk + b; the four b-groups are added in a fixed order
         double yacc = (pa[0] * c0[0] + pa[1] * c0[1]) + (pa[2] * c0[2] + pa[3] * c0[3]);
@@ -967,6 +968,7 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_step(int m, int it, const double 
         for (int kk = 0; kk < 4; ++kk) {
             rN = XB_MFMA(ta[kk], cB[kk], rN);
             pN = XB_MFMA(ra[kk], m1B[kk], pN); pN = XB_MFMA(ta[kk], m3B[kk], pN); pN = XB_MFMA(pa[kk], m2B[kk], pN);
+            if (Ypanel) yN = XB_MFMA(pa[kk], cB[kk], yN);                  // Y += P c, all columns (the auxiliary solutions are kept for the next solve)
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -974,24 +976,40 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_step(int m, int it, const double 
             if (row >= 0) {
                 const size_t o = (size_t)row * XB_SP + a;
                 R[o] = rN[u]; P[o] = pN[u];
+                if (Ypanel) Ypanel[o] = yN[u];
                 const int sr = nsrank[row];
                 if (sr >= 0) QS[xtb_qs_pos(sr, a)] = sc[row] * pN[u];
             }
         }
     }
 }
-// before the first product: P = [y, 0, ...] stands in for Y0 (the product below is A Y0), QS = S Y0 over S; y0 = y
+// before the first product: P = Y0 stands in for Y0 (the product below is A Y0), QS = S Y0 over S; y0 = column 0.  Column 0 starts from y;
+// the auxiliary columns from zero, or -- yaux != nullptr: columns hs ... s - 1, the hash set -- from the UNSCALED solutions the previous solve left
+// (their right-hand sides are the same in every solve): their residuals then carry what the previous solve had not yet resolved, which is what
+// the block Krylov space of this one should contain (tools/warm_aux_proto.py).  Ypanel (may be null): the scaled block iterate Y, all columns.
 __global__ void k_xtb_init(int m, const double *__restrict__ y, const double *__restrict__ sc, const int *__restrict__ nsrank,
-                           double *__restrict__ y0, double *__restrict__ P, double *__restrict__ QS)
+                           double *__restrict__ y0, double *__restrict__ P, double *__restrict__ QS,
+                           const double *__restrict__ yaux = nullptr, int hs = 16, int s = 16, double *__restrict__ Ypanel = nullptr)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m * XB_SP) return;
     const int row = i >> 4, v = i & 15;
-    const double yv = v == 0 ? y[row] : 0.0;
+    double yv = 0.0;
+    if (v == 0) yv = y[row];
+    else if (yaux && v >= hs && v < s) yv = yaux[i] / sc[row];
     P[i] = yv;
+    if (Ypanel) Ypanel[i] = yv;
     if (v == 0) y0[row] = yv;
     const int sr = nsrank[row];
     if (sr >= 0) QS[xtb_qs_pos(sr, v)] = sc[row] * yv;
+}
+// the auxiliary solutions a solve leaves for the next one: unscaled (x = S y)
+__global__ void k_xtb_yaux_out(int n, const int *__restrict__ rowlist, const double *__restrict__ Ypanel, const double *__restrict__ sc, double *__restrict__ yaux)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * XB_SP) return;
+    const int row = rowlist ? rowlist[i >> 4] : (i >> 4), v = i & 15;
+    yaux[(size_t)row * XB_SP + v] = Ypanel[(size_t)row * XB_SP + v] * sc[row];
 }
 __global__ void k_xtb_zero(long long n, double *__restrict__ p)
 {
@@ -1022,6 +1040,19 @@ int g_xtb_fault_iter = -1;
 // ---- host loop ------------------------------------------------------------------------------------------------------------------------
 // Returns 0 with the scaled solution of column 0 in A.y; DKMC_XTB_BREAKDOWN (> 0, no error recorded) when an s x s system lost
 // definiteness: A.y then holds the last good iterate and the caller continues with the single-vector loop from it.
+// Auxiliary columns (dkmc_set_x_aux, dkmc_set_x_aux_warm).  Returns hs: columns 1 ... hs - 1 take the SMOOTH set (lowest Laplacian modes of the
+// bounding box, always from a zero start: their systems converge before the physical one does, a warm start would leave them without a
+// residual), columns hs ... s - 1 the HASH set -- started from the previous solve's solutions when the caller keeps them (warm).
+//   mode 0: all hash.  1 / 3: all smooth.  2 (default): at tolerances of 1e-8 and looser the smooth set -- or, with the warm auxiliary start,
+//   half smooth + half hash (measured on the oracle's X, tools/warm_aux_proto.py: 2.5 nm 33 -> 16-19 sweeps, against 40 with column 0 alone
+//   warm-started); below 1e-8 all hash (smooth systems lose rank close to a converged tolerance).
+static int xtb_aux_split(int mode, double tol2, bool warm, int s)
+{
+    if (mode == 0) return 1;
+    if (mode == 1 || mode == 3) return 16;
+    if (!(tol2 >= 1e-16)) return 1;
+    return warm ? std::max(1, s / 2) : 16;
+}
 static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *peer_used);
 static int xtb_cg_slab(const XtbArgs &A, int nr, int me0, const XShare *emu_shares, int time_rank, int *iters_out, double *rr_out);
 int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
@@ -1073,18 +1104,25 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
     }
     // smooth auxiliary columns (see xtb_rhs): dkmc_set_x_aux 0 never, 1 always, 2 (default) at tolerances of 1e-8 and looser, 3 always with x modes only
     XbAux *aux = nullptr;
-    if (A.ax && A.ay && A.az && m > 2 && (e.x_aux == 1 || e.x_aux == 3 || (e.x_aux == 2 && A.tol2 >= 1e-16))) {
+    // which auxiliary columns take which set, and which start from the previous solve's solutions (A.yaux, dkmc_set_x_aux_warm): see xtb_aux_split
+    const int hs = xtb_aux_split(e.x_aux, A.tol2, A.yaux != nullptr, s);
+    const bool keep_aux = A.yaux != nullptr;
+    double *Ypanel = keep_aux ? (double *)scratch(S_XTB_YPANEL, pan * 8) : nullptr;
+    if (keep_aux && !Ypanel) return e.err_code;
+    if (A.ax && A.ay && A.az && m > 2 && hs > 1) {
         aux = (XbAux *)scratch(S_XTB_XI, sizeof(XbAux));
         if (!aux) return e.err_code;
         XbAux h0{};
+        h0.hs = hs;
         for (int d = 0; d < 3; ++d) { h0.mm[2 * d] = ~0ull; h0.mm[2 * d + 1] = 0ull; }
         HIPCHK(hipMemcpyAsync(aux, &h0, sizeof(XbAux), hipMemcpyHostToDevice, st));       // (pageable source: copied before the call returns)
         hipLaunchKernelGGL(k_xtb_box, dim3(std::min((m - 2 + 255) / 256, 256)), dim3(256), 0, st, m - 2, A.ax, A.ay, A.az, aux);
         hipLaunchKernelGGL(k_xtb_modes, dim3(1), dim3(512), 0, st, aux, e.x_aux == 3 ? 1 : 0);
     }
-    e.stats.xb_aux = aux ? 1 : 0;
+    e.stats.xb_aux = aux ? (hs >= s ? 1 : 2) : 0;
     int local_fail = 0;
-    hipLaunchKernelGGL(k_xtb_init, dim3((unsigned)((pan + 255) / 256)), dim3(256), 0, st, m, (const double *)A.y, A.sc, A.nsrank, y0, P, QS);
+    hipLaunchKernelGGL(k_xtb_init, dim3((unsigned)((pan + 255) / 256)), dim3(256), 0, st, m, (const double *)A.y, A.sc, A.nsrank, y0, P, QS,
+                       (const double *)((keep_aux && A.yaux_valid) ? A.yaux : nullptr), hs, s, Ypanel);
     const int ntb = (A.item_n + 3) / 4;
     const int nnb = 2 * XB_DSPLIT + (std::max(m - 2, 1) + 15) / 16;
     const int gs = xt_grid((m + 15) / 16, 4, 2048);
@@ -1147,7 +1185,8 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
     hipLaunchKernelGGL(k_xtb_gred, dim3(XB_NG * 16), dim3(XT_NT), 0, st, ng, (const double *)gpart, gfin, (const XCtrl *)A.ctrl);
     hipLaunchKernelGGL(k_xtb_small, dim3(1), dim3(256), 0, st, -1, s, (const double *)gfin, mats, A.ctrl, A.tol2);
     hipLaunchKernelGGL(k_xtb_zero, dim3((unsigned)((pan + 255) / 256)), dim3(256), 0, st, (long long)pan, P);          // Y0 has served: P_{-1} = 0
-    hipLaunchKernelGGL(k_xtb_step, dim3(gs), dim3(XT_NT), 0, st, m, -1, (const double *)mats, y0, R, P, (const double *)T, A.sc, A.nsrank, QS, (const XCtrl *)A.ctrl);
+    hipLaunchKernelGGL(k_xtb_step, dim3(gs), dim3(XT_NT), 0, st, m, -1, (const double *)mats, y0, R, P, (const double *)T, A.sc, A.nsrank, QS, (const XCtrl *)A.ctrl,
+                       (const int *)nullptr, Ypanel);
     KCHK();
     int it = 0, launched = 0, batch = 4;
     if (e.x_iter_hint > 12) batch = e.x_iter_hint - 4;
@@ -1173,7 +1212,8 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
             if (int rcx = rows(false, it, pb ? evs[4 * sl + 2] : nullptr, pb ? evs[4 * sl + 3] : nullptr)) return rcx;
             hipLaunchKernelGGL(k_xtb_gred, dim3(XB_NG * 16), dim3(XT_NT), 0, st, ng, (const double *)gpart, gfin, (const XCtrl *)A.ctrl);
             hipLaunchKernelGGL(k_xtb_small, dim3(1), dim3(256), 0, st, it, s, (const double *)gfin, mats, A.ctrl, A.tol2);
-            hipLaunchKernelGGL(k_xtb_step, dim3(gs), dim3(XT_NT), 0, st, m, it, (const double *)mats, y0, R, P, (const double *)T, A.sc, A.nsrank, QS, (const XCtrl *)A.ctrl);
+            hipLaunchKernelGGL(k_xtb_step, dim3(gs), dim3(XT_NT), 0, st, m, it, (const double *)mats, y0, R, P, (const double *)T, A.sc, A.nsrank, QS, (const XCtrl *)A.ctrl,
+                               (const int *)nullptr, Ypanel);
         }
         launched = batch;
         KCHK();
@@ -1185,6 +1225,7 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
     if (h.aborted) return dkmc_fail(46, "a peer rank aborted the sharded current solve", __FILE__, __LINE__);
     if (e.err_code) return e.err_code;
     HIPCHK(hipMemcpyAsync(A.y, y0, (size_t)m * 8, hipMemcpyDeviceToDevice, st));
+    if (keep_aux) hipLaunchKernelGGL(k_xtb_yaux_out, dim3((unsigned)((pan + 255) / 256)), dim3(256), 0, st, m, (const int *)nullptr, (const double *)Ypanel, A.sc, A.yaux);
     e.x_iter_hint = h.iters;
     if (iters_out) *iters_out = h.iters;
     if (rr_out) *rr_out = h.rr[h.iters & 1];

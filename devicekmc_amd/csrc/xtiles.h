@@ -69,6 +69,7 @@ struct XtbArgs {
     const double *ax, *ay, *az;                   // position of the atom of row r >= 2 at [r - 2] (smooth auxiliary columns; may be null)
     const double *b;                              // scaled right-hand side
     double *y;                                    // in: scaled start vector y / s; out: scaled solution
+    double *yaux; int yaux_valid;                 // UNSCALED solutions of the auxiliary columns, [m][16] (may be null): in (if valid) the previous solve's, out this solve's
     XCtrl *ctrl; double tol2; bool nt_loads;
     bool sharded; int w_lo, w_hi;                 // sharded solve (comm.hip): windows of this rank's tiles
 };

@@ -314,7 +314,8 @@ def save_restart(path, device: Device, sim: KMCProcess, gpubuf: GPUBuffers, kmc_
     """Device::writeSnapshot (Device.cpp:236-252) + the state it drops (io.write_restart): after load_restart the run continues with
     the same event sequence, bit for bit.  The start vector of the next current solve is part of that state in both modes of
     dkmc_set_current_warm_start: gpubuf.atom_virtual_potentials (mode 0 reads it) and the library's private unscaled copy of the last
-    solution (mode 1, the default; dkmc_get_current_warm_vector)."""
+    solution (mode 1, the default; dkmc_get_current_warm_vector) together with the solutions of the block-CG's auxiliary columns
+    (dkmc_get_current_warm_aux)."""
     from . import io
     L = _lib.load()
     gpubuf.sync_GPUToHost(device)
@@ -323,10 +324,15 @@ def save_restart(path, device: Device, sim: KMCProcess, gpubuf: GPUBuffers, kmc_
     warm = np.zeros(n.value)
     if n.value:
         check(L.dkmc_get_current_warm_vector(C.byref(gpubuf.c), _np_ptr(warm), n.value, C.byref(n)))
+    na = C.c_longlong(0)
+    check(L.dkmc_get_current_warm_aux(C.byref(gpubuf.c), None, 0, C.byref(na)))
+    warm_aux = np.zeros(na.value)
+    if na.value:
+        check(L.dkmc_get_current_warm_aux(C.byref(gpubuf.c), _np_ptr(warm_aux), na.value, C.byref(na)))
     state = dict(site_charge=device.site_charge, site_potential_boundary=device.site_potential_boundary,
                  site_potential_charge=device.site_potential_charge, site_power=device.site_power,
                  site_temperature=device.site_temperature, site_CB_edge=device.site_CB_edge,
-                 atom_virtual_potentials=gpubuf.atom_virtual_potentials.cpu().numpy(), current_warm_vector=warm,
+                 atom_virtual_potentials=gpubuf.atom_virtual_potentials.cpu().numpy(), current_warm_vector=warm, current_warm_aux=warm_aux,
                  T_bg=float(device.T_bg), kmc_time=float(kmc_time), kmc_step_count=int(kmc_step_count),
                  rnd_seed_kmc=int(sim.random_generator.seed), kmc_rng_raw_draws=int(sim.random_generator.n_raw),
                  current_warm_start=int(L.dkmc_get_current_warm_start()), N_atom_buffer=int(gpubuf.N_atom_))
@@ -357,6 +363,8 @@ def load_restart(path, p: KMCParameters, device="cuda:0", gpu_neighbors=None):
             raise ValueError("restart sidecar was written in warm-start mode 1 by a version that did not save the private start vector: "
                              "a bit-identical continuation is not possible")
         check(_lib.load().dkmc_set_current_warm_vector(C.byref(gb.c), _np_ptr(warm) if len(warm) else None, len(warm)))
+        waux = np.asarray(state["current_warm_aux"], dtype=np.float64) if "current_warm_aux" in state else np.zeros(0)
+        check(_lib.load().dkmc_set_current_warm_aux(C.byref(gb.c), _np_ptr(waux) if len(waux) else None, len(waux)))
         # the start vector of the next current solve: entries [0, Na + 1) of the saved buffer are read (Na = atoms of the snapshot).  The
         # buffer of the saved run was sized for ITS initial atom count, this one for the snapshot's: the used part must fit both.
         m = np.asarray(state["atom_virtual_potentials"], dtype=np.float64)

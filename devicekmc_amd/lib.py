@@ -64,6 +64,8 @@ SYMBOLS = {
     "dkmc_get_k_slab": (_I, []),
     "dkmc_set_x_slab": (None, [_I]),
     "dkmc_get_x_slab": (_I, []),
+    "dkmc_set_x_aux_warm": (None, [_I]),
+    "dkmc_get_x_aux_warm": (_I, []),
     "dkmc_set_x_aux": (None, [_I]),
     "dkmc_get_x_aux": (_I, []),
     "dkmc_set_k_blocked": (None, [_I]),
@@ -75,6 +77,8 @@ SYMBOLS = {
     "dkmc_get_current_warm_start": (_I, []),
     "dkmc_get_current_warm_vector": (_I, [C.POINTER(dkmc_gpubuf), vp, _I, c_int_p]),
     "dkmc_set_current_warm_vector": (_I, [C.POINTER(dkmc_gpubuf), vp, _I]),
+    "dkmc_get_current_warm_aux": (_I, [C.POINTER(dkmc_gpubuf), vp, C.c_longlong, C.POINTER(C.c_longlong)]),
+    "dkmc_set_current_warm_aux": (_I, [C.POINTER(dkmc_gpubuf), vp, C.c_longlong]),
     "dkmc_set_profiling": (None, [_I]),
     "dkmc_set_x_format": (None, [_I]),
     "dkmc_get_x_format": (_I, []),

@@ -164,6 +164,14 @@ int dkmc_get_k_slab(void);
  * rank close to a converged tolerance).  No counterpart in the reference. */
 void dkmc_set_x_aux(int mode);
 int dkmc_get_x_aux(void);
+/* With dkmc_set_current_warm_start(1).  1: the auxiliary columns of the hash set start from the solutions the previous solve left for them (their
+ * right-hand sides never change), and at tolerances of 1e-8 and looser the set is half smooth (zero start) + half hash (warm): the residuals the
+ * warm columns start with carry what the previous solve had not resolved yet.  0 (default): every auxiliary column starts from zero.  On the
+ * oracle's X of the 2.5 nm device the warm auxiliary start halves the sweeps (33 -> 16-19, tools/warm_aux_proto.py); measured on the GPU it gains
+ * nothing from 85 k sites up (profiles/r05_ab_aux_warm.json: 9.4e5 sites 435 -> 425-445 sweeps), hence off.  Column 0 and the contract
+ * (solution within the stop test) are unaffected either way. */
+void dkmc_set_x_aux_warm(int on);
+int dkmc_get_x_aux_warm(void);
 /* 1 (default): initialize_sparsity also builds the blocked form of the K pattern (csrc/kcg.hip) for systems of up to 262 144 device rows:
  * the CG on K (background potential, CB edge: solve_sparse_CG_Jacobi on K, iterative_solvers_gpu.cu:309-480) then runs in an internal
  * x-sorted row order, one block of rows per CU with its window of the direction vector in LDS; site order outside the solve is untouched.
@@ -180,6 +188,9 @@ void dkmc_set_current_warm_start(int mode);
 int dkmc_get_current_warm_start(void);
 int dkmc_get_current_warm_vector(const dkmc_gpubuf *buf, double *h_out, int capacity, int *n_out);
 int dkmc_set_current_warm_vector(const dkmc_gpubuf *buf, const double *h_in, int n);
+/* the same for the solutions of the block-CG's auxiliary columns (dkmc_set_x_aux_warm): [rows][16] doubles */
+int dkmc_get_current_warm_aux(const dkmc_gpubuf *buf, double *h_out, long long capacity, long long *n_out);
+int dkmc_set_current_warm_aux(const dkmc_gpubuf *buf, const double *h_in, long long n);
 /* 1: bracket every SpMV launch of the CG solves with HIP events on the engine's stream and accumulate
  * their durations into dkmc_stats (measurement aid for bench.py; off by default) */
 void dkmc_set_profiling(int on);

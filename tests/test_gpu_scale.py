@@ -205,7 +205,9 @@ def test_tile20_current_off_first_superstep():
     assert host.get_stats()["cg_rr_K"] <= 1e-24
     pb2, pc2 = gb.site_potential_boundary.cpu().numpy(), gb.site_potential_charge.cpu().numpy()
     assert np.array_equal(pc2, pc)                                               # same charges, same pair sum, bit for bit
-    assert np.abs(pb2 - pb).max() <= 1e-3                                         # the default-tolerance solution sits within cond(K) x 1e-6 of it
+    # (the default-tolerance solution above is NOT close to it everywhere: cond(K) x 1e-6 leaves weakly coupled sites up to 0.15 V away, measured
+    # here -- which is why the event sequence is compared on converged potentials)
+    assert np.abs(pb2 - pb).max() <= 0.5
     sres2 = (K @ pb2[nl:nl + m] - rhs) / np.sqrt(K.diagonal())
     assert np.linalg.norm(sres2) <= 1e-9, np.linalg.norm(sres2)                   # (true residual: the recurrence's 1e-12 minus the rounding of K phi)
     pb = pb2

@@ -121,3 +121,48 @@ def test_warm_vector_export_import(cell_2p5, hip):
     check(L.dkmc_set_current_warm_vector(C.byref(gb2.c), None, 0))
     check(L.dkmc_get_current_warm_vector(C.byref(gb2.c), None, 0, C.byref(n)))
     assert n.value == 0
+
+
+def test_auxiliary_columns_warm_start_option(cell_2p5, hip):
+    """dkmc_set_x_aux_warm(1) (off by default: profiles/r05_ab_aux_warm.json): the hash auxiliary columns start from the solutions the previous
+    solve left, the default set becomes half smooth + half hash.  Whatever the auxiliary columns start from, the physical column's solution meets
+    the reference's stop test in the true scaled residual of the CSR X; here over four coupled supersteps, and the auxiliary panel survives an
+    export / import (restart)."""
+    import ctypes as C
+    from devicekmc_amd import params as pm
+    from devicekmc_amd.lib import check
+    host, L = hip
+    p = pm.KMCParameters(); p.solve_heating_global = False
+    try:
+        L.dkmc_set_x_aux_warm(1)
+        dev = host.Device(cell_2p5, p); sim = host.KMCProcess(dev, p.freq); gb = dev.make_gpubuf("cuda:0")
+        dev.setLaplacePotential(gb, p, Vd); gb.sync_HostToGPU(dev)
+        sweeps = []
+        for k in range(4):
+            dev.updateCharge(gb); dev.updatePotential(gb, p, Vd, k)
+            sim.executeKMCStep(gb, dev)
+            dev.updatePower(gb, p, Vd)
+            st = host.get_stats()
+            assert st["xb_width"] == 16 and st["xb_fallback"] == 0 and st["xb_aux"] == 2       # 2: mixed set
+            sweeps.append(st["cg_iters_X"])
+            m = get(gb, "atom_virtual_potentials").copy()
+            L.dkmc_set_x_format(0); L.dkmc_set_current_warm_start(0)
+            try:
+                dev.updatePower(gb, p, Vd)                     # the CSR X of the same state (for the true residual); leaves the private copies alone
+                rp, ci, data = host.get_last_X()
+            finally:
+                L.dkmc_set_x_format(1); L.dkmc_set_current_warm_start(1)
+            assert _scaled_residual(rp, ci, data, m, p.G0, p.X_loop_G) <= 10 * p.cg_tol, (k, sweeps)
+        print("sweeps with the warm auxiliary start (2.5 nm):", sweeps)
+        n = C.c_longlong(0)
+        check(L.dkmc_get_current_warm_aux(C.byref(gb.c), None, 0, C.byref(n)))
+        assert n.value == 16 * (dev.N_atom + 1)
+        w = np.zeros(n.value)
+        check(L.dkmc_get_current_warm_aux(C.byref(gb.c), w.ctypes.data_as(C.c_void_p), n.value, C.byref(n)))
+        assert np.abs(w.reshape(-1, 16)[:, 8:]).max() > 0 and np.abs(w.reshape(-1, 16)[:, 1:8]).max() > 0
+        check(L.dkmc_set_current_warm_aux(C.byref(gb.c), w.ctypes.data_as(C.c_void_p), n.value))
+        check(L.dkmc_set_current_warm_aux(C.byref(gb.c), None, 0))
+        check(L.dkmc_get_current_warm_aux(C.byref(gb.c), None, 0, C.byref(n)))
+        assert n.value == 0
+    finally:
+        L.dkmc_set_x_aux_warm(0)

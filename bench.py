@@ -657,6 +657,8 @@ def main():
     ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the replicas block")
     ap.add_argument("--no-single-ref", action="store_true", help="N > 1: skip the single-GPU run of the same simulation (reference point of the speed-up)")
     ap.add_argument("--no-alt", action="store_true", help="skip the reference_start_vector block")
+    ap.add_argument("--no-scaling-model", action="store_true", help="N = 1: skip strong_scaling_model / k_cg_slab_model (the virtual-rank emulations launch the solver's kernels on per-rank shares: "
+                                                                    "a kernel-trace profile of the run would average them in)")
     ap.add_argument("--no-cpp-host", action="store_true", help="N = 1: skip the cross-check line through the C++ host driver")
     ap.add_argument("--no-pmc", action="store_true", help="N = 1: do not measure roofline.traffic (two rocprofv3 --pmc child runs)")
     ap.add_argument("--no-log-tolerance", action="store_true", help="N = 1: skip the at_log_tolerance block")
@@ -729,7 +731,7 @@ def main():
         if n != args.steps:
             out["steps_requested"] = args.steps
         out.update(roofs)
-        if big and sim.x_block > 1 and "roofline" in out:
+        if big and sim.x_block > 1 and "roofline" in out and not args.no_scaling_model:
             out["strong_scaling_model"] = strong_scaling_model_slabs(sim, res)
         # ---- same simulation from the reference code's start vector (dkmc_set_current_warm_start(0)): what the default's warm start saves ----
         if args.warm_start == 1 and not args.no_alt:
@@ -845,7 +847,8 @@ def main():
                     r["what"] = ("a crossbar-SIZED stack with the current solve off, as every shipped crossbar parameter set runs "
                                  "(structures/crossbars/*/parameters.txt: solve_current = 0): charge + potential (K-CG + pair sum) + event loop")
                     r["us_per_executed_event"] = round(r["split_ms"]["rates"] * 1e3 / max(r["per_step"]["events"], 1), 1)
-                    r["k_cg_slab_model"] = k_slab_model(sp)
+                    if not args.no_scaling_model:
+                        r["k_cg_slab_model"] = k_slab_model(sp)
                 rf = rooflines(sp)
                 if nocur:                                # the library's X statistics are those of an earlier simulation of this process
                     rf.pop("roofline", None)

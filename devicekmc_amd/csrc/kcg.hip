@@ -643,8 +643,8 @@ int kcg_assemble_and_solve(int cb, int m, int N_left, const int *element, const 
 // -- identical scalars on every rank by construction, so all ranks stop at the same iteration and no flag has to travel.  Vectors keep their full
 // length on every rank (29 MB each at 3.6e6 rows); entries a rank neither owns nor reads are never touched.  The solution's own rows are
 // all-gathered once at the end.  The same host loop runs N VIRTUAL ranks in one process (dkmc_kcg_emulate_slabs): how it is tested on one GPU.
-#define KS_NPA 256          // block partials of the product per rank (its grid)
-#define KS_NP 64            // block partials of r'.r' per rank
+#define KS_NPA 2048         // block partials of the product per rank (its largest grid: 8 workgroups per CU; 16 KB per rank in exchange 1)
+#define KS_NP 512           // block partials of r'.r' per rank (4 KB per rank in exchange 2)
 __global__ __launch_bounds__(KC_NT) void k_ks_check0(int n, const double *__restrict__ xa, KCtrl *ctrl, double tol2)
 {
     __shared__ double red[KC_NT / 64];

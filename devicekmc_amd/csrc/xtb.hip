@@ -1189,7 +1189,9 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
                        (const int *)nullptr, Ypanel);
     KCHK();
     int it = 0, launched = 0, batch = 4;
-    if (e.x_iter_hint > 12) batch = e.x_iter_hint - 4;
+    // launch plan: the first batch covers three quarters of the previous solve's sweeps -- with the warm start the count moves by +-30 per cent from
+    // step to step (9.4e5 sites: 268 ... 505), and a batch sized to the previous count left up to a quarter of its launches as no-ops --, then batches of 8
+    if (e.x_iter_hint > 12) batch = std::max(4, e.x_iter_hint * 3 / 4);
     XCtrl h{};
     for (;;) {
         HIPCHK(hipMemcpyAsync(&h, A.ctrl, sizeof(XCtrl), hipMemcpyDeviceToHost, st));
@@ -1217,7 +1219,7 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
         }
         launched = batch;
         KCHK();
-        if (e.x_iter_hint > 12) batch = 4; else if (batch < 64) batch *= 2;
+        if (e.x_iter_hint > 12) batch = 8; else if (batch < 64) batch *= 2;
     }
 #undef XB_ROWS_ARGS
     if (local_fail) return local_fail;                                         // the peers were told (abort word)

@@ -145,12 +145,15 @@ __global__ __launch_bounds__(XT_NT) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__restrict__ tiles, int sub_base, const double *__restrict__ tval,
                  const double *__restrict__ QS, int nW, double *__restrict__ rowpartB, double *__restrict__ colpartB, const XCtrl *ctrl)
 {
-    // variant (measurement aid, dkmc_xtb_time_apply; 0 in every solve): 1 = no matrix instructions (stream + LDS traffic only), 2 = the
-    // tile stream is not re-read (matrix instructions + LDS traffic only), 3 = operand stages of one k-pair, 4 = no LDS traffic (the row
-    // sums replaced by as many products on the loaded registers); the results of 1, 2 and 4 are meaningless
+    // variant 0 = the product kernel.  Every other value is the ROUND-4 FORM of the loop (stages issued in bursts, conditional loads at the tile end,
+    // panel rows loaded directly), kept for same-box comparisons (dkmc_set_x_apply_form(1) = variant 8, same results as 0) and as the carrier of the
+    // measurement variants of dkmc_xtb_time_apply: 1 = no matrix instructions (stream + LDS traffic only), 2 = the tile stream is not re-read
+    // (matrix instructions + LDS traffic only), 3 = operand stages of one k-pair, 4 = no LDS traffic (the row sums replaced by as many products on
+    // the loaded registers), 7 = 2 and 4 together (the matrix instructions alone); the results of 1, 2, 4 and 7 are meaningless
     constexpr int so = 4 * NG;                                                 // vectors per row of the partial-sum arrays
     __shared__ __attribute__((aligned(16))) double qc[XT_C * XB_SP];          // the strip's 256 panel rows in QS order (32 KiB)
     __shared__ __attribute__((aligned(16))) double ts[4 * 2 * XT_SUB];        // per wave: two sub-block images (2 x 8 KiB)
+    __shared__ __attribute__((aligned(16))) double brs[variant == 0 ? 4 * XT_R * XB_SP : 2];   // per wave: the next tile's 32 panel rows (4 KiB)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, cc = lane & 15, rr = lane >> 4, jv = lane & 3, blk = cc >> 2;
     const int item = (int)blockIdx.x * 4 + wv;
@@ -165,6 +168,7 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
     }
     __syncthreads();
     double *tsw = ts + (size_t)wv * 2 * XT_SUB;
+    double *brw = brs + (variant == 0 ? (size_t)wv * XT_R * XB_SP : 0);
     double Yc[8][2][NG];
 #pragma unroll
     for (int q = 0; q < 8; ++q)
@@ -182,7 +186,7 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
     int qoff[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) qoff[g] = rr * 32 + ((2 * (4 * g + jv)) ^ (rr << 3));      // + (16 q + 4 kk) * 32
-#define XB_LD(dst, slot) if (variant != 2 || (slot) < 2) { _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) dst[j_] = NTL ? __builtin_nontemporal_load(base + (size_t)(8 * (slot) + j_) * 64) : base[(size_t)(8 * (slot) + j_) * 64]; }
+#define XB_LD(dst, slot) if ((variant != 2 && variant != 7) || (slot) < 2) { _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) dst[j_] = NTL ? __builtin_nontemporal_load(base + (size_t)(8 * (slot) + j_) * 64) : base[(size_t)(8 * (slot) + j_) * 64]; }
     // panel operands of the column sums: rows 4 j + rr of a tile's 32 panel rows, vectors 4 g + jv (the same in all four blocks)
 #define XB_LDBR(k_)                                                                                                            \
     {                                                                                                                           \
@@ -192,6 +196,11 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
             _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_) br[j_][g_] = qr_[r32_ * 32 + 2 * (4 * g_ + jv) + (rho_ & 1)];      \
         }                                                                                                                       \
     }
+    // the same rows by way of LDS -- four coalesced 16-byte loads per lane EARLY in the tile (LDBN), a plain copy into brw (WBN), read back in br's
+    // lane map once the tile's last column sums are issued (RDBRH).  vmcnt retires in order: loaded at the END of a tile (round-4 form) these rows sat
+    // behind the prefetched sub-blocks and the next tile's first stage drained the queue
+#define XB_LDBN(k_) { const dbl2 *qn_ = reinterpret_cast<const dbl2 *>(QS + (size_t)(k_) * XT_R * XB_SP) + lane; _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) bn[u_] = qn_[64 * u_]; }
+#define XB_WBN() { dbl2 *bw_ = reinterpret_cast<dbl2 *>(brw) + lane; _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) bw_[64 * u_] = bn[u_]; }
     // One sub-block = four stages of 8 NG matrix instructions each, software-pipelined by hand: hipcc issues an LDS read right in front of
     // the instructions that use it (measured: one exposed LDS latency per 4 matrix instructions, 3.5 ms per sweep at 9.4e5 sites where the
     // instructions alone take 1.9), so the operands of the row sums are requested one stage ahead and sched_barriers keep the order:
@@ -252,11 +261,11 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
 #define XB_COL(vv, q, bufi)                                                                                                    \
     {                                                                                                                           \
         double *img_ = tsw + (bufi) * XT_SUB;                                                                                   \
-        if (variant != 4) { _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) *reinterpret_cast<dbl2 *>(img_ + woff[j_]) = vv[j_]; } \
+        if (variant != 4 && variant != 7) { _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) *reinterpret_cast<dbl2 *>(img_ + woff[j_]) = vv[j_]; } \
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                                  \
         __builtin_amdgcn_wave_barrier();                                                                                        \
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                                  \
-        if (variant == 4) {                                                                                                     \
+        if (variant == 4 || variant == 7) {                                                                                     \
             XB_COLH(vv, q, 0) XB_COLH(vv, q, 4)                                                                                 \
             _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_)                                                                    \
                 _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_) {                                                             \
@@ -273,18 +282,42 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
         __builtin_amdgcn_sched_barrier(0);                                                                                      \
         XB_RDROW(R1, q, bufi, 2)                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                                      \
-        XB_ROWH(R0)                                                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                                      \
         XB_COLH(vv, q, 4)                                                                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                                      \
         }                                                                                                                       \
     }
 #define XB_ROW(q, bufi)                                                                                                        \
     {                                                                                                                           \
-        if (variant == 4) { }                                                                                                   \
+        if (variant == 4 || variant == 7) { }                                                                                   \
         else if (variant == 3) { XB_ROW1(Rb) XB_SB() }                                                                          \
-        else { XB_ROWH(R1) __builtin_amdgcn_sched_barrier(0); }                                                                 \
+        else { XB_ROWH(R0) __builtin_amdgcn_sched_barrier(0); XB_ROWH(R1) __builtin_amdgcn_sched_barrier(0); }                  \
     }
+    // PRODUCT FORM (variant 0): the same four stages of 8 NG matrix instructions, but nothing is issued in a burst BETWEEN stages: the LDS reads of the row operands,
+    // the image write of the next sub-block and the stream loads ride INSIDE a stage, spread over its matrix instructions by sched_group_barriers
+    // (an instruction of another pipe issues in the shadow of a matrix instruction; a burst of 12-20 LDS instructions leaves the matrix pipe idle):
+    //   S1: read row operands k 0,1 of q     + COLUMN sums loads 0-3        S3: load sub-block q + 2 into the free set + ROW sums k 0,1
+    //   S2: read row operands k 2,3 of q     + COLUMN sums loads 4-7        S4: write the image of sub-block q + 1   + ROW sums k 2,3
+#define XB_G(mask_, n_) __builtin_amdgcn_sched_group_barrier(mask_, n_, 0);
+#define XB_GREP(cnt_, body_) _Pragma("unroll") for (int gi_ = 0; gi_ < (cnt_); ++gi_) { body_ }
+#define XB_WIMG(vv, bufi)                                                                                                      \
+    {                                                                                                                           \
+        double *img_ = tsw + (bufi) * XT_SUB;                                                                                   \
+        _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) *reinterpret_cast<dbl2 *>(img_ + woff[j_]) = vv[j_];                    \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                                                  \
+        __builtin_amdgcn_wave_barrier();                                                                                        \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                                                  \
+    }
+#define XB_RDBRH(j0)                                                                                                           \
+    _Pragma("unroll") for (int j_ = (j0); j_ < (j0) + 4; ++j_) {                                                                \
+        const int rho_ = 4 * j_ + rr, r32_ = rho_ >> 1;                                                                         \
+        _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_) br[j_][g_] = brw[r32_ * 32 + 2 * (4 * g_ + jv) + (rho_ & 1)];         \
+    }
+    // groups: 0x008 matrix instruction, 0x020 VMEM read, 0x100 LDS read, 0x200 LDS write.  MF = matrix instructions of a stage (8 NG)
+#define XB6_S1(vv, q) { XB_RDROW(R0, q, (q) & 1, 0) XB_COLH(vv, q, 0) XB_GREP(2 + NG, XB_G(0x008, 2) XB_G(0x100, 2)) XB_G(0x008, 8 * NG - 2 * (2 + NG)) } XB_SB()
+#define XB6_S2(vv, q) { XB_RDROW(R1, q, (q) & 1, 2) XB_COLH(vv, q, 4) XB_GREP(2 + NG, XB_G(0x008, 2) XB_G(0x100, 2)) XB_G(0x008, 8 * NG - 2 * (2 + NG)) } XB_SB()
+#define XB6_S3(LOAD, EXTRA, NEX) { LOAD EXTRA XB_ROWH(R0) XB_GREP(8 + (NEX), XB_G(0x008, 1) XB_G(0x020, 1)) XB_G(0x008, 8 * NG - 8 - (NEX)) } XB_SB()
+#define XB6_S4(vo, qn, EXTRA, NEX) { XB_WIMG(vo, (qn) & 1) EXTRA XB_ROWH(R1) XB_GREP(8 + (NEX), XB_G(0x008, 1) XB_G(0x200, 1)) XB_G(0x008, 8 * NG - 8 - (NEX)) } XB_SB()
+#define XB6_SUB(vv, vo, q, LOAD, E3, N3, E4, N4) XB6_S1(vv, q) XB6_S2(vv, q) XB6_S3(LOAD, E3, N3) XB6_S4(vo, (q) + 1, E4, N4)
 #define XB_SUBBLOCK(vv, q, bufi) XB_COL(vv, q, bufi) XB_ROW(q, bufi)
     // The stream is pipelined ACROSS tiles: the first two sub-blocks of the next tile of the run (contiguous in the store) and its panel
     // rows are requested inside the last sub-block of this one -- one wave per SIMD holds two sub-blocks in flight, and a tile that
@@ -331,36 +364,61 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
             const dbl2 *base = reinterpret_cast<const dbl2 *>(tval + (size_t)(td.soff - sub_base) * XT_SUB) + lane;
             XB_LD(va, 0)
             XB_LD(vb, 1)
+            if (variant == 0) XB_WIMG(va, 0)
         }
         bool chain;
+        dbl2 bn[4];
 #pragma unroll 1
         do {
             XTile nxt = td;
             const bool more = t + 1 < it.t1;
-            if (more) nxt = tiles[t + 1];
+            if (variant == 0) nxt = tiles[min(t + 1, it.t1 - 1)];            // the tile itself at the end of the run
+            else if (more) nxt = tiles[t + 1];
             chain = more && nxt.mask == 0xffu;
             double Yr[2][NG];
 #pragma unroll
             for (int g = 0; g < NG; ++g) { Yr[0][g] = 0.0; Yr[1][g] = 0.0; }
             const dbl2 *base = reinterpret_cast<const dbl2 *>(tval + (size_t)(td.soff - sub_base) * XT_SUB) + lane;
-            XB_SUBBLOCK(va, 0, 0)
-            XB_LD(va, 2)
-            XB_SUBBLOCK(vb, 1, 1)
-            XB_LD(vb, 3)
-            XB_SUBBLOCK(va, 2, 0)
-            XB_LD(va, 4)
-            XB_SUBBLOCK(vb, 3, 1)
-            XB_LD(vb, 5)
-            XB_SUBBLOCK(va, 4, 0)
-            XB_LD(va, 6)
-            XB_SUBBLOCK(vb, 5, 1)
-            XB_LD(vb, 7)
-            XB_SUBBLOCK(va, 6, 0)
-            if (chain) { XB_LD(va, 8) }                                     // the next tile's first sub-block
-            XB_COL(vb, 7, 1)
-            if (more) XB_LDBR(nxt.k)                                        // this tile's column sums are issued: the panel registers are free
-            XB_ROW(7, 1)
-            if (chain) { XB_LD(vb, 9) }
+            // (the stream registers of a sub-block are free once its image is written and its COLUMN sums are issued -- the row sums read the image --:
+            // the loads of sub-block n + 2 go out there, a sub-block and a half ahead of their use instead of one: at 1.1 us of matrix work per
+            // sub-block the loaded HBM latency of ~1.8 us was exposed on every sub-block)
+            if (variant == 0) {
+                // No load under a condition in the body of a chain: hipcc's vmcnt counts must assume a conditional load was NOT issued, and the wait
+                // for an older one then waits for it too (round-4 form: a full drain in sub-block 7 and at every tile start).  Past the end of a chain
+                // the two slots re-read the first KiB of this tile (stride 0: cache hits, discarded)
+                const dbl2 *base1 = base;
+                const size_t lstr = chain ? 64 : 0;
+#define XB_LDN(dst, slot) { _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) dst[j_] = NTL ? __builtin_nontemporal_load(base1 + (size_t)(8 * (slot) + j_) * lstr) : base1[(size_t)(8 * (slot) + j_) * lstr]; }
+                XB6_SUB(va, vb, 0, XB_LD(va, 2), , 0, , 0)
+                XB6_SUB(vb, va, 1, XB_LD(vb, 3), XB_LDBN(nxt.k), 4, , 0)
+                XB6_SUB(va, vb, 2, XB_LD(va, 4), , 0, , 0)
+                XB6_SUB(vb, va, 3, XB_LD(vb, 5), , 0, , 0)
+                XB6_SUB(va, vb, 4, XB_LD(va, 6), , 0, , 0)
+                XB6_SUB(vb, va, 5, XB_LD(vb, 7), , 0, XB_WBN(), 4)
+                XB6_SUB(va, vb, 6, XB_LDN(va, 8), , 0, , 0)
+                // the tile's last column sums are issued after S2: the next tile's panel rows come back from LDS inside S3 and S4
+                XB6_S1(vb, 7) XB6_S2(vb, 7)
+                { XB_LDN(vb, 9) XB_RDBRH(0) XB_ROWH(R0)
+                  XB_GREP(4 * NG, XB_G(0x008, 1) XB_G(0x100, 1)) XB_GREP(8, XB_G(0x008, 1) XB_G(0x020, 1)) XB_G(0x008, 4 * NG - 8) } XB_SB()
+                { XB_WIMG(va, 0) XB_RDBRH(4) XB_ROWH(R1)
+                  XB_GREP(8, XB_G(0x008, 1) XB_G(0x200, 1)) XB_GREP(4 * NG, XB_G(0x008, 1) XB_G(0x100, 1)) XB_G(0x008, 4 * NG - 8) } XB_SB()
+#undef XB_LDN
+            } else {
+                // round-4 form
+                XB_COL(va, 0, 0) XB_LD(va, 2) XB_ROW(0, 0)
+                XB_COL(vb, 1, 1) XB_LD(vb, 3) XB_ROW(1, 1)
+                XB_COL(va, 2, 0) XB_LD(va, 4) XB_ROW(2, 0)
+                XB_COL(vb, 3, 1) XB_LD(vb, 5) XB_ROW(3, 1)
+                XB_COL(va, 4, 0) XB_LD(va, 6) XB_ROW(4, 0)
+                XB_COL(vb, 5, 1) XB_LD(vb, 7) XB_ROW(5, 1)
+                XB_COL(va, 6, 0)
+                if (chain) { XB_LD(va, 8) }                                 // the next tile's first sub-block
+                XB_ROW(6, 0)
+                XB_COL(vb, 7, 1)
+                if (more) XB_LDBR(nxt.k)                                    // this tile's column sums are issued: the panel registers are free
+                if (chain) { XB_LD(vb, 9) }
+                XB_ROW(7, 1)
+            }
             XB_ROWSUMS()
             td = nxt;
             ++t;
@@ -369,6 +427,8 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
 #undef XB_ROWSUMS
 #undef XB_LD
 #undef XB_LDBR
+#undef XB_LDBN
+#undef XB_WBN
 #undef XB_COL
 #undef XB_ROW
 #undef XB_RD1
@@ -379,6 +439,15 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
 #undef XB_COLH
 #undef XB_ROWH
 #undef XB_SUBBLOCK
+#undef XB_G
+#undef XB_GREP
+#undef XB_WIMG
+#undef XB_RDBRH
+#undef XB6_S1
+#undef XB6_S2
+#undef XB6_S3
+#undef XB6_S4
+#undef XB6_SUB
     // one record of column sums per workgroup: the four waves' accumulators are added in a fixed order through LDS, four sub-block
     // positions per round.  Yc[q][e][g] of lane (block n = blk, i = rr, j = jv) is column 32 q + 8 n + 2 i + e, vector 4 g + jv.
     double *rec = colpartB + (size_t)it.pad * XT_C * so;
@@ -1145,11 +1214,13 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
             (void)hipEventRecord(S.b[sl], S.st);
         }
         if (ntb > 0) {
-#define XB_APPLY(NTL_, NG_) hipExtLaunchKernelGGL((k_xtb_apply<NTL_, NG_>), dim3(ntb), dim3(XT_NT), 0, st, e0, e1, 0, A.item_n, A.items, A.tiles, A.sub_base, A.tval, \
-                                                  (const double *)QS, A.nW, rowpartB, colpartB, (const XCtrl *)A.ctrl)
+#define XB_APPLY_ARGS_ A.item_n, A.items, A.tiles, A.sub_base, A.tval, (const double *)QS, A.nW, rowpartB, colpartB, (const XCtrl *)A.ctrl
+#define XB_APPLY(NTL_, NG_) do { if (e.x_apply_form == 1) hipExtLaunchKernelGGL((k_xtb_apply<NTL_, NG_, 8>), dim3(ntb), dim3(XT_NT), 0, st, e0, e1, 0, XB_APPLY_ARGS_); \
+                                 else hipExtLaunchKernelGGL((k_xtb_apply<NTL_, NG_>), dim3(ntb), dim3(XT_NT), 0, st, e0, e1, 0, XB_APPLY_ARGS_); } while (0)
             if (A.nt_loads) { if (so == 4) XB_APPLY(1, 1); else if (so == 8) XB_APPLY(1, 2); else if (so == 12) XB_APPLY(1, 3); else XB_APPLY(1, 4); }
             else { if (so == 4) XB_APPLY(0, 1); else if (so == 8) XB_APPLY(0, 2); else if (so == 12) XB_APPLY(0, 3); else XB_APPLY(0, 4); }
 #undef XB_APPLY
+#undef XB_APPLY_ARGS_
         }
         if (side) (void)hipStreamWaitEvent(st, g_xb_side.b[sl], 0);           // the sparse sums are in T before the row kernel reads them
         else hipLaunchKernelGGL(k_xtb_neigh, dim3(nnb), dim3(XT_NT), 0, st, m, A.rp, A.ci, A.val, (const double *)P, A.sc, A.nsrank, (const XCtrl *)A.ctrl, T, drvpart);
@@ -1304,8 +1375,9 @@ extern "C" int dkmc_xtb_check_product(int width, double *max_abs_diff, double *m
     HIPCHK(hipMemsetAsync(colpartB, 0, (size_t)(nrec + 1) * XT_C * so * 8, st));
     HIPCHK(hipMemsetAsync(ctrl, 0, sizeof(XCtrl), st));
     hipLaunchKernelGGL(k_xtb_test_panel, dim3((ns * XB_SP + 255) / 256), dim3(256), 0, st, ns, QS);
-#define XB_APPLY(NG_) hipLaunchKernelGGL((k_xtb_apply<1, NG_>), dim3((X.item_n + 3) / 4), dim3(XT_NT), 0, st, X.item_n, (const XItem *)g_xb.items + X.item_lo, (const XTile *)g_xb.tiles, \
-                       (int)X.sub_base, (const double *)g_xb.tval, (const double *)QS, X.nW, rowpartB, colpartB, (const XCtrl *)ctrl)
+#define XB_APPLY_ARGS_ X.item_n, (const XItem *)g_xb.items + X.item_lo, (const XTile *)g_xb.tiles, (int)X.sub_base, (const double *)g_xb.tval, (const double *)QS, X.nW, rowpartB, colpartB, (const XCtrl *)ctrl
+#define XB_APPLY(NG_) do { if (e.x_apply_form == 1) hipLaunchKernelGGL((k_xtb_apply<1, NG_, 8>), dim3((X.item_n + 3) / 4), dim3(XT_NT), 0, st, XB_APPLY_ARGS_); \
+                           else hipLaunchKernelGGL((k_xtb_apply<1, NG_>), dim3((X.item_n + 3) / 4), dim3(XT_NT), 0, st, XB_APPLY_ARGS_); } while (0)
     if (so == 4) XB_APPLY(1); else if (so == 8) XB_APPLY(2); else if (so == 12) XB_APPLY(3); else XB_APPLY(4);
 #undef XB_APPLY
     hipLaunchKernelGGL((k_xtb_rows<1, 0>), dim3(ng), dim3(XT_NT), 0, st, ns, X.nK, X.nW, m, s, so, (const int2 *)g_xb.wrange, (const int *)g_xb.nitem_w, (const double *)rowpartB,
@@ -1348,12 +1420,12 @@ extern "C" int dkmc_xtb_time_apply(int width, int variant, int reps, double *us)
     hipEvent_t e0, e1; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     for (int r = -1; r < reps; ++r) {
         if (r == 0) HIPCHK(hipEventRecord(e0, st));
-#define XB_APPLY(NG_, V_) hipLaunchKernelGGL((k_xtb_apply<1, NG_, V_>), dim3((X.item_n + 3) / 4), dim3(XT_NT), 0, st, X.item_n, (const XItem *)g_xb.items + X.item_lo, (const XTile *)g_xb.tiles, \
-                       (int)X.sub_base, (const double *)g_xb.tval, (const double *)QS, X.nW, rowpartB, colpartB, (const XCtrl *)ctrl)
+#define XB_APPLY(NG_, V_) do { if (e.x_apply_form == 1 && (V_) == 0) hipLaunchKernelGGL((k_xtb_apply<1, NG_, 8>), dim3((X.item_n + 3) / 4), dim3(XT_NT), 0, st, XB_APPLY_ARGS_); \
+                               else hipLaunchKernelGGL((k_xtb_apply<1, NG_, V_>), dim3((X.item_n + 3) / 4), dim3(XT_NT), 0, st, XB_APPLY_ARGS_); } while (0)
         if (so == 4) XB_APPLY(1, 0);
         else if (so == 8) { if (variant == 1) XB_APPLY(2, 1); else if (variant == 2) XB_APPLY(2, 2); else XB_APPLY(2, 0); }
         else if (so == 12) XB_APPLY(3, 0);
-        else { if (variant == 1) XB_APPLY(4, 1); else if (variant == 2) XB_APPLY(4, 2); else if (variant == 3) XB_APPLY(4, 3); else if (variant == 4) XB_APPLY(4, 4); else XB_APPLY(4, 0); }
+        else { if (variant == 1) XB_APPLY(4, 1); else if (variant == 2) XB_APPLY(4, 2); else if (variant == 3) XB_APPLY(4, 3); else if (variant == 4) XB_APPLY(4, 4); else if (variant == 7) XB_APPLY(4, 7); else XB_APPLY(4, 0); }
 #undef XB_APPLY
     }
     HIPCHK(hipEventRecord(e1, st));

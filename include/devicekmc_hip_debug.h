@@ -25,9 +25,14 @@ int dkmc_xt_check_shares(int nranks, double *max_abs_diff, double *max_abs, long
  * sweep) against 16 passes of the single-vector tile kernel; largest absolute deviation and largest sum over the S rows. */
 int dkmc_xtb_check_product(int width, double *max_abs_diff, double *max_abs);
 /* Measurement aid: average duration [us] of the tile x panel kernel of the block-CG over the X left resident by the last single-GPU solve
- * (`reps` launches).  variant 0: as a solve runs it; 1: without its matrix instructions (tile stream + LDS traffic); 2: without re-reading
- * the tile stream (matrix instructions + LDS traffic). */
+ * (`reps` launches).  variant 0: as a solve runs it; on the round-4 form of the loop: 1: without its matrix instructions (tile stream + LDS
+ * traffic); 2: without re-reading the tile stream (matrix instructions + LDS traffic); 3: operand stages of one k-pair; 4: without LDS
+ * traffic; 7: the matrix instructions alone. */
 int dkmc_xtb_time_apply(int width, int variant, int reps, double *us);
+/* Same-box comparison aid: 1 = the solves (and variant 0 above) run the round-4 form of the tile x panel loop (stages issued in bursts,
+ * conditional loads at the tile end, panel rows loaded directly) instead of the product form; same results bit for bit.  Default 0. */
+void dkmc_set_x_apply_form(int form);
+int dkmc_get_x_apply_form(void);
 /* Test aid for the error path of a sharded current solve (no counterpart in the reference): the calling rank fails ONCE, in the
  * assembly of X (phase 1) or on the host side of CG iteration `iteration` (phase 2).  Every rank's dkmc_update_power_gpu_sparse then
  * returns non-zero (the failing rank its own code, the others 46) instead of blocking in a collective: the ranks agree on the

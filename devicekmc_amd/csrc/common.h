@@ -120,6 +120,7 @@ struct Engine {
     int x_slab = 1;                // > 1 rank: distribute the STATE of the block-CG by row slabs (xtb_slab.inc; dkmc_set_x_slab); 0: all-gather variant (tile stream sharded only)
     int k_slab = 1;                // > 1 rank, system above the size of the blocked form: CG on K distributed by row slabs (kcg.hip; dkmc_set_k_slab); 0: replicated
     int x_aux_warm = 0;            // 1: with the warm start of the current solve the hash auxiliary columns start from the previous solve's solutions too (dkmc_set_x_aux_warm; off: no gain beyond 1e4 rows, profiles/r05_ab_aux_warm.json)
+    int x_items_kc = 0;            // > 0: overrides the nominal run length kc (tiles) of the tile runs (dkmc_set_x_items; measurement)
     int x_apply_form = 0;          // tile x panel kernel of the block-CG: 0 = the product form, 1 = the round-4 form of its loop (same results; same-box comparisons, dkmc_set_x_apply_form)
     int x_block = 16;              // block-CG width of the current solve on the tiled X (dkmc_set_x_block; xtb.hip): 16 by default, 1 = the reference's single-vector loop (its iterate sequence)
     int x_format = 1;              // 1: tiled X (xt.hip, default); 0: CSR X as the reference stores it (current.hip + cg.hip)

@@ -1097,6 +1097,7 @@ int xt_assemble_and_solve(dkmc_gpubuf *buf, const XParams &P, int ns, const SEnt
             hipLaunchKernelGGL(k_xt_wrange, dim3((nK + 255) / 256), dim3(256), 0, st, nK, nW, (const unsigned *)cmask, wrange);
         }
         XShare sh{};
+        if (e.x_items_kc > 0) X.kc = e.x_items_kc;
         rc = xt_build_items(nK, nW, X.kc, ntiles, X.nsub_total, toff, tiles, nr, me, S_XT_NITEMW, S_XT_ITEMS, S_XT_SPLIT, &sh, 2); if (rc) return rc;
         if ((sh.item_lo | sh.item_n) & 3) return dkmc_fail(48, "update_power: run list not padded to groups of four", __FILE__, __LINE__);
         X.nitems = sh.nitems; X.maxchunk = sh.maxchunk; X.rec_shift = sh.rec_shift;
@@ -1358,6 +1359,30 @@ int xt_power(dkmc_gpubuf *buf, const XParams &P, const int *aflag, const int *at
 // iteration: the apply kernel over that rank's share of the work items (built with the work-item size an nranks run uses) plus the
 // neighbour part, and the three kernels around the exchange (partial row sums, finish, vector step).  The exchange itself (one
 // all-reduce of |S| + 1 doubles) cannot be measured on one GPU.  Vectors are scratch: the numbers computed here are discarded.
+// Measurement aid: how the resident X fills its tiles -- hist[c] = tiles with c of their 8 sub-blocks present (c = 0 .. 8), hist[9] = tiles that sit in a
+// chain of full tiles of length >= 2 inside a run (what the product kernel streams with sub-blocks in flight), hist[10] = runs
+extern "C" int dkmc_xt_tile_census(long long *hist)
+{
+    Engine &e = eng(); const XTState &X = g_xt;
+    if (!X.valid || X.ntiles <= 0 || !hist) return dkmc_fail(13, "xt_tile_census: needs the X of a solve", __FILE__, __LINE__);
+    std::vector<XTile> t((size_t)X.ntiles);
+    HIPCHK(hipStreamSynchronize(e.stream));
+    HIPCHK(hipMemcpy(t.data(), g_xb.tiles, (size_t)X.ntiles * sizeof(XTile), hipMemcpyDeviceToHost));
+    for (int c = 0; c < 11; ++c) hist[c] = 0;
+    for (const XTile &x : t) hist[__builtin_popcount(x.mask & 0xffu)]++;
+    std::vector<XItem> it((size_t)X.nitems);
+    HIPCHK(hipMemcpy(it.data(), g_xb.items, (size_t)X.nitems * sizeof(XItem), hipMemcpyDeviceToHost));
+    for (const XItem &r : it) {
+        if (r.t1 <= r.t0) continue;
+        hist[10]++;
+        int run = 0;
+        for (int q = r.t0; q <= r.t1; ++q) {
+            const bool full = q < r.t1 && (t[(size_t)q].mask & 0xffu) == 0xffu;
+            if (full) ++run; else { if (run >= 2) hist[9] += run; run = 0; }
+        }
+    }
+    return 0;
+}
 extern "C" int dkmc_xt_time_share(int nranks, int rank, int reps, double *apply_us, double *side_us, int *items_out, long long *subblocks_out)
 {
     Engine &e = eng(); hipStream_t st = e.stream; const XTState &X = g_xt;

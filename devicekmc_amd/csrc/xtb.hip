@@ -149,11 +149,13 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
     // panel rows loaded directly), kept for same-box comparisons (dkmc_set_x_apply_form(1) = variant 8, same results as 0) and as the carrier of the
     // measurement variants of dkmc_xtb_time_apply: 1 = no matrix instructions (stream + LDS traffic only), 2 = the tile stream is not re-read
     // (matrix instructions + LDS traffic only), 3 = operand stages of one k-pair, 4 = no LDS traffic (the row sums replaced by as many products on
-    // the loaded registers), 7 = 2 and 4 together (the matrix instructions alone); the results of 1, 2, 4 and 7 are meaningless
+    // the loaded registers), 7 = 2 and 4 together (the matrix instructions alone); 10 = the PRODUCT form without re-reading the tile stream; the
+    // results of 1, 2, 4, 7 and 10 are meaningless
     constexpr int so = 4 * NG;                                                 // vectors per row of the partial-sum arrays
+    constexpr bool PF = variant == 0 || variant == 10 || variant == 12;        // product form of the loop (12, measurement: partial tiles skipped)
     __shared__ __attribute__((aligned(16))) double qc[XT_C * XB_SP];          // the strip's 256 panel rows in QS order (32 KiB)
     __shared__ __attribute__((aligned(16))) double ts[4 * 2 * XT_SUB];        // per wave: two sub-block images (2 x 8 KiB)
-    __shared__ __attribute__((aligned(16))) double brs[variant == 0 ? 4 * XT_R * XB_SP : 2];   // per wave: the next tile's 32 panel rows (4 KiB)
+    __shared__ __attribute__((aligned(16))) double brs[PF ? 4 * XT_R * XB_SP : 2];   // per wave: the next tile's 32 panel rows (4 KiB)
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63, cc = lane & 15, rr = lane >> 4, jv = lane & 3, blk = cc >> 2;
     const int item = (int)blockIdx.x * 4 + wv;
@@ -168,7 +170,7 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
     }
     __syncthreads();
     double *tsw = ts + (size_t)wv * 2 * XT_SUB;
-    double *brw = brs + (variant == 0 ? (size_t)wv * XT_R * XB_SP : 0);
+    double *brw = brs + (PF ? (size_t)wv * XT_R * XB_SP : 0);
     double Yc[8][2][NG];
 #pragma unroll
     for (int q = 0; q < 8; ++q)
@@ -186,7 +188,7 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
     int qoff[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) qoff[g] = rr * 32 + ((2 * (4 * g + jv)) ^ (rr << 3));      // + (16 q + 4 kk) * 32
-#define XB_LD(dst, slot) if ((variant != 2 && variant != 7) || (slot) < 2) { _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) dst[j_] = NTL ? __builtin_nontemporal_load(base + (size_t)(8 * (slot) + j_) * 64) : base[(size_t)(8 * (slot) + j_) * 64]; }
+#define XB_LD(dst, slot) if ((variant != 2 && variant != 7 && variant != 10) || (slot) < 2) { _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) dst[j_] = NTL ? __builtin_nontemporal_load(base + (size_t)(8 * (slot) + j_) * 64) : base[(size_t)(8 * (slot) + j_) * 64]; }
     // panel operands of the column sums: rows 4 j + rr of a tile's 32 panel rows, vectors 4 g + jv (the same in all four blocks)
 #define XB_LDBR(k_)                                                                                                            \
     {                                                                                                                           \
@@ -309,7 +311,7 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
     }
 #define XB_RDBRH(j0)                                                                                                           \
     _Pragma("unroll") for (int j_ = (j0); j_ < (j0) + 4; ++j_) {                                                                \
-        const int rho_ = 4 * j_ + rr, r32_ = rho_ >> 1;                                                                         \
+        const int rho_ = 4 * j_ + rr; const int r32_ = rho_ >> 1;                                                                          \
         _Pragma("unroll") for (int g_ = 0; g_ < NG; ++g_) br[j_][g_] = brw[r32_ * 32 + 2 * (4 * g_ + jv) + (rho_ & 1)];         \
     }
     // groups: 0x008 matrix instruction, 0x020 VMEM read, 0x100 LDS read, 0x200 LDS write.  MF = matrix instructions of a stage (8 NG)
@@ -345,7 +347,7 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
             int sl = 0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                if ((td.mask >> q) & 1u) {
+                if (variant != 12 && ((td.mask >> q) & 1u)) {
                     dbl2 vp[8];
                     XB_LD(vp, sl)
                     XB_SUBBLOCK(vp, q, q & 1)
@@ -364,7 +366,7 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
             const dbl2 *base = reinterpret_cast<const dbl2 *>(tval + (size_t)(td.soff - sub_base) * XT_SUB) + lane;
             XB_LD(va, 0)
             XB_LD(vb, 1)
-            if (variant == 0) XB_WIMG(va, 0)
+            if (PF) XB_WIMG(va, 0)
         }
         bool chain;
         dbl2 bn[4];
@@ -372,7 +374,7 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
         do {
             XTile nxt = td;
             const bool more = t + 1 < it.t1;
-            if (variant == 0) nxt = tiles[min(t + 1, it.t1 - 1)];            // the tile itself at the end of the run
+            if (PF) nxt = tiles[min(t + 1, it.t1 - 1)];            // the tile itself at the end of the run
             else if (more) nxt = tiles[t + 1];
             chain = more && nxt.mask == 0xffu;
             double Yr[2][NG];
@@ -382,13 +384,13 @@ void k_xtb_apply(int nitems, const XItem *__restrict__ items, const XTile *__res
             // (the stream registers of a sub-block are free once its image is written and its COLUMN sums are issued -- the row sums read the image --:
             // the loads of sub-block n + 2 go out there, a sub-block and a half ahead of their use instead of one: at 1.1 us of matrix work per
             // sub-block the loaded HBM latency of ~1.8 us was exposed on every sub-block)
-            if (variant == 0) {
+            if (PF) {
                 // No load under a condition in the body of a chain: hipcc's vmcnt counts must assume a conditional load was NOT issued, and the wait
                 // for an older one then waits for it too (round-4 form: a full drain in sub-block 7 and at every tile start).  Past the end of a chain
                 // the two slots re-read the first KiB of this tile (stride 0: cache hits, discarded)
                 const dbl2 *base1 = base;
                 const size_t lstr = chain ? 64 : 0;
-#define XB_LDN(dst, slot) { _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) dst[j_] = NTL ? __builtin_nontemporal_load(base1 + (size_t)(8 * (slot) + j_) * lstr) : base1[(size_t)(8 * (slot) + j_) * lstr]; }
+#define XB_LDN(dst, slot) if (variant != 10) { _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) dst[j_] = NTL ? __builtin_nontemporal_load(base1 + (size_t)(8 * (slot) + j_) * lstr) : base1[(size_t)(8 * (slot) + j_) * lstr]; }
                 XB6_SUB(va, vb, 0, XB_LD(va, 2), , 0, , 0)
                 XB6_SUB(vb, va, 1, XB_LD(vb, 3), XB_LDBN(nxt.k), 4, , 0)
                 XB6_SUB(va, vb, 2, XB_LD(va, 4), , 0, , 0)
@@ -1425,7 +1427,7 @@ extern "C" int dkmc_xtb_time_apply(int width, int variant, int reps, double *us)
         if (so == 4) XB_APPLY(1, 0);
         else if (so == 8) { if (variant == 1) XB_APPLY(2, 1); else if (variant == 2) XB_APPLY(2, 2); else XB_APPLY(2, 0); }
         else if (so == 12) XB_APPLY(3, 0);
-        else { if (variant == 1) XB_APPLY(4, 1); else if (variant == 2) XB_APPLY(4, 2); else if (variant == 3) XB_APPLY(4, 3); else if (variant == 4) XB_APPLY(4, 4); else if (variant == 7) XB_APPLY(4, 7); else XB_APPLY(4, 0); }
+        else { if (variant == 1) XB_APPLY(4, 1); else if (variant == 2) XB_APPLY(4, 2); else if (variant == 3) XB_APPLY(4, 3); else if (variant == 4) XB_APPLY(4, 4); else if (variant == 7) XB_APPLY(4, 7); else if (variant == 10) XB_APPLY(4, 10); else if (variant == 12) XB_APPLY(4, 12); else XB_APPLY(4, 0); }
 #undef XB_APPLY
     }
     HIPCHK(hipEventRecord(e1, st));

@@ -8,7 +8,7 @@
 #define XT_SBW 32                    // columns per sub-block
 #define XT_SUB (XT_R * XT_SBW)       // doubles per sub-block (8 KiB)
 #define XT_NT 256
-#define XT_MAXKC 16
+#define XT_MAXKC 32
 #define XT_PROF_STRIDE 8
 
 typedef double dbl2 __attribute__((ext_vector_type(2)));

@@ -27,8 +27,14 @@ int dkmc_xtb_check_product(int width, double *max_abs_diff, double *max_abs);
 /* Measurement aid: average duration [us] of the tile x panel kernel of the block-CG over the X left resident by the last single-GPU solve
  * (`reps` launches).  variant 0: as a solve runs it; on the round-4 form of the loop: 1: without its matrix instructions (tile stream + LDS
  * traffic); 2: without re-reading the tile stream (matrix instructions + LDS traffic); 3: operand stages of one k-pair; 4: without LDS
- * traffic; 7: the matrix instructions alone. */
+ * traffic; 7: the matrix instructions alone; 10: the product form without re-reading the tile stream. */
 int dkmc_xtb_time_apply(int width, int variant, int reps, double *us);
+/* Measurement aid: how the resident X fills its tiles -- hist[c] = tiles with c of their 8 sub-blocks present (c = 0 .. 8), hist[9] = tiles inside a
+ * chain (>= 2) of full tiles of a run, hist[10] = runs.  hist: 11 entries. */
+int dkmc_xt_tile_census(long long *hist);
+/* Measurement aid for the run list of the tile kernels (takes effect at the next assembly of X): kc > 0 overrides the nominal run length in tiles
+ * (default min(32, tiles / ranks / 4096)); 0 restores it. */
+void dkmc_set_x_items(int kc);
 /* Same-box comparison aid: 1 = the solves (and variant 0 above) run the round-4 form of the tile x panel loop (stages issued in bursts,
  * conditional loads at the tile end, panel rows loaded directly) instead of the product form; same results bit for bit.  Default 0. */
 void dkmc_set_x_apply_form(int form);

@@ -1,5 +1,5 @@
-# round 5: what k_xtb_apply is made of, same box, same launch: dkmc_xtb_time_apply with the measurement variants (1 = no matrix instructions, 2 = no stream
-# re-read, 4 = no LDS traffic, 7 = matrix instructions alone) beside the product kernel and the round-4 form of its loop (dkmc_set_x_apply_form 0 / 1); the variants ride on the round-4 form
+# round 5: what k_xtb_apply is made of, same box, same launch: dkmc_xtb_time_apply with the measurement variants (2 = no stream
+# re-read, 4 = no LDS traffic, 7 = matrix instructions alone, 10 = the product form without the stream re-read) beside the product kernel and the round-4 form of its loop (dkmc_set_x_apply_form 0 / 1); the variants ride on the round-4 form
 mkdir -p gpurun_out/r05
 python3 - <<'PY' 2>gpurun_out/r05/apply_parts.err | tee -a gpurun_out/r05/apply_parts.log
 import ctypes as C, json, sys
@@ -19,7 +19,7 @@ for rep in (1, 2):
         sim.L.dkmc_set_x_apply_form(form)
         out["product_form_%d_us" % form] = t(16, 0)
     sim.L.dkmc_set_x_apply_form(0)
-    for v in (1, 2, 4, 7):
+    for v in (2, 4, 7, 10, 12):
         out["variant_%d_us" % v] = t(16, v)
     print(json.dumps(out), flush=True)
 PY

@@ -6,7 +6,7 @@
 // reads cost more than the freed registers buy.  Hot loop: 1024 matrix instructions, no scratch, vmcnt waits all >= 24 (35.5 KB of code).
 // ---- tiles x panel, four sub-blocks in flight (round 5) -------------------------------------------------------------------------------------
 // Same product, same lane maps, same partial-sum outputs as k_xtb_apply; what differs is how the tile stream reaches the matrix pipe.  Counters
-// of k_xtb_apply at 2.3e5 sites (profiles/r05_pmc_apply_wave_cycles.json): matrix pipe busy 47 % of the wave cycles, 45 % of them spent in
+// of k_xtb_apply at 2.3e5 sites (profiles/r05_pmc_apply_wave_cycles_round4_loop.json): matrix pipe busy 47 % of the wave cycles, 45 % of them spent in
 // s_waitcnt of which 3.6 % on LDS -- the waves wait for the tile stream.  Three causes, three changes:
 //  * with the COLUMN sums fed from the stream's registers a wave could keep only two sub-blocks (16 KiB) in flight.  Here ALL operands of the
 //    matrix instructions come from the LDS image (the column sums read it back in the lane map it was written in: conflict-free), so a stream

@@ -46,13 +46,19 @@ def test_tile_panel_product_matches_single_vector_kernel(cell_2p5, dev_7p5, hip,
         L.dkmc_set_x_block(1)
         dev, sim, gb, _ = _fresh_device(structure, p, hip)
         dev.updateCharge(gb); dev.updatePotential(gb, p, Vd, 0); dev.updatePower(gb, p, Vd)
-        for width in (16, 12, 8, 4):
-            d, a = C.c_double(-1), C.c_double(-1)
-            from devicekmc_amd.lib import check
-            check(L.dkmc_xtb_check_product(width, C.byref(d), C.byref(a)))
-            assert a.value > 0 and d.value <= 1e-12 * a.value, (width, d.value, a.value)
+        from devicekmc_amd.lib import check
+        # the tiles the product runs over: full and partial ones (the loop takes the two kinds on different paths)
+        h = (C.c_longlong * 11)()
+        check(L.dkmc_xt_tile_census(h))
+        assert sum(h[:9]) > 0 and h[0] == 0 and h[8] > 0 and sum(h[1:8]) > 0, list(h)
+        for form in (0, 1):                                  # 0: the product form of the loop, 1: the round-4 form (same sums, same order)
+            L.dkmc_set_x_apply_form(form)
+            for width in (16, 12, 8, 4):
+                d, a = C.c_double(-1), C.c_double(-1)
+                check(L.dkmc_xtb_check_product(width, C.byref(d), C.byref(a)))
+                assert a.value > 0 and d.value <= 1e-12 * a.value, (form, width, d.value, a.value)
     finally:
-        L.dkmc_set_x_block(16)
+        L.dkmc_set_x_block(16); L.dkmc_set_x_apply_form(0)
 
 
 def test_block_cg_agrees_with_single_vector_cg_7p5(dev_7p5, hip):

@@ -98,8 +98,7 @@ __global__ __launch_bounds__(CG_NT) void k_spmv(int nrows, const int *__restrict
         } else if (MODE == M_DIAG) {                     // s = 1/sqrt(diag); x *= s; y /= s (:227-306)
             double d = 0.0;
             for (RP p = p0 + l; p < p1; p += LPR) if (ci[p] == row) d = a[p];
-#pragma unroll
-            for (int off = LPR / 2; off > 0; off >>= 1) d += __shfl_xor(d, off, LPR);
+            d = group_sum<LPR>(d);
             if (l == 0) {
                 const double s = 1.0 / sqrt(d);
                 vout[row] = s;
@@ -109,8 +108,7 @@ __global__ __launch_bounds__(CG_NT) void k_spmv(int nrows, const int *__restrict
         } else {
             double s = 0.0;
             for (RP p = p0 + l; p < p1; p += LPR) s += a[p] * vin[ci[p]];
-#pragma unroll
-            for (int off = LPR / 2; off > 0; off >>= 1) s += __shfl_xor(s, off, LPR);
+            s = group_sum<LPR>(s);
             if (l == 0) {
                 if (MODE == M_INIT) {                    // r = A y - x ; p = -r
                     const double r = -aux0[row] + s;
@@ -158,8 +156,7 @@ __global__ __launch_bounds__(SPMV_NT) void k_spmv_ap(int n_short, const int *__r
             const RP p0 = rp[row], p1 = rp[row + 1];
             double s = 0.0;
             for (RP q = p0 + l; q < p1; q += 16) s += a[q] * p[ci[q]];
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+            s = group_sum<16>(s);
             if (l == 0) { t[row] = s; acc += p[row] * s; }
         }
     } else if (RUNS) {
@@ -173,8 +170,7 @@ __global__ __launch_bounds__(SPMV_NT) void k_spmv_ap(int n_short, const int *__r
             const int nsg = nruns[ridx];
             const double *sp = pS + seg_off[ridx];            // pS slot carries the segment partials in this mode
             for (int j = l; j < nsg; j += 16) s += sp[j];
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+            s = group_sum<16>(s);
             if (l == 0) { t[row] = s; acc += p[row] * s; }
         }
     } else {
@@ -222,8 +218,7 @@ __global__ __launch_bounds__(SPMV_NT) void k_rowsum_owner(int row_lo, int row_hi
         const int nsg = nruns[ridx];
         const double *sp = seg_part + seg_off[ridx];
         for (int j = l; j < nsg; j += 16) s += sp[j];
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+        s = group_sum<16>(s);
         if (l == 0) mine[ridx - row_lo] = s;
     }
 }
@@ -423,8 +418,7 @@ __global__ __launch_bounds__(SEGK_NT) void k_spmv_segs(int nseg, const RunDesc *
             double s = 0.0;
             const RP p0 = rp[row], p1 = rp[row + 1];
             for (RP q = p0 + l; q < p1; q += 16) s += a[q] * p[ci[q]];
-#pragma unroll
-            for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+            s = group_sum<16>(s);
             if (l == 0) { t[row] = s; acc += p[row] * s; }
         }
         const double tot = block_sum_all<SEGK_NT>(acc, red);

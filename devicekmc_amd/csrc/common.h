@@ -49,25 +49,54 @@ __device__ __forceinline__ double v_solve(double r, int charge, double sigma, do
     return (double)charge * erfc(r / (sigma * sqrt(2.0))) * k * DKMC_Q / r;
 }
 
-// ---- wave64 / block reductions with a fixed combination order (deterministic) -----------------
-__device__ __forceinline__ double wave_sum(double v)
+// ---- lane exchange without the LDS ------------------------------------------------------------
+// hipcc lowers every __shfl_xor to ds_bpermute_b32 -- an LDS instruction per 32 bits, two per double.  Inside a row of 16 lanes the exchange
+// "lane i <- lane i ^ OFF" (OFF = 1, 2, 4, 8) is a DPP move on the vector ALU (tools/probe_dpp_xor.hip: identical to __shfl_xor on gfx950); the
+// per-row reductions of the sparse kernels were bound by the bpermutes, not by their memory traffic.  Offsets 16 / 32 stay on __shfl_xor.
+template <int OFF> __device__ __forceinline__ int xor_lane_i(int x)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
-    return v;   // valid in lane 0
+    static_assert(OFF == 1 || OFF == 2 || OFF == 4 || OFF == 8 || OFF == 16 || OFF == 32, "xor_lane: power of two below the wave size");
+    if constexpr (OFF == 1) return __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);        // quad_perm [1,0,3,2]
+    else if constexpr (OFF == 2) return __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    else if constexpr (OFF == 4) {                                                                   // row_shl:4 into banks 0, 2; row_shr:4 into banks 1, 3
+        const int t = __builtin_amdgcn_update_dpp(0, x, 0x104, 0xf, 0x5, false);
+        return __builtin_amdgcn_update_dpp(t, x, 0x114, 0xf, 0xa, false);
+    }
+    else if constexpr (OFF == 8) return __builtin_amdgcn_update_dpp(0, x, 0x128, 0xf, 0xf, false);  // row_ror:8
+    else return __shfl_xor(x, OFF, WAVE);
 }
-__device__ __forceinline__ double wave_sum_all(double v)
+template <int OFF> __device__ __forceinline__ double xor_lane(double x)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
-    return v;   // same value in every lane
+    if constexpr (OFF >= 16) return __shfl_xor(x, OFF, WAVE);
+    else return __hiloint2double(xor_lane_i<OFF>(__double2hiint(x)), xor_lane_i<OFF>(__double2loint(x)));
 }
-__device__ __forceinline__ int wave_sum_all_i(int v)
+// butterfly sum over groups of W lanes (W a power of two), offsets W / 2, ..., 1 in that order: every lane of a group ends with the group's sum
+template <int W> __device__ __forceinline__ double group_sum(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    if constexpr (W >= 64) v += xor_lane<32>(v);
+    if constexpr (W >= 32) v += xor_lane<16>(v);
+    if constexpr (W >= 16) v += xor_lane<8>(v);
+    if constexpr (W >= 8) v += xor_lane<4>(v);
+    if constexpr (W >= 4) v += xor_lane<2>(v);
+    if constexpr (W >= 2) v += xor_lane<1>(v);
     return v;
 }
+template <int W> __device__ __forceinline__ int group_sum_i(int v)
+{
+    if constexpr (W >= 64) v += xor_lane_i<32>(v);
+    if constexpr (W >= 32) v += xor_lane_i<16>(v);
+    if constexpr (W >= 16) v += xor_lane_i<8>(v);
+    if constexpr (W >= 8) v += xor_lane_i<4>(v);
+    if constexpr (W >= 4) v += xor_lane_i<2>(v);
+    if constexpr (W >= 2) v += xor_lane_i<1>(v);
+    return v;
+}
+
+// ---- wave64 / block reductions with a fixed combination order (deterministic) -----------------
+// (lane 0 of the butterfly sees the same additions in the same order as the shift-down form it replaces: same bits)
+__device__ __forceinline__ double wave_sum(double v) { return group_sum<WAVE>(v); }       // valid in lane 0 (and everywhere)
+__device__ __forceinline__ double wave_sum_all(double v) { return group_sum<WAVE>(v); }   // same value in every lane
+__device__ __forceinline__ int wave_sum_all_i(int v) { return group_sum_i<WAVE>(v); }
 // inclusive scan across the wave
 __device__ __forceinline__ double wave_scan_incl(double v, int lane)
 {

@@ -380,8 +380,7 @@ __global__ __launch_bounds__(256) void k_power(int Na, int nrows, const int *__r
         if ((ical < 0 && Vd > 0) || (ical > 0 && Vd < 0)) v = -ical;
         p += v * (m[c] - mi);
     }
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) p += __shfl_xor(p, o, LPR);
+    p = group_sum<LPR>(p);
     const int a = i - 2;
     if (l == 0 && !(aflag[a] & AF_METAL)) site_power[atom_site[a]] = -1 * alpha * p;
 }

@@ -60,8 +60,7 @@ __global__ __launch_bounds__(KC_NT) void k_kc_assemble(int m, int N_left, const 
     const bool cut = CB == 2 && k_interstitial(ei);
     for (int p = lrp[r] + l; p < lrp[r + 1] && !cut; p += LPR) { const int j = lci[p]; const int ej = element[j]; if (CB == 2 && k_interstitial(ej)) continue; kl += k_high<CB>(ei, ej, qi, charge[j], ms) ? high_G : low_G; }
     for (int p = rrp[r] + l; p < rrp[r + 1] && !cut; p += LPR) { const int j = N_left + m + rci[p]; const int ej = element[j]; if (CB == 2 && k_interstitial(ej)) continue; kr += k_high<CB>(ei, ej, qi, charge[j], ms) ? high_G : low_G; }
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) { off += __shfl_xor(off, o, LPR); kl += __shfl_xor(kl, o, LPR); kr += __shfl_xor(kr, o, LPR); }
+    { off = group_sum<LPR>(off); kl = group_sum<LPR>(kl); kr = group_sum<LPR>(kr); }
     if (l == 0) {
         double d = off;          // reduce_rows_into_diag: -(sum of off-diagonals)
         d += kl;                 // add_vector_to_diagonal (left)
@@ -154,7 +153,7 @@ __global__ __launch_bounds__(KC_NT) void k_kc_apply(int m, const int *__restrict
             for (int u = 0; u < 4; ++u) x[u] = (c[u] & 0x7fffffff) == row ? 0.0 : (c[u] < 0 ? high_G : low_G) * x[u];
             sum += (x[0] + x[1]) + (x[2] + x[3]);
         }
-        sum += __shfl_xor(sum, 4, 8); sum += __shfl_xor(sum, 2, 8); sum += __shfl_xor(sum, 1, 8);
+        sum = group_sum<8>(sum);
         if (l == 0) {
             const double tv = sv * (dg * qr - sum);
             if (MODE != 1) { t[row] = tv; acc[0] += a1 * tv; acc[1] += a2 * tv; acc[2] += tv * tv; }
@@ -219,8 +218,7 @@ __global__ __launch_bounds__(KC_NT) void k_kb_assemble(int m, int N_left, int R,
     const bool cut = CB == 2 && k_interstitial(ei);
     for (int p = lrp[r] + l; p < lrp[r + 1] && !cut; p += LPR) { const int j = lci[p]; const int ej = element[j]; if (CB == 2 && k_interstitial(ej)) continue; kl += k_high<CB>(ei, ej, qi, charge[j], ms) ? high_G : low_G; }
     for (int p = rrp[r] + l; p < rrp[r + 1] && !cut; p += LPR) { const int j = N_left + m + rci[p]; const int ej = element[j]; if (CB == 2 && k_interstitial(ej)) continue; kr += k_high<CB>(ei, ej, qi, charge[j], ms) ? high_G : low_G; }
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) { off += __shfl_xor(off, o, LPR); kl += __shfl_xor(kl, o, LPR); kr += __shfl_xor(kr, o, LPR); }
+    { off = group_sum<LPR>(off); kl = group_sum<LPR>(kl); kr = group_sum<LPR>(kr); }
     if (l == 0) {
         double d = off;
         d += kl;
@@ -310,7 +308,7 @@ __global__ __launch_bounds__(KB_NT) void k_kb_apply(int m, int R, const int4 *__
             for (int u = 8; u < 16; ++u) x[u] = (c[u] & 0x7fffffff) == row ? 0.0 : (c[u] < 0 ? high_G : low_G) * x[u];
             sum += ((x[8] + x[9]) + (x[10] + x[11])) + ((x[12] + x[13]) + (x[14] + x[15]));
         }
-        sum += __shfl_xor(sum, 2, 4); sum += __shfl_xor(sum, 1, 4);
+        sum = group_sum<4>(sum);
         if (l == 0) {
             const double tv = sv * (dg * qr - sum);
             if (MODE == 0) { t[row] = tv; acc[0] += a1 * tv; acc[1] += a2 * tv; acc[2] += tv * tv; }

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(SP_NT) void k_sp_apply(int m, const int *__restrict
             const int p0 = rp[row], p1 = rp[row + 1];
             double s = 0.0;
             for (int q = p0 + l; q < p1; q += 8) s += a[q] * p[ci[q]];
-            s += __shfl_xor(s, 4, 8); s += __shfl_xor(s, 2, 8); s += __shfl_xor(s, 1, 8);
+            s = group_sum<8>(s);
             if (l == 0) t[row] = s;
         }
         return;

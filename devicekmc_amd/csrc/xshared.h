@@ -313,8 +313,7 @@ __global__ __launch_bounds__(256) void k_xval(XParams P, int nrows, const SEntry
             if (c == i) { dpos = p; dval = v; } else { data[p] = v; off += v; }
         }
     }
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) off += __shfl_xor(off, o, LPR);
+    off = group_sum<LPR>(off);
     if (dpos >= 0) { data[dpos] = dval + -off; if (diag_pos) diag_pos[i] = dpos; }      // calc_diagonal_X_gpu
 }
 

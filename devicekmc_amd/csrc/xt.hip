@@ -429,7 +429,7 @@ __device__ __forceinline__ void xt_neigh_roles(int bid, int nsb, int Nsub, const
                 for (int u = 0; u < 4; ++u) xx[u] = q[cc[u]];
                 s += (vv[0] * xx[0] + vv[1] * xx[1]) + (vv[2] * xx[2] + vv[3] * xx[3]);
             }
-            s += __shfl_xor(s, 4, 8); s += __shfl_xor(s, 2, 8); s += __shfl_xor(s, 1, 8);
+            s = group_sum<8>(s);
             if (l == 0 && row < Nsub) t[row] = sr[j] < 0 ? scale[j] * s : s;
         }
         return;
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(XT_NT) void k_xt_power_rows(int Nsub, const xrp_t *
         if ((ical < 0 && Vd > 0) || (ical > 0 && Vd < 0)) v = -ical;
         p += v * (m[c] - mi);
     }
-    p += __shfl_xor(p, 4, 8); p += __shfl_xor(p, 2, 8); p += __shfl_xor(p, 1, 8);
+    p = group_sum<8>(p);
     const int a = i - 2;
     if (l == 0 && !(aflag[a] & AF_METAL)) {
         const int sr = nsrank[i];

@@ -525,30 +525,54 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_neigh(int m, const xrp_t *__restr
         }
         return;
     }
-    // atom rows (<= nn + 3 entries): the 16 lanes of a row first fetch its entries, one or two per lane, and fold the column's scaling into the
-    // value; every entry is then handed round the group (shuffles) and all 16 panel reads of a batch are issued together -- three dependent
-    // memory rounds per row instead of two per four entries (26 -> 12 us per sweep at 85 k sites)
-    const int li = ((int)blockIdx.x - 2 * XB_DSPLIT) * 16 + g;
+    // atom rows (<= nn + 3 entries): the 16 lanes of a row first fetch ALL its entries, up to four per lane (64 entries per trip), and fold the column's
+    // scaling into the values; then, batch of 16 by batch of 16, every entry is handed round the group (shuffles) and the 16 panel reads of the batch
+    // are issued together.  A latency-bound kernel (its bytes need 0.05 ms per sweep at 9.4e5 sites, it took 0.27): what counts is dependent memory
+    // rounds per row x registers per wave.  Round 4 fetched the entries of a batch inside the batch loop -- two dependent rounds per batch; here the row
+    // pointer, the entries and one round per batch, at the same registers.  The additions keep the entry order of the row: same bits.
+    // XCD-aware order of the row blocks: workgroups b and b + 8 share an XCD (and its 4 MiB L2), so XCD x takes the x-th CONTIGUOUS eighth of the
+    // row blocks -- neighbouring rows (atoms in structure order: neighbours in space) then re-read panel rows from their own L2 instead of each of
+    // the eight L2s pulling the whole panel from the Infinity Cache (1.4 GB of 128-byte gathers per sweep at 9.4e5 sites)
+    const int nb = (int)gridDim.x - 2 * XB_DSPLIT, b = (int)blockIdx.x - 2 * XB_DSPLIT;     // (2 XB_DSPLIT is a multiple of 8)
+    const int xq = nb >> 3, xr = nb & 7, xc = b & 7;
+    const int lb = xc * xq + min(xc, xr) + (b >> 3);
+    const int li = lb * 16 + g;
     const int row = rowlist ? (li < nlist ? rowlist[li] : m) : 2 + li;
     const bool ok = row < m;
     const xrp_t p0 = ok ? rp[row] : 0, p1 = ok ? rp[row + 1] : 0;
+    const int nsr = ok ? nsrank[row] : 0;
+    const double scr = ok ? sc[row] : 0.0;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    for (xrp_t base = p0; base < p1; base += 16) {
-        const xrp_t pe = base + v;
-        const int cm = pe < p1 ? ci[pe] : -1;
-        const double wm = cm >= 0 ? val[pe] * sc[cm] : 0.0;
-        double x[16]; double w[16];
+    for (xrp_t base = p0; base < p1; base += 64) {
+        int cm[4]; double wm[4];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int cu = __shfl(cm, u, 16);
-            w[u] = __shfl(wm, u, 16);
-            x[u] = cu >= 0 ? P[(size_t)cu * XB_SP + v] : 0.0;
+        for (int b = 0; b < 4; ++b) { const xrp_t pe = base + 16 * b + v; cm[b] = pe < p1 ? ci[pe] : -1; wm[b] = pe < p1 ? val[pe] : 0.0; }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) wm[b] = cm[b] >= 0 ? wm[b] * sc[cm[b]] : 0.0;
+        // entry u of the batch to all 16 lanes of the row's group: DPP row_newbcast (a VALU move; __shfl would be an LDS ds_bpermute per value -- three
+        // per entry, 1.6e7 of them per sweep at 9.4e5 sites: that, not the gathers, was what the kernel took its time for)
+#define XN_BC(x_, u_) __builtin_amdgcn_update_dpp(0, (x_), 0x150 + (u_), 0xf, 0xf, false)
+#define XN_GATHER(u_) { const int cu_ = XN_BC(cmb, u_); \
+            x[u_] = cu_ >= 0 ? *reinterpret_cast<const double *>(reinterpret_cast<const char *>(P) + ((unsigned)cu_ * (unsigned)(XB_SP * 8) + (unsigned)(v * 8))) : 0.0; }
+#define XN_W(u_) __hiloint2double(XN_BC(whi, u_), XN_BC(wlo, u_))
+#define XN_ACC(u_) { s0 += XN_W(u_) * x[u_]; s1 += XN_W(u_ + 1) * x[u_ + 1]; s2 += XN_W(u_ + 2) * x[u_ + 2]; s3 += XN_W(u_ + 3) * x[u_ + 3]; }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (base + 16 * b >= p1) break;
+            double x[16];
+            const int cmb = cm[b], wlo = __double2loint(wm[b]), whi = __double2hiint(wm[b]);
+            // (32-bit byte offsets from the panel's base: the panel is m x 128 B, far below 4 GB)
+            XN_GATHER(0) XN_GATHER(1) XN_GATHER(2) XN_GATHER(3) XN_GATHER(4) XN_GATHER(5) XN_GATHER(6) XN_GATHER(7)
+            XN_GATHER(8) XN_GATHER(9) XN_GATHER(10) XN_GATHER(11) XN_GATHER(12) XN_GATHER(13) XN_GATHER(14) XN_GATHER(15)
+            XN_ACC(0) XN_ACC(4) XN_ACC(8) XN_ACC(12)
         }
-#pragma unroll
-        for (int u = 0; u < 16; u += 4) { s0 += w[u] * x[u]; s1 += w[u + 1] * x[u + 1]; s2 += w[u + 2] * x[u + 2]; s3 += w[u + 3] * x[u + 3]; }
+#undef XN_BC
+#undef XN_GATHER
+#undef XN_W
+#undef XN_ACC
     }
     const double s = (s0 + s1) + (s2 + s3);
-    if (ok) T[(size_t)row * XB_SP + v] = nsrank[row] < 0 ? sc[row] * s : s;
+    if (ok) T[(size_t)row * XB_SP + v] = nsr < 0 ? scr * s : s;
 }
 
 // ---- row kernel: partial sums -> S rows of T, then the partial Gram matrices of this workgroup's rows ------------------------------------

@@ -593,18 +593,26 @@ __device__ __forceinline__ double xtb_list_sum(const double *__restrict__ p, siz
     }
     return (a0 + a1) + (a2 + a3);
 }
-// two lists of the same shape (the thread's rows r4 and r4 + 16, `off` doubles apart): the loads of both are in flight together
-__device__ __forceinline__ void xtb_list_sum2(const double *__restrict__ p, size_t stride, size_t off, int first, int n, double &sa, double &sb)
+// two lists of the same shape (the thread's rows r4 and r4 + 16, `off` doubles apart; p points at the thread's vector v of row r4).  Loaded as 16-byte
+// pairs: the even lane of a pair takes vectors (v, v + 1) of row r4, the odd one (v - 1, v) of row r4 + 16 -- twice the bytes per load instruction of
+// the 8-byte form at the same number of loads in flight -- and one DPP exchange hands each lane the sum it does not hold.  Every (row, vector) list is
+// still added by ONE thread in the same grouping (term j to accumulator j % 4): same bits as the 8-byte form.
+__device__ __forceinline__ void xtb_list_sum2(const double *__restrict__ p, size_t stride, size_t off, int first, int n, int v, double &sa, double &sb)
 {
+    const bool odd = (v & 1) != 0;
+    const dbl2 *__restrict__ q = reinterpret_cast<const dbl2 *>(odd ? p - 1 + off : p);
+    const size_t st2 = stride >> 1;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
     for (int c = first; c < n; c += 16) {
-        double x[16], y[16];
+        dbl2 x[16];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int cu = c + u; const bool ok = cu < n; x[u] = ok ? p[(size_t)cu * stride] : 0.0; y[u] = ok ? p[(size_t)cu * stride + off] : 0.0; }
+        for (int u = 0; u < 16; ++u) { const int cu = c + u; x[u] = cu < n ? __builtin_nontemporal_load(q + (size_t)cu * st2) : (dbl2)(0.0); }      // (read once per sweep: non-temporal)
 #pragma unroll
-        for (int u = 0; u < 16; u += 4) { a0 += x[u]; a1 += x[u + 1]; a2 += x[u + 2]; a3 += x[u + 3]; b0 += y[u]; b1 += y[u + 1]; b2 += y[u + 2]; b3 += y[u + 3]; }
+        for (int u = 0; u < 16; u += 4) { a0 += x[u].x; a1 += x[u + 1].x; a2 += x[u + 2].x; a3 += x[u + 3].x; b0 += x[u].y; b1 += x[u + 1].y; b2 += x[u + 2].y; b3 += x[u + 3].y; }
     }
-    sa = (a0 + a1) + (a2 + a3); sb = (b0 + b1) + (b2 + b3);
+    const double sx = (a0 + a1) + (a2 + a3), sy = (b0 + b1) + (b2 + b3);
+    const double got = xor_lane<1>(odd ? sx : sy);
+    sa = odd ? got : sx; sb = odd ? sy : got;
 }
 // ---- sharded solve: this rank's tile sums of every S row -> the exchange buffer xbuf[ns][so]; behind them the control words: rank 0's stop
 // decision and any rank's abort word.  [w_lo, w_hi): windows that can hold this rank's partial sums (every other cell of its arrays is zero)
@@ -629,8 +637,8 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_fold_local(int ns, int nK, int nW
             const double *cpp = colpartB + ((size_t)cbase * XT_C + (XT_R * (k % (XT_C / XT_R)) + r4)) * so + v;
             const size_t rs = (size_t)XT_R * so, cs = (size_t)XT_C * so;
             double cA, cB, rA_, rB_;
-            xtb_list_sum2(cpp, cs, (size_t)16 * so, 0, nc, cA, cB);
-            xtb_list_sum2(rpp, rs, (size_t)16 * so, wr.x, wr.y, rA_, rB_);
+            xtb_list_sum2(cpp, cs, (size_t)16 * so, 0, nc, v, cA, cB);
+            xtb_list_sum2(rpp, rs, (size_t)16 * so, wr.x, wr.y, v, rA_, rB_);
             tA = cA + rA_; tB = cB + rB_;
             const int sA = XT_R * k + r4, sB = sA + 16;
             if (sA < ns) xbuf[(sdst ? (size_t)sdst[sA] : (size_t)sA * so) + v] = tA;
@@ -700,8 +708,8 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_rows(int ns, int nK, int nW, int 
             const double *cpp = colpartB + ((size_t)cbase * XT_C + (XT_R * (k % (XT_C / XT_R)) + r4)) * so + v;
             const size_t rs = (size_t)XT_R * so, cs = (size_t)XT_C * so;
             double cA, cB, rA_, rB_;
-            xtb_list_sum2(cpp, cs, (size_t)16 * so, 0, nc, cA, cB);
-            xtb_list_sum2(rpp, rs, (size_t)16 * so, wr.x, wr.y, rA_, rB_);
+            xtb_list_sum2(cpp, cs, (size_t)16 * so, 0, nc, v, cA, cB);
+            xtb_list_sum2(rpp, rs, (size_t)16 * so, wr.x, wr.y, v, rA_, rB_);
             tA = cA + rA_; tB = cB + rB_;
         }
         double pA = 0.0, pB = 0.0, rA = 0.0, rB = 0.0;

@@ -1441,6 +1441,9 @@ extern "C" int dkmc_xtb_time_apply(int width, int variant, int reps, double *us)
 {
     Engine &e = eng(); hipStream_t st = e.stream; const XTState &X = g_xt;
     if (!X.valid || comm_attached() || X.tile_n != X.ntiles || X.ns <= 0 || reps < 1) return dkmc_fail(13, "xtb_time_apply: needs the X of a single-GPU solve", __FILE__, __LINE__);
+#ifndef DKMC_MEASURE_VARIANTS
+    if (variant != 0) return dkmc_fail(13, "xtb_time_apply: this build carries no measurement variants (DKMC_MEASURE_VARIANTS=1 python __graft_entry__.py)", __FILE__, __LINE__);
+#endif
     const int s = std::max(2, std::min(width, 16)), so = 4 * ((s + 3) / 4);
     const long long ncell = (long long)X.nK * X.nW;
     const int nrec = X.nitems >> X.rec_shift;
@@ -1456,10 +1459,15 @@ extern "C" int dkmc_xtb_time_apply(int width, int variant, int reps, double *us)
         if (r == 0) HIPCHK(hipEventRecord(e0, st));
 #define XB_APPLY(NG_, V_) do { if (e.x_apply_form == 1 && (V_) == 0) hipLaunchKernelGGL((k_xtb_apply<1, NG_, 8>), dim3((X.item_n + 3) / 4), dim3(XT_NT), 0, st, XB_APPLY_ARGS_); \
                                else hipLaunchKernelGGL((k_xtb_apply<1, NG_, V_>), dim3((X.item_n + 3) / 4), dim3(XT_NT), 0, st, XB_APPLY_ARGS_); } while (0)
+#ifdef DKMC_MEASURE_VARIANTS
         if (so == 4) XB_APPLY(1, 0);
         else if (so == 8) { if (variant == 1) XB_APPLY(2, 1); else if (variant == 2) XB_APPLY(2, 2); else XB_APPLY(2, 0); }
         else if (so == 12) XB_APPLY(3, 0);
         else { if (variant == 1) XB_APPLY(4, 1); else if (variant == 2) XB_APPLY(4, 2); else if (variant == 3) XB_APPLY(4, 3); else if (variant == 4) XB_APPLY(4, 4); else if (variant == 7) XB_APPLY(4, 7); else if (variant == 10) XB_APPLY(4, 10); else if (variant == 12) XB_APPLY(4, 12); else XB_APPLY(4, 0); }
+#else
+        // (the library as shipped carries the product kernel and the round-4 form only; DKMC_MEASURE_VARIANTS=1 python __graft_entry__.py builds the rest)
+        if (so == 4) XB_APPLY(1, 0); else if (so == 8) XB_APPLY(2, 0); else if (so == 12) XB_APPLY(3, 0); else XB_APPLY(4, 0);
+#endif
 #undef XB_APPLY
     }
     HIPCHK(hipEventRecord(e1, st));

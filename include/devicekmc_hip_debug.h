@@ -27,7 +27,9 @@ int dkmc_xtb_check_product(int width, double *max_abs_diff, double *max_abs);
 /* Measurement aid: average duration [us] of the tile x panel kernel of the block-CG over the X left resident by the last single-GPU solve
  * (`reps` launches).  variant 0: as a solve runs it; on the round-4 form of the loop: 1: without its matrix instructions (tile stream + LDS
  * traffic); 2: without re-reading the tile stream (matrix instructions + LDS traffic); 3: operand stages of one k-pair; 4: without LDS
- * traffic; 7: the matrix instructions alone; 10: the product form without re-reading the tile stream. */
+ * traffic; 7: the matrix instructions alone; 10: the product form without re-reading the tile stream; 12: the product form with the partial
+ * tiles skipped.  Variants other than 0 exist only in a library built with DKMC_MEASURE_VARIANTS=1 (python __graft_entry__.py); the shipped one
+ * returns error 13 for them. */
 int dkmc_xtb_time_apply(int width, int variant, int reps, double *us);
 /* Measurement aid: how the resident X fills its tiles -- hist[c] = tiles with c of their 8 sub-blocks present (c = 0 .. 8), hist[9] = tiles inside a
  * chain (>= 2) of full tiles of a run, hist[10] = runs.  hist: 11 entries. */

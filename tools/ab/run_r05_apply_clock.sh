@@ -1,6 +1,6 @@
 # round 5: the shader clock k_xtb_apply runs at -- GRBM_GUI_ACTIVE (busy cycles, summed over the 8 XCDs) / kernel duration per dispatch, for the product
 # kernel (round-4 form = <.., 8> and product form = <.., 0>, widths 16 and 8) and the measurement variants 2 (no stream), 4 (no LDS), 7 (matrix instructions alone)
-mkdir -p gpurun_out/r05
+mkdir -p gpurun_out/r05      # (the library must have been built with DKMC_MEASURE_VARIANTS=1 python __graft_entry__.py before the gpurun call)
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/r05/pmcclk -- python3 $R/tools/ab/apply_clock.py > $R/gpurun_out/r05/pmcclk.out 2>&1 || echo "pmc pass failed"

@@ -1,6 +1,6 @@
 # round 5: what k_xtb_apply is made of, same box, same launch: dkmc_xtb_time_apply with the measurement variants (2 = no stream
 # re-read, 4 = no LDS traffic, 7 = matrix instructions alone, 10 = the product form without the stream re-read) beside the product kernel and the round-4 form of its loop (dkmc_set_x_apply_form 0 / 1); the variants ride on the round-4 form
-mkdir -p gpurun_out/r05
+mkdir -p gpurun_out/r05      # (the library must have been built with DKMC_MEASURE_VARIANTS=1 python __graft_entry__.py before the gpurun call)
 python3 - <<'PY' 2>gpurun_out/r05/apply_parts.err | tee -a gpurun_out/r05/apply_parts.log
 import ctypes as C, json, sys
 sys.path.insert(0, ".")

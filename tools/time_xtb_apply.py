@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Where the time of the block-CG's tile x panel kernel goes: the kernel as it runs, without its matrix instructions, and without
-re-reading the tile stream, on one workload (dkmc_xtb_time_apply).  usage: python tools/time_xtb_apply.py tile:10 [width ...]"""
+re-reading the tile stream, on one workload (dkmc_xtb_time_apply).  usage: python tools/time_xtb_apply.py tile:10 [width ...]
+(the measurement variants exist only in a library built with DKMC_MEASURE_VARIANTS=1 python __graft_entry__.py)"""
 import ctypes as C
 import json
 import os

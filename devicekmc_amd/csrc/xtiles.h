@@ -8,7 +8,7 @@
 #define XT_SBW 32                    // columns per sub-block
 #define XT_SUB (XT_R * XT_SBW)       // doubles per sub-block (8 KiB)
 #define XT_NT 256
-#define XT_MAXKC 32
+#define XT_MAXKC 32                   // largest nominal run length (tiles) of a wave: min(XT_MAXKC, tiles / ranks / 4096); 16 until round 5 (profiles/r05_ab_tile_run_lists.jsonl)
 #define XT_PROF_STRIDE 8
 
 typedef double dbl2 __attribute__((ext_vector_type(2)));

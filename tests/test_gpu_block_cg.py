@@ -3,6 +3,7 @@ tile kernel, the block solve against the single-vector solve and against the ora
 default tolerance with the oracle fed the GPU's potentials.  The block loop does not follow the reference's iterate sequence: the
 contract is the SOLUTION within the reference's stop test (||S (X m - b)||_2 <= tol on the physical column)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -202,3 +203,19 @@ def test_smooth_auxiliary_columns(cell_2p5, dev_7p5, hip, which):
         assert _scaled_residual(rp, ci, data, c["m"], p.G0, p.X_loop_G) <= 3e-9
     finally:
         L.dkmc_set_x_format(1); L.dkmc_set_x_block(16); L.dkmc_set_x_aux(2); L.dkmc_set_cg_tolerance(1e-6)
+
+
+def test_dpp_lane_exchange_matches_shfl_xor(tmp_path):
+    """csrc/common.h replaces the ds_bpermute hipcc emits for __shfl_xor by DPP moves (xor_lane: quad_perm, row_shl / row_shr under bank masks, row_ror) in
+    every per-row reduction of the sparse kernels: the probe builds those forms stand-alone and compares them with __shfl_xor lane by lane for the
+    offsets 1, 2, 4, 8 (the reductions then add the same pairs in the same order: same bits as before the replacement)."""
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("no hipcc on this box")
+    exe = str(tmp_path / "probe_dpp_xor")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "probe_dpp_xor.hip")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", src, "-o", exe], check=True, capture_output=True, timeout=600)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "identical to __shfl_xor" in r.stdout, (r.returncode, r.stdout, r.stderr)

@@ -1581,7 +1581,8 @@ extern "C" int dkmc_xtb_emulate_slabs(int nranks, int width, double tol, int tim
     B.y = yref;
     int it_ref = 0, it_slab = 0; double rr = 0.0;
     int rc = 0;
-    if (sweep_cap <= 0) { rc = xtb_cg(B, &it_ref, &rr); if (rc && rc != DKMC_XTB_BREAKDOWN) return rc; }
+    // (the one-GPU loop WITHOUT the split polynomial preconditioner: the slab-distributed loop has none, and the two are compared sweep for sweep)
+    if (sweep_cap <= 0) { const int pd0 = e.x_poly; e.x_poly = 0; rc = xtb_cg(B, &it_ref, &rr); e.x_poly = pd0; if (rc && rc != DKMC_XTB_BREAKDOWN) return rc; }
     // (2) nranks virtual ranks: the shares of an nranks-way assembly
     const int ntiles = X.ntiles;
     int kc = std::max(1, std::min(XT_MAXKC, ntiles / nranks / 4096));

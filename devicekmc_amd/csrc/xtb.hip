@@ -657,7 +657,9 @@ __global__ void k_xtb_set_sharded(XCtrl *ctrl) { ctrl->sharded = 1; }
 // decision and its abort word.  Every rank adds the slots IN RANK ORDER: the same bits everywhere by construction (no transport decides the
 // grouping of the additions, nothing has to be re-published from rank 0), and turns rank 0's stop decision / any rank's abort word into `done`
 // here, in the same iteration.
-template <int INIT, int SH = 0>
+// NF (split polynomial preconditioner, dkmc_set_x_poly): T is final in every row -- folded by k_xtb_fold_rows and carried through L -- this pass only forms R (INIT) and
+// the partial Gram matrices.
+template <int INIT, int SH = 0, int NF = 0>
 __global__ __launch_bounds__(XT_NT) void k_xtb_rows(int ns, int nK, int nW, int m, int s, int so, const int2 *__restrict__ wrange, const int *__restrict__ nitem_w,
                                                     const double *__restrict__ rowpartB, const double *__restrict__ colpartB,
                                                     const int *__restrict__ srow, const double *__restrict__ sS, const int *__restrict__ nsrank,
@@ -703,7 +705,7 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_rows(int ns, int nK, int nW, int 
                     if (sB < ns) tB += xbuf[r * xslot + (size_t)sB * so + v];
                 }
             }
-        } else if (v < so) {
+        } else if (!NF && v < so) {
             const double *rpp = rowpartB + ((size_t)k * nW * XT_R + r4) * so + v;
             const double *cpp = colpartB + ((size_t)cbase * XT_C + (XT_R * (k % (XT_C / XT_R)) + r4)) * so + v;
             const size_t rs = (size_t)XT_R * so, cs = (size_t)XT_C * so;
@@ -715,12 +717,12 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_rows(int ns, int nK, int nW, int 
         double pA = 0.0, pB = 0.0, rA = 0.0, rB = 0.0;
         if (sA < ns) {
             const int row = srow[sA]; const size_t o = (size_t)row * XB_SP + v;
-            tA = sS[sA] * (T[o] + tA); T[o] = tA;
+            if (NF) tA = T[o]; else { tA = sS[sA] * (T[o] + tA); T[o] = tA; }
             if (INIT) { rA = tA - xtb_rhs(b, row, v, s, aux, ax, ay, az, sc); R[o] = rA; } else { pA = P[o]; rA = R[o]; }
         } else tA = 0.0;
         if (sB < ns) {
             const int row = srow[sB]; const size_t o = (size_t)row * XB_SP + v;
-            tB = sS[sB] * (T[o] + tB); T[o] = tB;
+            if (NF) tB = T[o]; else { tB = sS[sB] * (T[o] + tB); T[o] = tB; }
             if (INIT) { rB = tB - xtb_rhs(b, row, v, s, aux, ax, ay, az, sc); R[o] = rB; } else { pB = P[o]; rB = R[o]; }
         } else tB = 0.0;
         if (!INIT) {
@@ -752,7 +754,7 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_rows(int ns, int nK, int nW, int 
                 const bool use = row < i1 && sr[u] < 0;
                 const size_t o = (size_t)row * XB_SP + v;
                 double t_ = use ? tv[u] : 0.0, p_ = 0.0, r_ = 0.0;
-                if (use && row < 2) {
+                if (!NF && use && row < 2) {
                     double sd = 0.0;
 #pragma unroll
                     for (int w = 0; w < XB_DSPLIT; ++w) sd += drvpart[(row * XB_DSPLIT + w) * XB_SP + v];
@@ -779,6 +781,130 @@ __global__ __launch_bounds__(XT_NT) void k_xtb_rows(int ns, int nK, int nW, int 
             gpart[(size_t)blockIdx.x * (XB_NG * 256) + h * (XB_NG / 2) * 256 + e] = (lg[0][g][u][l] + lg[1][g][u][l]) + (lg[2][g][u][l] + lg[3][g][u][l]);
         }
     }
+}
+
+// ---- split polynomial preconditioner (dkmc_set_x_poly(d), one GPU) -------------------------------------------------------------------------
+// The block loop runs on L A L, A = S X S the Jacobi-scaled operator, L = sum_j c_j N^j the degree-d truncation of the series of (I - N)^(-1/2),
+// N = I - An, An = the neighbour part of A with A's full (unit) diagonal -- the couplings of the two driver nodes stay outside N.  CG on A
+// preconditioned with An EXACTLY needs 8 iterations where A needs 666 (85 k sites, tools/precond_proto.py): the ill-conditioning of X lives in its
+// sparse part, and 2 d sparse panel products per sweep buy 2-3x fewer passes over the tiles (tools/precond_block_proto.py).  The loop's algebra
+// is untouched: it sees another SPD operator.  A start vector y0 enters as the right-hand side: A d = b - A y0, d = L dh, dh from zero.
+// out = ca * add + cb * (N in): 16 lanes per row as in k_xtb_neigh; rows 0 / 1 (driver nodes) and their columns take no part in N
+__global__ __launch_bounds__(XT_NT) void k_xtb_nmul(int m, const xrp_t *__restrict__ rp, const int *__restrict__ ci, const double *__restrict__ val,
+                                                    const double *__restrict__ sc, const double *__restrict__ in, const double *__restrict__ add,
+                                                    double ca, double cb, double *__restrict__ out, const XCtrl *ctrl)
+{
+    if (ctrl->done) return;
+    const int v = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int nb = (int)gridDim.x, b = (int)blockIdx.x;
+    const int xq = nb >> 3, xr = nb & 7, xc = b & 7;
+    const int row = (xc * xq + min(xc, xr) + (b >> 3)) * 16 + g;               // XCD-contiguous row blocks (see k_xtb_neigh)
+    const bool ok = row < m, atom = ok && row >= 2;
+    const xrp_t p0 = atom ? rp[row] : 0, p1 = atom ? rp[row + 1] : 0;
+    const double scr = ok ? sc[row] : 0.0;
+    const double av = ok ? add[(size_t)row * XB_SP + v] : 0.0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    for (xrp_t base = p0; base < p1; base += 64) {
+        int cm[4]; double wm[4];
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq) { const xrp_t pe = base + 16 * bq + v; int c = pe < p1 ? ci[pe] : -1; if (c < 2 || c == row) c = -1; cm[bq] = c; wm[bq] = c >= 0 ? val[pe] : 0.0; }
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq) wm[bq] = cm[bq] >= 0 ? wm[bq] * sc[cm[bq]] : 0.0;
+#define XN_BC(x_, u_) __builtin_amdgcn_update_dpp(0, (x_), 0x150 + (u_), 0xf, 0xf, false)
+#define XN_GATHER(u_) { const int cu_ = XN_BC(cmb, u_); \
+            x[u_] = cu_ >= 0 ? *reinterpret_cast<const double *>(reinterpret_cast<const char *>(in) + ((unsigned)cu_ * (unsigned)(XB_SP * 8) + (unsigned)(v * 8))) : 0.0; }
+#define XN_W(u_) __hiloint2double(XN_BC(whi, u_), XN_BC(wlo, u_))
+#define XN_ACC(u_) { s0 += XN_W(u_) * x[u_]; s1 += XN_W(u_ + 1) * x[u_ + 1]; s2 += XN_W(u_ + 2) * x[u_ + 2]; s3 += XN_W(u_ + 3) * x[u_ + 3]; }
+#pragma unroll
+        for (int bq = 0; bq < 4; ++bq) {
+            if (base + 16 * bq >= p1) break;
+            double x[16];
+            const int cmb = cm[bq], wlo = __double2loint(wm[bq]), whi = __double2hiint(wm[bq]);
+            XN_GATHER(0) XN_GATHER(1) XN_GATHER(2) XN_GATHER(3) XN_GATHER(4) XN_GATHER(5) XN_GATHER(6) XN_GATHER(7)
+            XN_GATHER(8) XN_GATHER(9) XN_GATHER(10) XN_GATHER(11) XN_GATHER(12) XN_GATHER(13) XN_GATHER(14) XN_GATHER(15)
+            XN_ACC(0) XN_ACC(4) XN_ACC(8) XN_ACC(12)
+        }
+#undef XN_BC
+#undef XN_GATHER
+#undef XN_W
+#undef XN_ACC
+    }
+    if (ok) out[(size_t)row * XB_SP + v] = ca * av - cb * (scr * ((s0 + s1) + (s2 + s3)));
+}
+// QS (the compact, interleaved copy of the S rows the tile kernel reads) of an arbitrary panel
+__global__ void k_xtb_qs_from(int m, const double *__restrict__ V, const double *__restrict__ sc, const int *__restrict__ nsrank, double *__restrict__ QS, const XCtrl *ctrl)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * XB_SP || ctrl->done) return;
+    const int row = i >> 4, v = i & 15;
+    const int sr = nsrank[row];
+    if (sr >= 0) QS[xtb_qs_pos(sr, v)] = sc[row] * V[i];
+}
+// the fold of k_xtb_rows alone: S rows of T <- scaling x (sparse sum + tile sums), driver rows from their partial sums
+__global__ __launch_bounds__(XT_NT) void k_xtb_fold_rows(int ns, int nK, int nW, int so, const int2 *__restrict__ wrange, const int *__restrict__ nitem_w,
+                                                         const double *__restrict__ rowpartB, const double *__restrict__ colpartB, const int *__restrict__ srow,
+                                                         const double *__restrict__ sS, const double *__restrict__ sc, const double *__restrict__ drvpart,
+                                                         double *__restrict__ T, const XCtrl *ctrl)
+{
+    if (ctrl->done) return;
+    const int v = threadIdx.x & 15, r4 = threadIdx.x >> 4;
+    const int rec_shift = nitem_w[2 * (nW + 2)];
+    if (blockIdx.x == 0 && threadIdx.x < 32) {
+        const int row = threadIdx.x >> 4;
+        double sd = 0.0;
+#pragma unroll
+        for (int w = 0; w < XB_DSPLIT; ++w) sd += drvpart[(row * XB_DSPLIT + w) * XB_SP + v];
+        T[(size_t)row * XB_SP + v] = sc[row] * sd;
+    }
+    for (int k = blockIdx.x; k < nK; k += gridDim.x) {
+        const int2 wr = wrange[k];
+        const int wk = k / (XT_C / XT_R);
+        const int nc = nitem_w[wk] >> rec_shift, cbase = nitem_w[nW + 2 + wk] >> rec_shift;
+        double tA = 0.0, tB = 0.0;
+        const int sA = XT_R * k + r4, sB = sA + 16;
+        if (v < so) {
+            const double *rpp = rowpartB + ((size_t)k * nW * XT_R + r4) * so + v;
+            const double *cpp = colpartB + ((size_t)cbase * XT_C + (XT_R * (k % (XT_C / XT_R)) + r4)) * so + v;
+            const size_t rs = (size_t)XT_R * so, cs = (size_t)XT_C * so;
+            double cA, cB, rA_, rB_;
+            xtb_list_sum2(cpp, cs, (size_t)16 * so, 0, nc, v, cA, cB);
+            xtb_list_sum2(rpp, rs, (size_t)16 * so, wr.x, wr.y, v, rA_, rB_);
+            tA = cA + rA_; tB = cB + rB_;
+        }
+        if (sA < ns) { const size_t o = (size_t)srow[sA] * XB_SP + v; T[o] = sS[sA] * (T[o] + tA); }
+        if (sB < ns) { const size_t o = (size_t)srow[sB] * XB_SP + v; T[o] = sS[sB] * (T[o] + tB); }
+    }
+}
+// start of a preconditioned solve: W <- [T(:, 0) - b | 0 ... 0] (T = A Y0: the residual of the start vector, sign r = A y - b)
+__global__ void k_xtb_pre_resid(int m, const double *__restrict__ T, const double *__restrict__ b, double *__restrict__ W)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * XB_SP) return;
+    W[i] = (i & 15) == 0 ? T[i] - b[i >> 4] : 0.0;
+}
+// W <- [y | 0 ... 0]
+__global__ void k_xtb_pre_col0(int m, const double *__restrict__ y, double *__restrict__ W)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m * XB_SP) return;
+    W[i] = (i & 15) == 0 ? y[i >> 4] : 0.0;
+}
+// end of a preconditioned solve: y <- y + Z(:, 0)  (Z = L dh, the correction)
+__global__ void k_xtb_pre_add(int m, const double *__restrict__ Z, double *__restrict__ y)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) y[i] += Z[(size_t)i * XB_SP];
+}
+// ||T(:, 0) - b||^2 in one workgroup (fixed order): the TRUE residual of the unpreconditioned scaled system, for the stop test a caller relies on
+__global__ __launch_bounds__(1024) void k_xtb_pre_rr(int m, const double *__restrict__ T, const double *__restrict__ b, double *__restrict__ out)
+{
+    __shared__ double red[1024];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < m; i += 1024) { const double d = T[(size_t)i * XB_SP] - b[i]; a += d * d; }
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[0] = red[0];
 }
 
 // ---- Gram matrices: the row kernel's partials, reduced in a fixed order ----------------------------------------------------------------
@@ -1165,7 +1291,21 @@ int xtb_cg(const XtbArgs &A, int *iters_out, double *rr_out)
     // below, which shards the tile stream only)
     if (A.sharded && eng().x_slab && comm_nranks() > 1 && comm_nranks() <= XS_MAXR && A.ay && A.az)
         return xtb_cg_slab(A, comm_nranks(), comm_rank(), nullptr, -1, iters_out, rr_out);
-    const int rc = xtb_cg_body(A, iters_out, rr_out, &peer_used);
+    double rr0 = 0.0;
+    int rc = xtb_cg_body(A, iters_out, &rr0, &peer_used);
+    // split polynomial preconditioner: the loop stops on the residual of L A L; when the TRUE residual of column 0 does not meet the stop test yet, the
+    // solve is re-entered from the iterate it reached (the check and the code DKMC_XTB_AGAIN: end of xtb_cg_body).  A round that no longer reduces the
+    // true residual by a factor of four has reached what the arithmetic gives (at tolerances of 1e-12 the recurrence residual the reference's test --
+    // and the plain loop -- stop on goes below what the true one can reach): the solve ends there, as the plain loop's does.
+    for (int round = 1; rc == DKMC_XTB_AGAIN && round < 6; ++round) {
+        int it2 = 0; double rr1 = 0.0;
+        rc = xtb_cg_body(A, &it2, &rr1, &peer_used);
+        if (iters_out) *iters_out += it2;
+        if (rc == DKMC_XTB_AGAIN && !(rr1 < 0.25 * rr0)) rc = 0;
+        rr0 = rr1;
+    }
+    if (rc == DKMC_XTB_AGAIN) rc = 0;
+    if (rr_out) *rr_out = rr0;
     // a sharded solve that failed with the peer-write exchange in use: the ranks' sequence counters may have drifted (comm.hip)
     if (rc != 0 && rc != DKMC_XTB_BREAKDOWN && peer_used) comm_peer_drop();
     return rc;
@@ -1186,6 +1326,20 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
     if (!panels || !QS || !rowpartB || !colpartB || !gpart || !small) return e.err_code;
     double *R = panels, *P = panels + pan, *T = panels + 2 * pan, *y0 = panels + 3 * pan;
     double *mats = small, *drvpart = small + 4 * 256, *gfin = drvpart + 2 * XB_DSPLIT * XB_SP;
+    // split polynomial preconditioner (dkmc_set_x_poly; one GPU): see k_xtb_nmul.  Vp = L P, Zp = A Vp before the second L, W1 / W2 the Horner steps;
+    // behind Vp: m zeros (the right-hand side of column 0 once the start vector has gone into it) and one double for the true residual
+    const int pd = (!A.sharded && m > 2 && A.ns > 0) ? e.x_poly : 0;
+    double *Vp = nullptr, *W1 = nullptr, *W2 = nullptr, *Zp = nullptr, *bz = nullptr;
+    if (pd > 0) {
+        Vp = (double *)scratch(S_XTB_PRE_V, (pan + m + 16) * 8); W1 = (double *)scratch(S_XTB_PRE_W1, pan * 8); W2 = (double *)scratch(S_XTB_PRE_W2, pan * 8);
+        Zp = (double *)scratch(S_XTB_PRE_Z, pan * 8);
+        if (!Vp || !W1 || !W2 || !Zp) return e.err_code;
+        bz = Vp + pan;
+        HIPCHK(hipMemsetAsync(bz, 0, (size_t)(m + 16) * 8, st));
+    }
+    double pc[9]; pc[0] = 1.0;
+    for (int j = 1; j <= 8; ++j) pc[j] = pc[j - 1] * (double)(2 * j - 1) / (double)(2 * j);      // series of (1 - x)^(-1/2)
+    const double tol2_loop = pd > 0 ? A.tol2 / 2.25 : A.tol2;                 // ||r|| <= 1.42 ||L r||: the loop stops a little early, the true residual is checked at the end
     HIPCHK(hipMemsetAsync(QS, 0, (size_t)A.ns_pad * XB_SP * 8, st));
     HIPCHK(hipMemsetAsync(rowpartB, 0, (size_t)(ncell + 1) * XT_R * so * 8, st));
     HIPCHK(hipMemsetAsync(colpartB, 0, (size_t)(A.nrecords + 1) * XT_C * so * 8, st));
@@ -1209,7 +1363,7 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
     XbAux *aux = nullptr;
     // which auxiliary columns take which set, and which start from the previous solve's solutions (A.yaux, dkmc_set_x_aux_warm): see xtb_aux_split
     const int hs = xtb_aux_split(e.x_aux, A.tol2, A.yaux != nullptr, s);
-    const bool keep_aux = A.yaux != nullptr;
+    const bool keep_aux = A.yaux != nullptr && pd == 0;
     double *Ypanel = keep_aux ? (double *)scratch(S_XTB_YPANEL, pan * 8) : nullptr;
     if (keep_aux && !Ypanel) return e.err_code;
     if (A.ax && A.ay && A.az && m > 2 && hs > 1) {
@@ -1259,8 +1413,35 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
         if (side) (void)hipStreamWaitEvent(st, g_xb_side.b[sl], 0);           // the sparse sums are in T before the row kernel reads them
         else hipLaunchKernelGGL(k_xtb_neigh, dim3(nnb), dim3(XT_NT), 0, st, m, A.rp, A.ci, A.val, (const double *)P, A.sc, A.nsrank, (const XCtrl *)A.ctrl, T, drvpart);
     };
+    // dst = L src (Horner: d sparse panel products); dst must be none of src, W1, W2
+    const int nmb = (m + 15) / 16;
+    auto applyL = [&](const double *src, double *dst) {
+        if (pd <= 0) return;
+        const double *in = src;
+        for (int i = 0; i < pd; ++i) {
+            double *out = (i == pd - 1) ? dst : ((i & 1) ? W2 : W1);
+            const int j = pd - 1 - i;                                         // out = c_j src + N (previous), the first step carries c_d
+            hipLaunchKernelGGL(k_xtb_nmul, dim3(nmb), dim3(XT_NT), 0, st, m, A.rp, A.ci, A.val, A.sc, in, src, pc[j], i == 0 ? pc[pd] : 1.0, out, (const XCtrl *)A.ctrl);
+            in = out;
+        }
+    };
+    auto fold_rows = [&](double *Tt) {
+        hipLaunchKernelGGL(k_xtb_fold_rows, dim3(std::max(ng, 1)), dim3(XT_NT), 0, st, A.ns, A.nK, A.nW, so, A.wrange, A.nitem_w, (const double *)rowpartB, (const double *)colpartB,
+                           A.srow, A.sS, A.sc, (const double *)drvpart, Tt, (const XCtrl *)A.ctrl);
+    };
+    // T = L A L P
+    auto product_pre = [&](hipEvent_t e0, hipEvent_t e1) {
+        applyL((const double *)P, Vp);
+        hipLaunchKernelGGL(k_xtb_qs_from, dim3((unsigned)((pan + 255) / 256)), dim3(256), 0, st, m, (const double *)Vp, A.sc, A.nsrank, QS, (const XCtrl *)A.ctrl);
+        double *Pk = P, *Tk = T; P = Vp; T = Zp;                              // (the product reads P and QS, writes T)
+        product(e0, e1);
+        P = Pk; T = Tk;
+        fold_rows(Zp);
+        applyL((const double *)Zp, T);
+    };
+    const double *bsel = A.b;
 #define XB_ROWS_ARGS(IT_) A.ns, A.nK, A.nW, m, s, so, A.wrange, A.nitem_w, (const double *)rowpartB, (const double *)colpartB, A.srow, A.sS, A.nsrank, A.sc, \
-                     (const double *)drvpart, T, (const double *)P, R, A.b, gpart, A.ctrl, (const double *)xbuf, IT_, nr, (const XbAux *)aux, A.ax, A.ay, A.az
+                     (const double *)drvpart, T, (const double *)P, R, bsel, gpart, A.ctrl, (const double *)xbuf, IT_, nr, (const XbAux *)aux, A.ax, A.ay, A.az
     // S rows of T + partial Gram matrices; a sharded solve exchanges the tile sums first.  A host-side failure of this rank between two
     // collectives must not leave the peers in the all-reduce: it still joins, with the abort word set, and every rank leaves together.
     auto rows = [&](bool init, int itn, hipEvent_t e2, hipEvent_t e3) -> int {
@@ -1278,6 +1459,9 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
             } else if (int rcx = comm_allgather_f64(xbuf, xcount)) return rcx;
             if (init) hipLaunchKernelGGL((k_xtb_rows<1, 1>), dim3(ng), dim3(XT_NT), 0, st, XB_ROWS_ARGS(itn));
             else hipExtLaunchKernelGGL((k_xtb_rows<0, 1>), dim3(ng), dim3(XT_NT), 0, st, e2, e3, 0, XB_ROWS_ARGS(itn));
+        } else if (pd > 0) {
+            if (init) hipLaunchKernelGGL((k_xtb_rows<1, 0, 1>), dim3(ng), dim3(XT_NT), 0, st, XB_ROWS_ARGS(itn));
+            else hipExtLaunchKernelGGL((k_xtb_rows<0, 0, 1>), dim3(ng), dim3(XT_NT), 0, st, e2, e3, 0, XB_ROWS_ARGS(itn));
         } else {
             if (init) hipLaunchKernelGGL((k_xtb_rows<1, 0>), dim3(ng), dim3(XT_NT), 0, st, XB_ROWS_ARGS(itn));
             else hipExtLaunchKernelGGL((k_xtb_rows<0, 0>), dim3(ng), dim3(XT_NT), 0, st, e2, e3, 0, XB_ROWS_ARGS(itn));
@@ -1286,9 +1470,17 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
     };
     // ---- R = A Y0 - B ; first directions ----
     product(nullptr, nullptr);
+    if (pd > 0) {
+        // the start vector goes into the right-hand side: column 0 solves L A L dh = L (b - A y0) from zero, the auxiliary columns keep their own
+        fold_rows(T);                                                         // T = A Y0
+        hipLaunchKernelGGL(k_xtb_pre_resid, dim3((unsigned)((pan + 255) / 256)), dim3(256), 0, st, m, (const double *)T, A.b, Zp);
+        applyL((const double *)Zp, T);                                        // T(:, 0) = L (A y0 - b), the other columns 0
+        bsel = bz;                                                            // R = T - [0 | auxiliary right-hand sides]
+        HIPCHK(hipMemsetAsync(y0, 0, (size_t)m * 8, st));
+    }
     if (int rcx = rows(true, -1, nullptr, nullptr)) return rcx;
     hipLaunchKernelGGL(k_xtb_gred, dim3(XB_NG * 16), dim3(XT_NT), 0, st, ng, (const double *)gpart, gfin, (const XCtrl *)A.ctrl);
-    hipLaunchKernelGGL(k_xtb_small, dim3(1), dim3(256), 0, st, -1, s, (const double *)gfin, mats, A.ctrl, A.tol2);
+    hipLaunchKernelGGL(k_xtb_small, dim3(1), dim3(256), 0, st, -1, s, (const double *)gfin, mats, A.ctrl, tol2_loop);
     hipLaunchKernelGGL(k_xtb_zero, dim3((unsigned)((pan + 255) / 256)), dim3(256), 0, st, (long long)pan, P);          // Y0 has served: P_{-1} = 0
     hipLaunchKernelGGL(k_xtb_step, dim3(gs), dim3(XT_NT), 0, st, m, -1, (const double *)mats, y0, R, P, (const double *)T, A.sc, A.nsrank, QS, (const XCtrl *)A.ctrl,
                        (const int *)nullptr, Ypanel);
@@ -1315,10 +1507,11 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
             const bool pb = prof && ntb > 0 && bq < 8 * XT_PROF_STRIDE && (bq % XT_PROF_STRIDE == 0);      // (no tile launch: its events would never be recorded)
             const int sl = bq / XT_PROF_STRIDE;
             if (g_xtb_fault_iter >= 0 && sharded && it >= g_xtb_fault_iter) { g_xtb_fault_iter = -1; local_fail = dkmc_fail(91, "injected fault (block-CG iteration)", __FILE__, __LINE__); }
-            product(pb ? evs[4 * sl] : nullptr, pb ? evs[4 * sl + 1] : nullptr);
+            if (pd > 0) product_pre(pb ? evs[4 * sl] : nullptr, pb ? evs[4 * sl + 1] : nullptr);
+            else product(pb ? evs[4 * sl] : nullptr, pb ? evs[4 * sl + 1] : nullptr);
             if (int rcx = rows(false, it, pb ? evs[4 * sl + 2] : nullptr, pb ? evs[4 * sl + 3] : nullptr)) return rcx;
             hipLaunchKernelGGL(k_xtb_gred, dim3(XB_NG * 16), dim3(XT_NT), 0, st, ng, (const double *)gpart, gfin, (const XCtrl *)A.ctrl);
-            hipLaunchKernelGGL(k_xtb_small, dim3(1), dim3(256), 0, st, it, s, (const double *)gfin, mats, A.ctrl, A.tol2);
+            hipLaunchKernelGGL(k_xtb_small, dim3(1), dim3(256), 0, st, it, s, (const double *)gfin, mats, A.ctrl, tol2_loop);
             hipLaunchKernelGGL(k_xtb_step, dim3(gs), dim3(XT_NT), 0, st, m, it, (const double *)mats, y0, R, P, (const double *)T, A.sc, A.nsrank, QS, (const XCtrl *)A.ctrl,
                                (const int *)nullptr, Ypanel);
         }
@@ -1331,6 +1524,26 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
     if (h.xchg_timeout) return dkmc_fail(48, "block-CG: the peer-write exchange timed out waiting for a peer's slot", __FILE__, __LINE__);
     if (h.aborted) return dkmc_fail(46, "a peer rank aborted the sharded current solve", __FILE__, __LINE__);
     if (e.err_code) return e.err_code;
+    bool again = false;
+    if (pd > 0) {
+        // y = y0 + L dh, then the TRUE residual of column 0 in the unpreconditioned system: one more pass over the tiles
+        HIPCHK(hipMemsetAsync(A.ctrl, 0, sizeof(XCtrl), st));                 // (the kernels below are gated by `done`)
+        hipLaunchKernelGGL(k_xtb_pre_col0, dim3((unsigned)((pan + 255) / 256)), dim3(256), 0, st, m, (const double *)y0, Zp);
+        applyL((const double *)Zp, Vp);
+        hipLaunchKernelGGL(k_xtb_pre_add, dim3((m + 255) / 256), dim3(256), 0, st, m, (const double *)Vp, A.y);
+        if (!h.pad[0]) {
+            hipLaunchKernelGGL(k_xtb_pre_col0, dim3((unsigned)((pan + 255) / 256)), dim3(256), 0, st, m, (const double *)A.y, P);
+            hipLaunchKernelGGL(k_xtb_qs_from, dim3((unsigned)((pan + 255) / 256)), dim3(256), 0, st, m, (const double *)P, A.sc, A.nsrank, QS, (const XCtrl *)A.ctrl);
+            product(nullptr, nullptr);
+            fold_rows(T);
+            hipLaunchKernelGGL(k_xtb_pre_rr, dim3(1), dim3(1024), 0, st, m, (const double *)T, A.b, bz + m);
+            double rr_true = 0.0;
+            HIPCHK(hipMemcpyAsync(&rr_true, bz + m, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            h.rr[h.iters & 1] = rr_true;
+            again = rr_true > A.tol2;
+        }
+    } else
     HIPCHK(hipMemcpyAsync(A.y, y0, (size_t)m * 8, hipMemcpyDeviceToDevice, st));
     if (keep_aux) hipLaunchKernelGGL(k_xtb_yaux_out, dim3((unsigned)((pan + 255) / 256)), dim3(256), 0, st, m, (const int *)nullptr, (const double *)Ypanel, A.sc, A.yaux);
     e.x_iter_hint = h.iters;
@@ -1340,7 +1553,8 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
         e.stats.spmv_long_ms = prof_long_ms; e.stats.spmv_short_ms = prof_short_ms;
         e.stats.spmv_long_launches = prof_long_n; e.stats.spmv_short_launches = prof_short_n;
     }
-    return h.pad[0] ? DKMC_XTB_BREAKDOWN : 0;
+    if (h.pad[0]) return DKMC_XTB_BREAKDOWN;
+    return again ? DKMC_XTB_AGAIN : 0;
 }
 
 #include "xtb_slab.inc"

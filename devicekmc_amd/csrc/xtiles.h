@@ -56,6 +56,7 @@ static inline int xt_grid(long long work, int per_block, int cap)
 }
 
 // ---- block-CG on the tiled X (xtb.hip) ----
+#define DKMC_XTB_AGAIN 1001          // xtb_cg_body (preconditioned solve): the true residual does not meet the stop test yet; y holds the iterate reached
 #define DKMC_XTB_BREAKDOWN 1000      // xtb_cg: an s x s system lost definiteness; y holds the last good iterate (not an error)
 struct XtbArgs {
     int m, ns, ns_pad, nK, nW;                    // system rows; |S|; padded |S|; row blocks; windows

@@ -64,6 +64,8 @@ SYMBOLS = {
     "dkmc_get_k_slab": (_I, []),
     "dkmc_xt_tile_census": (_I, [C.POINTER(C.c_longlong)]),
     "dkmc_set_x_items": (None, [_I]),
+    "dkmc_set_x_poly": (None, [_I]),
+    "dkmc_get_x_poly": (_I, []),
     "dkmc_set_x_apply_form": (None, [_I]),
     "dkmc_get_x_apply_form": (_I, []),
     "dkmc_set_x_slab": (None, [_I]),

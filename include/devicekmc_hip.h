@@ -149,6 +149,12 @@ int dkmc_get_x_block(void);
  * slab of the device: neighbour part, Gram pass and panel updates run on its rows only; per sweep the tile sums of the S rows go to their owners
  * (all-to-all-v), 6 x 256 Gram entries are all-gathered and added in rank order, the own rows of Q = S P and the halo rows of P go out
  * (all-to-all-v) (csrc/xtb_slab.inc).  0: the all-gather variant -- only the tile stream is sharded, everything else replicated. */
+/* Split polynomial preconditioner of the block-CG of the current solve (one GPU; csrc/xtb.hip): degree d > 0 runs the block loop on L A L with
+ * L = the degree-d truncation of the series of (I - N)^(-1/2), N = I - (neighbour part + diagonal of the Jacobi-scaled X).  A sweep then costs 2 d
+ * more sparse panel products and the loop needs 2-3x fewer sweeps (tools/precond_block_proto.py); the start vector enters through the right-hand
+ * side L (b - A y0), the result meets the reference's stop test in the TRUE residual (checked, the loop is re-entered if it does not).  0 = off (default). */
+void dkmc_set_x_poly(int degree);
+int dkmc_get_x_poly(void);
 void dkmc_set_x_slab(int on);
 int dkmc_get_x_slab(void);
 /* More than one rank, K system above the size of the blocked form (262 144 rows): 1 (default) distributes the CG on K (background potential, CB

@@ -52,7 +52,12 @@ def main():
     L_.okmc_atom_neighbors(o.N, o.nn, oc._p(o.neigh), Na, oc._p(atom_site), oc._p(an))
     rows = np.repeat(np.arange(Na), o.nn); cols = an.ravel(); keep = cols >= 0
     Pn = sp.csr_matrix((np.ones(keep.sum()), (rows[keep] + 2, cols[keep] + 2)), shape=(Na + 2, Na + 2))[:m, :m]
-    Pn = ((Pn + Pn.T) > 0).astype(np.float64).tolil(); Pn[0:2, :] = 1.0; Pn[:, 0:2] = 1.0; Pn.setdiag(1.0); Pn = Pn.tocsr()
+    Pn = ((Pn + Pn.T) > 0).astype(np.float64).tolil()
+    if not os.environ.get("NO_DRIVERS"):
+        Pn[0:2, :] = 1.0; Pn[:, 0:2] = 1.0
+    else:
+        Pn[0:2, :] = 0.0; Pn[:, 0:2] = 0.0                    # the two driver nodes' couplings stay outside the preconditioner
+    Pn.setdiag(1.0); Pn = Pn.tocsr()
     An = As.multiply(Pn).tocsr()
     N = (sp.identity(m, format="csr") - An).tocsr(); N.eliminate_zeros()
     ev = spl.eigsh(N, k=1, which="LA", return_eigenvectors=False)[0]

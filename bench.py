@@ -720,7 +720,10 @@ def main():
                        "start_vector_of_X": "previous step's solution (library default)" if sim.warm_start else "the reference code's G0-scaled buffer",
                        "cg_on_X": ("block-CG of width %d, tile x panel product on the matrix cores (csrc/xtb.hip)" % sim.x_block) if sim.x_block > 1
                                   else "single-vector CG in the reference's iterate order (csrc/xt.hip)",
-                       "x_aux_columns": ("smooth (lowest Laplacian modes of the bounding box / s)" if sim.host.get_stats()["xb_aux"] else "fixed-seed hash") if sim.x_block > 1 else None},
+                       "x_aux_columns": ("smooth (lowest Laplacian modes of the bounding box / s)" if sim.host.get_stats()["xb_aux"] else "fixed-seed hash") if sim.x_block > 1 else None,
+                       "x_poly": (("split polynomial preconditioner of degree %d on the neighbour part of X (library default; dkmc_set_x_poly): the block loop runs on L A L, "
+                                   "2 d sparse panel products per sweep, stop test checked on the TRUE residual" % sim.L.dkmc_get_x_poly())
+                                  if (sim.x_block > 1 and world == 1 and sim.L.dkmc_get_x_poly() > 0) else None)},
             "split_ms": res["split_ms"], "per_step": res["per_step"],
             "steady": {"steps": n, "ms_each": [round(t * 1e3, 1) for t, _ in sim.step_log], "cg_sweeps_X_each": [i for _, i in sim.step_log]},
             "cold_step": ({"ms": round(sim.cold[0] * 1e3, 1), "cg_sweeps_X": sim.cold[1],
@@ -731,8 +734,27 @@ def main():
         if n != args.steps:
             out["steps_requested"] = args.steps
         out.update(roofs)
+        # ---- the same simulation without the split polynomial preconditioner (dkmc_set_x_poly(0)): what it saves, and the baseline of the strong-scaling
+        # model below (the slab-distributed loop carries no preconditioner yet: the model compares plain loop with plain loop) ----
+        res_plain = None
+        pd_default = sim.L.dkmc_get_x_poly()
+        if sim.x_block > 1 and pd_default > 0 and not args.no_alt:
+            sim.L.dkmc_set_x_poly(0)
+            t0 = time.perf_counter(); itp = 0; npl = 2 if big else min(n, 5)
+            for _ in range(npl):
+                sim.step(False); itp += sim.host.get_stats()["cg_iters_X"]
+            tp = time.perf_counter() - t0
+            sim.L.dkmc_set_x_poly(pd_default)
+            res_plain = {"per_step": {"cg_iters_X": itp / npl}, "ms_per_step": round(tp / npl * 1e3, 3)}
+            out["plain_block_loop"] = {"x_poly": 0, "steps": npl, "value": round(npl / tp, 5), "ms_per_step": res_plain["ms_per_step"], "cg_sweeps_X": itp / npl,
+                                       "note": "the next %d steps of the same simulation with dkmc_set_x_poly(0): the block-CG on the Jacobi-scaled X as in round 4" % npl}
+            out["x_poly_gain"] = {"sweeps": round(itp / npl / max(res["per_step"]["cg_iters_X"], 1), 2), "steps_per_s": round(out["value"] / (npl / tp), 2),
+                                  "note": "ratio of different steps of one trajectory (the sweeps of a step follow its events): tools/ab_x_poly.py compares the same steps"}
         if big and sim.x_block > 1 and "roofline" in out and not args.no_scaling_model:
-            out["strong_scaling_model"] = strong_scaling_model_slabs(sim, res)
+            out["strong_scaling_model"] = strong_scaling_model_slabs(sim, res_plain or res)
+            if res_plain:
+                out["strong_scaling_model"]["baseline"] = ("the PLAIN block loop (plain_block_loop above): the slab-distributed loop has no split polynomial preconditioner "
+                                                           "yet, so the model compares plain with plain -- the preconditioned single-GPU step of this line is faster than its N = 1 row")
         # ---- same simulation from the reference code's start vector (dkmc_set_current_warm_start(0)): what the default's warm start saves ----
         if args.warm_start == 1 and not args.no_alt:
             sim.warm_start = 0

@@ -1337,8 +1337,34 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
         bz = Vp + pan;
         HIPCHK(hipMemsetAsync(bz, 0, (size_t)(m + 16) * 8, st));
     }
-    double pc[9]; pc[0] = 1.0;
-    for (int j = 1; j <= 8; ++j) pc[j] = pc[j - 1] * (double)(2 * j - 1) / (double)(2 * j);      // series of (1 - x)^(-1/2)
+    // coefficients of L = p(N), p ~ (1 - x)^(-1/2): the Chebyshev interpolant of degree d on [-1, 1 - delta], delta = min(0.5, 1.6 / d^2), in the monomial
+    // basis (Horner).  Against the Taylor series of the same degree -- which is exact at 0 and weakest where it matters, towards x -> 1 (the largest
+    // eigenvalue of N is 0.99994 at 9.4 k sites) -- the block loop needs a third fewer sweeps (85 k sites, d = 4: 34 -> 24, 95 without preconditioner).
+    double pc[9] = {1.0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (pd > 0) {
+        const int d = pd, n = d + 1;
+        const double a = -1.0, b = 1.0 - std::min(0.5, 1.6 / (double)(d * d));
+        double fx[9], c[9], pt[9] = {0}, Tm2[9] = {0}, Tm1[9] = {0};
+        for (int k = 0; k < n; ++k) { const double t = cos(M_PI * (k + 0.5) / n), x = 0.5 * (b - a) * t + 0.5 * (b + a); fx[k] = 1.0 / sqrt(1.0 - x); }
+        for (int j = 0; j < n; ++j) { double acc = 0.0; for (int k = 0; k < n; ++k) acc += fx[k] * cos(M_PI * j * (k + 0.5) / n); c[j] = acc * 2.0 / n; }
+        c[0] *= 0.5;
+        Tm2[0] = 1.0; Tm1[1] = 1.0;                                           // T_0, T_1 in powers of t
+        pt[0] += c[0]; pt[1] += c[1];
+        for (int j = 2; j <= d; ++j) {
+            double Tj[9];
+            for (int i = 0; i < 9; ++i) Tj[i] = (i >= 1 ? 2.0 * Tm1[i - 1] : 0.0) - Tm2[i];
+            for (int i = 0; i < 9; ++i) { pt[i] += c[j] * Tj[i]; Tm2[i] = Tm1[i]; Tm1[i] = Tj[i]; }
+        }
+        const double al = 2.0 / (b - a), be = -(a + b) / (b - a);             // t = al x + be
+        double res[9] = {0}; res[0] = pt[d]; int deg = 0;
+        for (int i = d - 1; i >= 0; --i) {
+            double nr[9] = {0};
+            for (int q = 0; q <= deg; ++q) { nr[q] += res[q] * be; nr[q + 1] += res[q] * al; }
+            ++deg; nr[0] += pt[i];
+            for (int q = 0; q < 9; ++q) res[q] = nr[q];
+        }
+        for (int q = 0; q <= d; ++q) pc[q] = res[q];
+    }
     const double tol2_loop = pd > 0 ? A.tol2 / 2.25 : A.tol2;                 // ||r|| <= 1.42 ||L r||: the loop stops a little early, the true residual is checked at the end
     HIPCHK(hipMemsetAsync(QS, 0, (size_t)A.ns_pad * XB_SP * 8, st));
     HIPCHK(hipMemsetAsync(rowpartB, 0, (size_t)(ncell + 1) * XT_R * so * 8, st));

@@ -23,7 +23,7 @@ def _library_defaults():
         L.dkmc_set_current_warm_start(1); L.dkmc_set_x_block(16); L.dkmc_set_x_format(1); L.dkmc_set_x_aux(2)
         L.dkmc_set_cg_tolerance(1e-6); L.dkmc_set_cb_edge_domain(0); L.dkmc_set_tcache_budget(-1); L.dkmc_set_pair_cutoff(6.5)
         L.dkmc_set_k_blocked(1); L.dkmc_set_profiling(0); L.dkmc_set_x_aux_warm(0); L.dkmc_set_x_slab(1); L.dkmc_set_k_slab(1)
-        L.dkmc_set_x_apply_form(0); L.dkmc_set_x_items(0); L.dkmc_set_x_poly(4)
+        L.dkmc_set_x_apply_form(0); L.dkmc_set_x_items(0); L.dkmc_set_x_poly(8)
     yield
 
 

@@ -419,7 +419,7 @@ def test_rccl_transport_one_rank():
         lib.load().dkmc_set_x_block(1)
         ref_t1 = _supersteps(1, fmt=1, big=True)
     finally:
-        lib.load().dkmc_set_x_block(16); lib.load().dkmc_set_x_poly(4)
+        lib.load().dkmc_set_x_block(16); lib.load().dkmc_set_x_poly(8)
     # one rank: the all-reduce is the identity and the exchange buffer holds the sums the one-GPU kernels form: same bits as without it, in both loops
     assert got_t[0] == ref_t[0] and got_t[1] == ref_t[1] and got_t[3]["spmv_tiles"] > 0 and got_t[3]["xb_width"] == 16
     assert got_t1[0] == ref_t1[0] and got_t1[1] == ref_t1[1] and got_t1[3]["xb_width"] == 1

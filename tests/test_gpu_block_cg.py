@@ -238,7 +238,7 @@ def test_split_polynomial_preconditioner_7p5(dev_7p5, hip):
             plain = _solve(dev, gb, p, hip, 16, tol)
             assert plain["width"] == 16 and plain["fallback"] == 0
             sweeps = {0: plain["iters"]}
-            for d in (1, 2, 4):
+            for d in (1, 2, 4, 8):
                 L.dkmc_set_x_poly(d)
                 a = _solve(dev, gb, p, hip, 16, tol)
                 # a start vector that is not zero (the preconditioned loop takes it into its right-hand side): the library's warm start from the solve
@@ -257,6 +257,6 @@ def test_split_polynomial_preconditioner_7p5(dev_7p5, hip):
                 # (at 1e-10 the true residual of a converged solve sits at its rounding floor, ~1e-9 -- see test_block_cg_agrees_with_single_vector_cg_7p5 --
                 # above the tolerance: a re-solve then iterates again, with or without the preconditioner)
                 if tol >= 1e-6: assert b["iters"] <= 3, (tol, d, b["iters"])
-            assert sweeps[4] < sweeps[2] < sweeps[1] < sweeps[0] and 2 * sweeps[4] < sweeps[0], sweeps
+            assert sweeps[8] < sweeps[4] < sweeps[2] < sweeps[1] < sweeps[0] and 3 * sweeps[8] < sweeps[0], sweeps
     finally:
-        L.dkmc_set_x_block(16); L.dkmc_set_x_format(1); L.dkmc_set_cg_tolerance(1e-6); L.dkmc_set_x_poly(4); L.dkmc_set_current_warm_start(1)
+        L.dkmc_set_x_block(16); L.dkmc_set_x_format(1); L.dkmc_set_cg_tolerance(1e-6); L.dkmc_set_x_poly(8); L.dkmc_set_current_warm_start(1)

@@ -52,7 +52,7 @@ int dkmc_get_k_slab(void) { return eng().k_slab; }
 void dkmc_set_x_aux_warm(int on) { eng().x_aux_warm = on ? 1 : 0; }
 int dkmc_get_x_aux_warm(void) { return eng().x_aux_warm; }
 void dkmc_set_x_items(int kc) { eng().x_items_kc = kc > 0 ? (kc < 256 ? kc : 256) : 0; }
-void dkmc_set_x_poly(int degree) { eng().x_poly = degree < 0 ? 0 : (degree > 8 ? 8 : degree); }
+void dkmc_set_x_poly(int degree) { eng().x_poly = degree < 0 ? 0 : (degree > 16 ? 16 : degree); }
 int dkmc_get_x_poly(void) { return eng().x_poly; }
 void dkmc_set_x_apply_form(int form) { eng().x_apply_form = form == 1 ? 1 : 0; }
 int dkmc_get_x_apply_form(void) { return eng().x_apply_form; }

@@ -44,6 +44,7 @@
 #include <vector>
 
 #define XB_SP 16                      // vectors per panel row (padded block width)
+#define XB_MAXPOLY 16                 // largest degree of the split polynomial preconditioner (dkmc_set_x_poly)
 #define XB_DSPLIT 8                   // workgroups per driver row of Xs
 #define XB_NG 6                       // Gram matrices per pass: P'T, P'R, T'R, T'T, R'R, P'P
 typedef double dbl4 __attribute__((ext_vector_type(4)));
@@ -1328,7 +1329,7 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
     double *mats = small, *drvpart = small + 4 * 256, *gfin = drvpart + 2 * XB_DSPLIT * XB_SP;
     // split polynomial preconditioner (dkmc_set_x_poly; one GPU): see k_xtb_nmul.  Vp = L P, Zp = A Vp before the second L, W1 / W2 the Horner steps;
     // behind Vp: m zeros (the right-hand side of column 0 once the start vector has gone into it) and one double for the true residual
-    const int pd = (!A.sharded && m > 2 && A.ns > 0) ? e.x_poly : 0;
+    const int pd = (!A.sharded && m > 2 && A.ns > 0) ? std::min(e.x_poly, XB_MAXPOLY) : 0;
     double *Vp = nullptr, *W1 = nullptr, *W2 = nullptr, *Zp = nullptr, *bz = nullptr;
     if (pd > 0) {
         Vp = (double *)scratch(S_XTB_PRE_V, (pan + m + 16) * 8); W1 = (double *)scratch(S_XTB_PRE_W1, pan * 8); W2 = (double *)scratch(S_XTB_PRE_W2, pan * 8);
@@ -1340,28 +1341,28 @@ static int xtb_cg_body(const XtbArgs &A, int *iters_out, double *rr_out, bool *p
     // coefficients of L = p(N), p ~ (1 - x)^(-1/2): the Chebyshev interpolant of degree d on [-1, 1 - delta], delta = min(0.5, 1.6 / d^2), in the monomial
     // basis (Horner).  Against the Taylor series of the same degree -- which is exact at 0 and weakest where it matters, towards x -> 1 (the largest
     // eigenvalue of N is 0.99994 at 9.4 k sites) -- the block loop needs a third fewer sweeps (85 k sites, d = 4: 34 -> 24, 95 without preconditioner).
-    double pc[9] = {1.0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double pc[XB_MAXPOLY + 1] = {1.0};
     if (pd > 0) {
         const int d = pd, n = d + 1;
         const double a = -1.0, b = 1.0 - std::min(0.5, 1.6 / (double)(d * d));
-        double fx[9], c[9], pt[9] = {0}, Tm2[9] = {0}, Tm1[9] = {0};
+        double fx[XB_MAXPOLY + 1], c[XB_MAXPOLY + 1], pt[XB_MAXPOLY + 1] = {0}, Tm2[XB_MAXPOLY + 1] = {0}, Tm1[XB_MAXPOLY + 1] = {0};
         for (int k = 0; k < n; ++k) { const double t = cos(M_PI * (k + 0.5) / n), x = 0.5 * (b - a) * t + 0.5 * (b + a); fx[k] = 1.0 / sqrt(1.0 - x); }
         for (int j = 0; j < n; ++j) { double acc = 0.0; for (int k = 0; k < n; ++k) acc += fx[k] * cos(M_PI * j * (k + 0.5) / n); c[j] = acc * 2.0 / n; }
         c[0] *= 0.5;
         Tm2[0] = 1.0; Tm1[1] = 1.0;                                           // T_0, T_1 in powers of t
         pt[0] += c[0]; pt[1] += c[1];
         for (int j = 2; j <= d; ++j) {
-            double Tj[9];
-            for (int i = 0; i < 9; ++i) Tj[i] = (i >= 1 ? 2.0 * Tm1[i - 1] : 0.0) - Tm2[i];
-            for (int i = 0; i < 9; ++i) { pt[i] += c[j] * Tj[i]; Tm2[i] = Tm1[i]; Tm1[i] = Tj[i]; }
+            double Tj[XB_MAXPOLY + 1];
+            for (int i = 0; i <= XB_MAXPOLY; ++i) Tj[i] = (i >= 1 ? 2.0 * Tm1[i - 1] : 0.0) - Tm2[i];
+            for (int i = 0; i <= XB_MAXPOLY; ++i) { pt[i] += c[j] * Tj[i]; Tm2[i] = Tm1[i]; Tm1[i] = Tj[i]; }
         }
         const double al = 2.0 / (b - a), be = -(a + b) / (b - a);             // t = al x + be
-        double res[9] = {0}; res[0] = pt[d]; int deg = 0;
+        double res[XB_MAXPOLY + 2] = {0}; res[0] = pt[d]; int deg = 0;
         for (int i = d - 1; i >= 0; --i) {
-            double nr[9] = {0};
+            double nr[XB_MAXPOLY + 2] = {0};
             for (int q = 0; q <= deg; ++q) { nr[q] += res[q] * be; nr[q + 1] += res[q] * al; }
             ++deg; nr[0] += pt[i];
-            for (int q = 0; q < 9; ++q) res[q] = nr[q];
+            for (int q = 0; q <= XB_MAXPOLY + 1; ++q) res[q] = nr[q];
         }
         for (int q = 0; q <= d; ++q) pc[q] = res[q];
     }

@@ -976,6 +976,9 @@ def main():
                                            "one simulation; X generated/stored/streamed in %d per-rank shares, one exchange of 16 |S| + 2 doubles per block-CG sweep, slots added in rank order (all-gather variant)"
                                            if sharded else "replicas x%d") % world,
                            "x_slab": int(sim.L.dkmc_get_x_slab()) if sharded else None,
+                           "x_poly": ("none: the sharded / slab-distributed block loops do not carry the split polynomial preconditioner of the one-GPU loop yet (dkmc_set_x_poly, "
+                                      "degree 8 there, ~3.5x fewer seconds per step at 9.4e5 sites) -- an N-rank run of this round is compared with the PLAIN one-GPU loop, "
+                                      "not with the N = 1 line of bench.py") if sharded else None,
                            "exchange": ("peer-write over hipIpc-mapped buffers (opt-in, all-gather variant)" if peer_on else "all-to-all-v + all-gather of the transport (slab-distributed block-CG)") if sharded else None,
                            "transport": transport, "transport_note": transport_note, "x_format": "tiled", "current_warm_start": sim.warm_start, "cg_tol": sim.p.cg_tol,
                            "comm_ranks": min(i[0] for i in infos), "comm_rank_ids": sorted(i[1] for i in infos),
